@@ -1,0 +1,157 @@
+"""ctypes binding of libfvit_hip.so (C ABI declared in include/fvit_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the HIP library is missing or fails to
+load, everything that needs it raises RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "libfvit_hip.so")
+
+FVIT_ABI_VERSION = 1
+FVIT_F32, FVIT_F16, FVIT_BF16 = 0, 1, 2
+FVIT_TILE_N, FVIT_TILE_K = 128, 64
+FVIT_MASK_BIAS = -30000.0
+FVIT_PROF_KINDS = 8
+
+# every symbol include/fvit_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTED_SYMBOLS = (
+    "fvit_abi_version", "fvit_last_error", "fvit_attention_spad", "fvit_stage_workspace_bytes",
+    "fvit_workspace_init", "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_window_partition",
+    "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_window_attention",
+    "fvit_gather_layernorm", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_kind_name",
+)
+
+
+class FvitStageDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "C", "heads", "dpad", "ws", "H", "W", "Hp", "Wp", "cw", "hier", "square", "hidden",
+        "depth", "do_propagation", "operand_dtype", "spad", "gpad")]
+
+
+class FvitAttnWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_qkv", "b_qkv", "w_proj", "b_proj", "bias", "ln_w", "ln_b", "gamma")]
+
+
+class FvitMlpWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_fc1", "b_fc1", "w_fc2", "b_fc2", "ln_w", "ln_b", "gamma")]
+
+
+class FvitBlockWeights(C.Structure):
+    _fields_ = [("attn", FvitAttnWeights), ("mlp", FvitMlpWeights), ("hat_attn", FvitAttnWeights),
+                ("hat_mlp", FvitMlpWeights), ("pe_x", C.c_void_p), ("pe_ct", C.c_void_p),
+                ("last", C.c_int32), ("_pad", C.c_int32)]
+
+
+class FvitStageTables(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_src", "ln1_add", "ct_src", "up_idx")]
+
+
+class FvitMapView(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride_b", C.c_int64), ("stride_c", C.c_int64), ("stride_h", C.c_int64),
+                ("stride_w", C.c_int64), ("dtype", C.c_int32), ("_pad", C.c_int32)]
+
+
+class FvitProfEntry(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libfvit_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j4"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose:
+        print(res.stdout)
+    if res.returncode != 0 or not os.path.isfile(LIB_PATH):
+        raise RuntimeError("building libfvit_hip.so failed:\n" + res.stdout)
+    return LIB_PATH
+
+
+def _declare(lib):
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    lib.fvit_abi_version.restype = C.c_int
+    lib.fvit_last_error.restype = C.c_char_p
+    lib.fvit_attention_spad.restype = C.c_int
+    lib.fvit_attention_spad.argtypes = [i32]
+    lib.fvit_stage_workspace_bytes.restype = C.c_size_t
+    lib.fvit_stage_workspace_bytes.argtypes = [C.POINTER(FvitStageDesc)]
+    lib.fvit_workspace_init.restype = C.c_int
+    lib.fvit_workspace_init.argtypes = [C.POINTER(FvitStageDesc), vp, C.c_size_t, vp]
+    lib.fvit_hat_stage_forward.restype = C.c_int
+    lib.fvit_hat_stage_forward.argtypes = [C.POINTER(FvitStageDesc), C.POINTER(FvitBlockWeights),
+                                           C.POINTER(FvitStageTables), C.POINTER(FvitMapView), vp,
+                                           C.POINTER(FvitMapView), vp, C.c_size_t, vp]
+    lib.fvit_hat_block_forward.restype = C.c_int
+    lib.fvit_hat_block_forward.argtypes = [C.POINTER(FvitStageDesc), C.POINTER(FvitBlockWeights),
+                                           C.POINTER(FvitStageTables), vp, vp, vp, C.c_size_t, vp]
+    lib.fvit_window_partition.restype = C.c_int
+    lib.fvit_window_partition.argtypes = [C.POINTER(FvitMapView), i32, i32, i32, i32, i32, vp, vp]
+    lib.fvit_window_reverse.restype = C.c_int
+    lib.fvit_window_reverse.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(FvitMapView), vp]
+    lib.fvit_gemm_bias_act.restype = C.c_int
+    lib.fvit_gemm_bias_act.argtypes = [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.fvit_gemm_residual.restype = C.c_int
+    lib.fvit_gemm_residual.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fvit_window_attention.restype = C.c_int
+    lib.fvit_window_attention.argtypes = [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, vp]
+    lib.fvit_gather_layernorm.restype = C.c_int
+    lib.fvit_gather_layernorm.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, f32, i32, i32, i32, vp]
+    lib.fvit_prof_enable.restype = C.c_int
+    lib.fvit_prof_enable.argtypes = [C.c_int]
+    lib.fvit_prof_collect.restype = C.c_int
+    lib.fvit_prof_collect.argtypes = [C.POINTER(FvitProfEntry)]
+    lib.fvit_prof_kind_name.restype = C.c_char_p
+    lib.fvit_prof_kind_name.argtypes = [C.c_int]
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises RuntimeError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the FasterViT HAT path has no CPU/eager fallback. Build it with "
+            "`make -C fastervit_amd/csrc -j` (or `python -c 'import __graft_entry__ as g; g.build()'`).")
+    try:
+        handle = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    missing = [s for s in EXPORTED_SYMBOLS if not hasattr(handle, s)]
+    if missing:
+        raise RuntimeError(f"{LIB_PATH} lacks symbols {missing}; rebuild it")
+    _declare(handle)
+    if handle.fvit_abi_version() != FVIT_ABI_VERSION:
+        raise RuntimeError(f"ABI mismatch: library {handle.fvit_abi_version()} vs binding {FVIT_ABI_VERSION}")
+    _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().fvit_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def prof_enable(on: bool) -> None:
+    check(lib().fvit_prof_enable(1 if on else 0), "fvit_prof_enable")
+
+
+def prof_collect() -> dict:
+    """Return {kind_name: dict(launches, ms, flops, bytes)} for the launches since prof_enable(True)."""
+    arr = (FvitProfEntry * FVIT_PROF_KINDS)()
+    check(lib().fvit_prof_collect(arr), "fvit_prof_collect")
+    out = {}
+    for k in range(FVIT_PROF_KINDS):
+        e = arr[k]
+        out[lib().fvit_prof_kind_name(k).decode()] = dict(launches=int(e.launches), ms=float(e.ms), flops=float(e.flops),
+                                                         bytes=float(e.bytes))
+    return out

@@ -1,0 +1,370 @@
+// fvit_api.hip -- C ABI of libfvit_hip.so (see include/fvit_hip.h) and the host-side sequencing of
+// one HAT stage: workspace layout, per-block launch order, error plumbing, kernel timer.
+//
+// The launch order of one block follows HAT.forward (AR:668-707 / FV:662-701):
+//   carrier branch (hier only)  : gather(ct_dewindow)+pe+LN -> qkv -> attention -> proj+res
+//                                 -> LN -> fc1+GELU -> fc2+res
+//   window branch               : gather(cat(ct_window(ct), x+pe))+LN -> qkv -> attention -> proj+res
+//                                 -> LN -> fc1+GELU -> fc2+res
+// The fp32 residual stream X holds the carrier tokens of every window in front of its ws^2 local
+// tokens for the whole stage, so torch.cat / split (AR:693,701) cost nothing.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "fvit_common.h"
+
+namespace fvit {
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return FVIT_ELAUNCH;
+    }
+    return FVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel timer: an event pair around every launch, on the launch stream
+// ------------------------------------------------------------------------------------------
+struct ProfRec {
+    int kind;
+    double flops, bytes;
+};
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_events;  // 2 per record
+static std::vector<ProfRec> g_recs;
+
+ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t stream) : slot_(-1), stream_(stream) {
+    if (!g_prof_on) return;
+    slot_ = (int)g_recs.size();
+    while ((int)g_events.size() < 2 * (slot_ + 1)) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { slot_ = -1; return; }
+        g_events.push_back(e);
+    }
+    g_recs.push_back({kind, flops, bytes});
+    hipEventRecord(g_events[2 * slot_], stream_);
+}
+
+ProfScope::~ProfScope() {
+    if (slot_ >= 0) hipEventRecord(g_events[2 * slot_ + 1], stream_);
+}
+
+// ------------------------------------------------------------------------------------------
+// stage workspace layout
+// ------------------------------------------------------------------------------------------
+extern "C" int fvit_attention_spad(int32_t S);
+
+struct StageLayout {
+    int nW, nloc, ncw, S, G;
+    int64_t Mx, Mc;          // window-tensor rows, carrier rows
+    int ldn, ldqkv, ldao, ldh;
+    size_t off_X, off_Xn, off_QKV, off_AO, off_H, off_R, off_Rn, off_RQKV, off_RAO, off_RH, total;
+};
+
+static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
+    if (d.batch <= 0 || d.C <= 0 || d.heads <= 0 || d.C % d.heads || d.ws <= 0 || d.Hp % d.ws || d.Wp % d.ws ||
+        (d.dpad != 32 && d.dpad != 64) || d.dpad < d.C / d.heads || d.hidden <= 0 || (d.C % 16) || (d.hidden % 16) ||
+        (d.operand_dtype != FVIT_F16 && d.operand_dtype != FVIT_BF16) || (d.hier && d.cw <= 0)) {
+        set_error("stage descriptor rejected: batch=%d C=%d heads=%d dpad=%d ws=%d Hp=%d Wp=%d hidden=%d hier=%d cw=%d dtype=%d",
+                  d.batch, d.C, d.heads, d.dpad, d.ws, d.Hp, d.Wp, d.hidden, d.hier, d.cw, d.operand_dtype);
+        return false;
+    }
+    L.nW = (d.Hp / d.ws) * (d.Wp / d.ws);
+    L.nloc = d.ws * d.ws;
+    L.ncw = d.hier ? d.cw * d.cw : 0;
+    L.S = L.nloc + L.ncw;
+    L.G = L.ncw * L.nW;
+    L.Mx = (int64_t)d.batch * L.nW * L.S;
+    L.Mc = (int64_t)d.batch * L.G;
+    L.ldn = round_up(d.C, FVIT_TILE_K);
+    L.ldqkv = 3 * d.heads * d.dpad;
+    L.ldao = round_up(d.heads * d.dpad, FVIT_TILE_K);
+    L.ldh = round_up(d.hidden, FVIT_TILE_K);
+    const int64_t Mxp = round_up64(L.Mx, 128), Mcp = round_up64(L.Mc, 128);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    L.off_X = take((size_t)L.Mx * d.C * 4);
+    L.off_Xn = take((size_t)Mxp * L.ldn * 2);
+    L.off_QKV = take((size_t)Mxp * L.ldqkv * 2);
+    L.off_AO = take((size_t)Mxp * L.ldao * 2);
+    L.off_H = take((size_t)Mxp * L.ldh * 2);
+    if (d.hier) {
+        L.off_R = take((size_t)L.Mc * d.C * 4);
+        L.off_Rn = take((size_t)Mcp * L.ldn * 2);
+        L.off_RQKV = take((size_t)Mcp * L.ldqkv * 2);
+        L.off_RAO = take((size_t)Mcp * L.ldao * 2);
+        L.off_RH = take((size_t)Mcp * L.ldh * 2);
+    } else {
+        L.off_R = L.off_Rn = L.off_RQKV = L.off_RAO = L.off_RH = 0;
+    }
+    L.total = off;
+    const int want_s = fvit_attention_spad(L.S), want_g = d.hier ? fvit_attention_spad(L.G) : d.gpad;
+    if (d.spad != want_s || d.gpad != want_g) {
+        set_error("stage descriptor: spad/gpad %d/%d do not match fvit_attention_spad (%d/%d)", d.spad, d.gpad, want_s, want_g);
+        return false;
+    }
+    return true;
+}
+
+#define FVIT_TRY(expr)            \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != FVIT_OK) return rc__; \
+    } while (0)
+
+// LN -> qkv -> attention -> proj + gamma-residual, on `rows` rows of the f32 stream `x`
+static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttnWeights& w, float* x, int64_t rows, void* xn,
+                    void* qkv, void* ao, int nwin, int S, bool ln_done, hipStream_t st) {
+    const int dt = d.operand_dtype;
+    if (!ln_done) {
+        LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
+        FVIT_TRY(launch_gather_layernorm(ln, st));
+    }
+    GemmCall g1 = {dt, xn, L.ldn, w.w_qkv, L.ldn, w.b_qkv, nullptr, qkv, L.ldqkv, (int)rows, L.ldqkv, L.ldn, 0};
+    FVIT_TRY(launch_gemm(g1, st));
+    const float scale = 1.0f / sqrtf((float)(d.C / d.heads));
+    AttnCall at = {dt, qkv, L.ldqkv, ao, L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale};
+    FVIT_TRY(launch_attention(at, st));
+    GemmCall g2 = {dt, ao, L.ldao, w.w_proj, L.ldao, w.b_proj, w.gamma, x, d.C, (int)rows, d.C, L.ldao, 2};
+    FVIT_TRY(launch_gemm(g2, st));
+    return FVIT_OK;
+}
+
+// LN -> fc1 + GELU -> fc2 + gamma-residual
+static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWeights& w, float* x, int64_t rows, void* xn, void* h,
+                   hipStream_t st) {
+    const int dt = d.operand_dtype;
+    LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
+    FVIT_TRY(launch_gather_layernorm(ln, st));
+    GemmCall g1 = {dt, xn, L.ldn, w.w_fc1, L.ldn, w.b_fc1, nullptr, h, L.ldh, (int)rows, d.hidden, L.ldn, 1};
+    FVIT_TRY(launch_gemm(g1, st));
+    GemmCall g2 = {dt, h, L.ldh, w.w_fc2, L.ldh, w.b_fc2, w.gamma, x, d.C, (int)rows, d.C, L.ldh, 2};
+    FVIT_TRY(launch_gemm(g2, st));
+    return FVIT_OK;
+}
+
+static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlockWeights& w, const FvitStageTables& t, char* ws,
+                     hipStream_t st) {
+    const int dt = d.operand_dtype;
+    float* X = (float*)(ws + L.off_X);
+    void* Xn = ws + L.off_Xn;
+    void* QKV = ws + L.off_QKV;
+    void* AO = ws + L.off_AO;
+    void* Hb = ws + L.off_H;
+    float* R = (float*)(ws + L.off_R);
+    const int rpi = L.nW * L.S;  // window-tensor rows per image
+    if (d.hier) {
+        void* Rn = ws + L.off_Rn;
+        void* RQKV = ws + L.off_RQKV;
+        void* RAO = ws + L.off_RAO;
+        void* RH = ws + L.off_RH;
+        // ct_dewindow gather (+ hat_pos_embed) -> R, LN(hat_norm1) -> Rn
+        LnCall ln = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), R, Rn, L.ldn,
+                     w.hat_attn.ln_w, w.hat_attn.ln_b, 1e-5f, (int)L.Mc, L.G, d.C};
+        FVIT_TRY(launch_gather_layernorm(ln, st));
+        FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st));
+        FVIT_TRY(run_mlp(d, L, w.hat_mlp, R, L.Mc, Rn, RH, st));
+    }
+    // cat(ct_window(ct), x + pos_embed) gather -> X, LN(norm1) -> Xn
+    LnCall ln1 = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, X, Xn, L.ldn,
+                  w.attn.ln_w, w.attn.ln_b, 1e-5f, (int)L.Mx, rpi, d.C};
+    FVIT_TRY(launch_gather_layernorm(ln1, st));
+    FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st));
+    FVIT_TRY(run_mlp(d, L, w.mlp, X, L.Mx, Xn, Hb, st));
+    return FVIT_OK;
+}
+
+static bool check_tables(const FvitStageDesc& d, const FvitStageTables* t) {
+    if (!t || !t->ln1_add || (d.hier && (!t->ln1_src || !t->ct_src)) || (d.hier && d.do_propagation && !t->up_idx)) {
+        set_error("stage tables missing (ln1_add%s)", d.hier ? ", ln1_src, ct_src, up_idx" : "");
+        return false;
+    }
+    return true;
+}
+
+}  // namespace fvit
+
+using namespace fvit;
+
+extern "C" {
+
+int fvit_abi_version(void) { return FVIT_ABI_VERSION; }
+const char* fvit_last_error(void) { return g_err; }
+
+int fvit_attention_spad(int32_t S) {
+    int sb = (S + 15) / 16;
+    if (sb == 9) sb = 10;
+    if (sb == 11 || sb == 12) sb = 13;
+    return sb * 16;
+}
+
+size_t fvit_stage_workspace_bytes(const FvitStageDesc* desc) {
+    StageLayout L;
+    if (!desc || !make_layout(*desc, L)) return 0;
+    return L.total;
+}
+
+int fvit_workspace_init(const FvitStageDesc* desc, void* workspace, size_t bytes, fvit_stream_t stream) {
+    StageLayout L;
+    if (!desc || !make_layout(*desc, L)) return FVIT_EINVAL;
+    if (!workspace || bytes < L.total) {
+        set_error("workspace too small: %zu < %zu", bytes, L.total);
+        return FVIT_EWORKSPACE;
+    }
+    if (hipMemsetAsync(workspace, 0, L.total, (hipStream_t)stream) != hipSuccess) return check_launch("workspace memset");
+    return FVIT_OK;
+}
+
+int fvit_hat_stage_forward(const FvitStageDesc* desc, const FvitBlockWeights* blocks, const FvitStageTables* tables,
+                           const FvitMapView* in, const float* ct_init, const FvitMapView* out, void* workspace,
+                           size_t workspace_bytes, fvit_stream_t stream) {
+    StageLayout L;
+    if (!desc || !blocks || !in || !out || !make_layout(*desc, L)) {
+        if (!desc || !blocks || !in || !out) set_error("null argument");
+        return FVIT_EINVAL;
+    }
+    const FvitStageDesc& d = *desc;
+    if (!check_tables(d, tables)) return FVIT_EINVAL;
+    if (!workspace || workspace_bytes < L.total) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes, L.total);
+        return FVIT_EWORKSPACE;
+    }
+    if (d.hier && !ct_init) {
+        set_error("hierarchical stage needs ct_init");
+        return FVIT_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* X = (float*)(ws + L.off_X);
+    PartitionCall pc = {*in, d.batch, d.C, d.Hp, d.Wp, d.ws, X, L.S, L.ncw, d.hier ? ct_init : nullptr, L.ncw};
+    FVIT_TRY(launch_partition(pc, st));
+    for (int i = 0; i < d.depth; ++i) FVIT_TRY(run_block(d, L, blocks[i], *tables, ws, st));
+    const bool prop = d.hier && d.do_propagation && d.depth > 0 && blocks[d.depth - 1].last;
+    ReverseCall rc = {X, L.S, L.ncw, d.batch, d.C, d.Hp, d.Wp, d.H, d.W, d.ws, *out,
+                      prop ? blocks[d.depth - 1].hat_attn.gamma : nullptr, prop ? tables->up_idx : nullptr};
+    FVIT_TRY(launch_reverse(rc, st));
+    return FVIT_OK;
+}
+
+int fvit_hat_block_forward(const FvitStageDesc* desc, const FvitBlockWeights* block, const FvitStageTables* tables, float* x,
+                           float* ct, void* workspace, size_t workspace_bytes, fvit_stream_t stream) {
+    StageLayout L;
+    if (!desc || !block || !x || !make_layout(*desc, L)) {
+        if (!desc || !block || !x) set_error("null argument");
+        return FVIT_EINVAL;
+    }
+    const FvitStageDesc& d = *desc;
+    if (!check_tables(d, tables)) return FVIT_EINVAL;
+    if (!workspace || workspace_bytes < L.total) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes, L.total);
+        return FVIT_EWORKSPACE;
+    }
+    if (d.hier && !ct) {
+        set_error("hierarchical block needs carrier tokens");
+        return FVIT_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* X = (float*)(ws + L.off_X);
+    const int nwin = d.batch * L.nW;
+    FVIT_TRY(launch_ct_copy(X, L.S, L.ncw, L.nloc, x, nwin, d.C, 1, st));
+    if (d.hier) FVIT_TRY(launch_ct_copy(X, L.S, 0, L.ncw, ct, nwin, d.C, 1, st));
+    FVIT_TRY(run_block(d, L, *block, *tables, ws, st));
+    if (d.hier && block->last && d.do_propagation)
+        FVIT_TRY(launch_propagate(X, block->hat_attn.gamma, tables->up_idx, L.S, L.ncw, L.nloc, nwin, d.C, st));
+    FVIT_TRY(launch_ct_copy(X, L.S, L.ncw, L.nloc, x, nwin, d.C, 0, st));
+    if (d.hier) FVIT_TRY(launch_ct_copy(X, L.S, 0, L.ncw, ct, nwin, d.C, 0, st));
+    return FVIT_OK;
+}
+
+int fvit_window_partition(const FvitMapView* in, int32_t batch, int32_t C, int32_t Hp, int32_t Wp, int32_t ws, float* windows,
+                          fvit_stream_t stream) {
+    if (!in || !windows) { set_error("null argument"); return FVIT_EINVAL; }
+    PartitionCall pc = {*in, batch, C, Hp, Wp, ws, windows, ws * ws, 0, nullptr, 0};
+    return launch_partition(pc, (hipStream_t)stream);
+}
+
+int fvit_window_reverse(const float* windows, int32_t batch, int32_t C, int32_t Hp, int32_t Wp, int32_t H, int32_t W, int32_t ws,
+                        const FvitMapView* out, fvit_stream_t stream) {
+    if (!out || !windows) { set_error("null argument"); return FVIT_EINVAL; }
+    ReverseCall rc = {windows, ws * ws, 0, batch, C, Hp, Wp, H, W, ws, *out, nullptr, nullptr};
+    return launch_reverse(rc, (hipStream_t)stream);
+}
+
+int fvit_gemm_bias_act(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias, void* out,
+                       int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, fvit_stream_t stream) {
+    GemmCall g = {operand_dtype, A, lda, Wt, ldw, bias, nullptr, out, ldo, M, N, K, act ? 1 : 0};
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+int fvit_gemm_residual(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias,
+                       const float* gamma, float* x, int32_t ldx, int32_t M, int32_t N, int32_t K, fvit_stream_t stream) {
+    GemmCall g = {operand_dtype, A, lda, Wt, ldw, bias, gamma, x, ldx, M, N, K, 2};
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+int fvit_window_attention(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, const float* bias,
+                          int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale, fvit_stream_t stream) {
+    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, bias, nwin, S, heads, dpad, scale};
+    return launch_attention(a, (hipStream_t)stream);
+}
+
+int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB,
+                          const int32_t* src_idx, const int32_t* add_idx, const float* add, float* x_out, void* n_out, int32_t ldn,
+                          const float* ln_w, const float* ln_b, float eps, int32_t rows, int32_t rows_per_image, int32_t C,
+                          fvit_stream_t stream) {
+    LnCall c = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, x_out, n_out, ldn, ln_w, ln_b, eps, rows,
+                rows_per_image, C};
+    return launch_gather_layernorm(c, (hipStream_t)stream);
+}
+
+int fvit_prof_enable(int on) {
+    g_prof_on = on != 0;
+    if (g_prof_on) g_recs.clear();
+    return FVIT_OK;
+}
+
+int fvit_prof_collect(FvitProfEntry* out) {
+    if (!out) return FVIT_EINVAL;
+    memset(out, 0, sizeof(FvitProfEntry) * FVIT_PROF_KINDS);
+    for (size_t i = 0; i < g_recs.size(); ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_events[2 * i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_events[2 * i], g_events[2 * i + 1]) != hipSuccess) {
+            set_error("profiler: event read failed (was the region captured into a graph?)");
+            (void)hipGetLastError();
+            return FVIT_ELAUNCH;
+        }
+        const ProfRec& r = g_recs[i];
+        FvitProfEntry& e = out[r.kind < 0 || r.kind >= FVIT_PROF_KINDS ? FVIT_K_OTHER : r.kind];
+        e.launches += 1;
+        e.ms += ms;
+        e.flops += r.flops;
+        e.bytes += r.bytes;
+    }
+    return FVIT_OK;
+}
+
+const char* fvit_prof_kind_name(int kind) {
+    static const char* names[FVIT_PROF_KINDS] = {"window_partition", "gather_layernorm", "gemm_bias", "gemm_gelu",
+                                                 "gemm_residual",    "window_attention", "window_reverse", "other"};
+    return (kind >= 0 && kind < FVIT_PROF_KINDS) ? names[kind] : "?";
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+// Internal header shared by the HIP translation units of libfvit_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/fvit_hip.h"
+
+namespace fvit {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// 16-bit MFMA operand traits: fp16 (default) or bf16, fp32 accumulate.
+template <typename T> struct Op16;
+template <> struct Op16<_Float16> {
+    typedef h8 v8;
+    typedef h4 v4;
+    static __device__ __forceinline__ f4 mfma(v8 a, v8 b, f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Op16<__bf16> {
+    typedef b8 v8;
+    typedef b4 v4;
+    static __device__ __forceinline__ f4 mfma(v8 a, v8 b, f4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+__host__ __device__ constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- error plumbing (thread-local message, negative return codes) ----
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- built-in kernel timer ----
+struct ProfScope {
+    ProfScope(int kind, double flops, double bytes, hipStream_t stream);
+    ~ProfScope();
+    int slot_;
+    hipStream_t stream_;
+};
+
+// ---- launchers (defined in the .hip files) ----
+struct GemmCall {
+    int dtype;           // FVIT_F16 / FVIT_BF16
+    const void* A;       // activations op16 [pad128(M)][lda]
+    int lda;
+    const void* W;       // weights op16 [pad128(N)][ldw]
+    int ldw;
+    const float* bias;   // [N] or null
+    const float* gamma;  // [N] or null (residual epilogue only)
+    void* out;           // op16 [..][ldo] (bias / gelu) or f32 x [..][ldo] (residual)
+    int ldo;
+    int M, N, K;
+    int epilogue;        // 0 bias, 1 bias+gelu, 2 gamma-residual into f32
+};
+int launch_gemm(const GemmCall& c, hipStream_t stream);
+
+struct AttnCall {
+    int dtype;
+    const void* qkv;  // op16 [rows][ldq], columns [q|k|v][head][dpad]
+    int ldq;
+    void* out;        // op16 [rows][ldo], columns [head][dpad]
+    int ldo;
+    const float* bias;  // f32 [heads][Spad][Spad]
+    int nwin, S, heads, dpad;
+    float scale;
+};
+int launch_attention(const AttnCall& c, hipStream_t stream);
+
+struct LnCall {
+    int dtype;
+    const float* srcA;
+    int rowsA;
+    const float* srcB;
+    int rowsB;
+    const int32_t* src_idx;
+    const int32_t* add_idx;
+    const float* add;
+    float* x_out;
+    void* n_out;
+    int ldn;
+    const float* ln_w;
+    const float* ln_b;
+    float eps;
+    int rows, rows_per_image, C;
+};
+int launch_gather_layernorm(const LnCall& c, hipStream_t stream);
+
+struct PartitionCall {
+    FvitMapView in;  // (B, C, Hp, Wp)
+    int batch, C, Hp, Wp, ws;
+    float* x;          // token rows, f32, row length C
+    int rows_per_win;  // S: rows reserved per window in x (ws*ws + ncw)
+    int row_off;       // ncw: first local-token row inside a window
+    const float* ct;   // optional (B, G, C) windowed carrier tokens copied into rows [0, ncw) (or null)
+    int ncw;
+};
+int launch_partition(const PartitionCall& c, hipStream_t stream);
+
+struct ReverseCall {
+    const float* x;
+    int rows_per_win, row_off;
+    int batch, C, Hp, Wp, H, W, ws;
+    FvitMapView out;       // (B, C, H, W)
+    const float* gamma;    // propagation: out = x + gamma * x[carrier up_idx] (gamma null => 1)
+    const int32_t* up_idx; // null => no propagation
+};
+int launch_reverse(const ReverseCall& c, hipStream_t stream);
+
+// copy f32 rows [rows][C] out of / into the windowed tensor's carrier slots (block-level API)
+int launch_ct_copy(float* x, int rows_per_win, int row_off, int ncw, float* ct, int nwin_total, int C, int to_x,
+                   hipStream_t stream);
+// x[win][ncw + t] += gamma * x[win][up_idx[t]] (block-level API; the stage API fuses this into window_reverse)
+int launch_propagate(float* x, const float* gamma, const int32_t* up_idx, int rows_per_win, int ncw, int nloc,
+                     int nwin_total, int C, hipStream_t stream);
+
+}  // namespace fvit

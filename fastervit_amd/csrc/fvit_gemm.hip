@@ -1,0 +1,236 @@
+// fvit_gemm.hip -- 16-bit MFMA GEMM with fused epilogues for the HAT Linear layers (gfx950).
+//
+//   out[m][n] = epilogue( sum_k X[m][k] * Wt[n][k] + bias[n] )
+//
+// Replaces the nn.Linear calls of WindowAttention (qkv, proj; AR:560,567) and Mlp (fc1, fc2;
+// AR:402-405) together with the ops the reference runs after them: bias add, exact-erf GELU
+// (AR:403), and the gamma-scaled residual add (AR:696-697).
+//
+// Design (CDNA4):
+//   * 128x128 output tile, BK = 64, 256 threads = 4 wave64 (2x2), each wave a 64x64 sub-tile as
+//     4x4 fragments of v_mfma_f32_16x16x32_{f16,bf16}; fp32 accumulators (64 VGPR).
+//   * Operands are staged HBM -> LDS with 16-byte global_load_lds (no VGPR round trip), double
+//     buffered (2 x 2 x 16 KiB), one barrier per K step.  The LDS image is lane-linear, so the
+//     bank-conflict swizzle is applied on the per-lane SOURCE address and undone on the ds_read.
+//   * The MFMA is issued "swapped": the weight tile is the A operand and the activation tile the
+//     B operand, and weight rows are assigned to A-row slots so that every lane ends up holding
+//     16 CONSECUTIVE output columns of one output row: the epilogue is 16-byte vector traffic
+//     (bias / gamma loads, fp32 residual read-modify-write, packed 16-bit stores), 128 B
+//     contiguous per row and store instruction.
+//   * blockIdx -> tile mapping is XCD aware: each XCD (blockIdx % 8) owns a contiguous range of
+//     tiles ordered n-fastest, so the activation tile is fetched from HBM once per XCD L2 and the
+//     (small) weight matrix stays L2 resident.
+#include "fvit_common.h"
+
+namespace fvit {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
+
+struct GemmParams {
+    const void* A;
+    const void* W;
+    const float* bias;
+    const float* gamma;
+    void* out;
+    int lda, ldw, ldo;
+    int M, N, K;
+    int tiles_m, tiles_n;
+};
+
+// swizzle of the 16-byte chunk index inside a 128-byte LDS row.
+//  X tile: fragments read 16 consecutive rows           -> f = (r >> 1) & 7
+//  W tile: fragments read rows {g*16 + ni*4 + r'}        -> f = perm(g) | (r' >> 1) << 2
+__device__ __forceinline__ int swz_x(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int swz_w(int r) { return ((0x78 >> (2 * ((r >> 4) & 3))) & 3) | ((r & 2) << 1); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <typename T, bool IS_W>
+__device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int row0, int k0, char* tile,
+                                           int wave, int lane) {
+    // 16 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces 4w..4w+3.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;
+        const int r = piece * 8 + (lane >> 3);
+        const int f = IS_W ? swz_w(r) : swz_x(r);
+        const int c = (lane & 7) ^ f;
+        const T* src = g + (size_t)(row0 + r) * ld + k0 + c * 8;
+        glds16(src, tile + piece * 1024);
+    }
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+    typedef typename Op16<T>::v8 v8;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // X0 X1 W0 W1
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile id (bijective for any grid size)
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, rr = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const int v = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ W = (const T*)p.W;
+
+    f4 acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage_tile<T, false>(A, p.lda, m0, 0, smem, wave, lane);
+    stage_tile<T, true>(W, p.ldw, n0, 0, smem + 2 * TILE_BYTES, wave, lane);
+
+    // per-lane fragment addressing (bytes inside a tile)
+    const int g = lane >> 4, s = lane & 15;
+    int xrow[4], wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xrow[i] = wm * 64 + i * 16 + s;                          // activation row (B operand column)
+        wrow[i] = wn * 64 + (s >> 2) * 16 + i * 4 + (s & 3);      // weight row for A-row slot s of fragment i
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            stage_tile<T, false>(A, p.lda, m0, (kt + 1) * BK, smem + (cur ^ 1) * TILE_BYTES, wave, lane);
+            stage_tile<T, true>(W, p.ldw, n0, (kt + 1) * BK, smem + (2 + (cur ^ 1)) * TILE_BYTES, wave, lane);
+        }
+        const char* xt = smem + cur * TILE_BYTES;
+        const char* wt = smem + (2 + cur) * TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int c = kk * 4 + g;
+            v8 xf[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xf[i] = *(const v8*)(xt + xrow[i] * 128 + ((c ^ swz_x(xrow[i])) << 4));
+                wf[i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[ni], xf[mi], acc[ni][mi]);
+        }
+    }
+
+    // ---- epilogue: lane holds out[m][nb .. nb+15] for 4 rows m (one per mi) ----
+    const int nb = n0 + wn * 64 + g * 16;
+    if (nb >= p.N) return;  // N is a multiple of 16
+    float bias[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f4 t = p.bias ? *(const f4*)(p.bias + nb + j * 4) : (f4){0.f, 0.f, 0.f, 0.f};
+        bias[j * 4 + 0] = t[0]; bias[j * 4 + 1] = t[1]; bias[j * 4 + 2] = t[2]; bias[j * 4 + 3] = t[3];
+    }
+    if (EPI == 2) {
+        float gam[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f4 t = p.gamma ? *(const f4*)(p.gamma + nb + j * 4) : (f4){1.f, 1.f, 1.f, 1.f};
+            gam[j * 4 + 0] = t[0]; gam[j * 4 + 1] = t[1]; gam[j * 4 + 2] = t[2]; gam[j * 4 + 3] = t[3];
+        }
+        float* X = (float*)p.out;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + s;
+            if (m < p.M) {
+                float* px = X + (size_t)m * p.ldo + nb;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    f4 x = *(f4*)(px + ni * 4);
+                    f4 a = acc[ni][mi];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] += gam[ni * 4 + r] * (a[r] + bias[ni * 4 + r]);
+                    *(f4*)(px + ni * 4) = x;
+                }
+            }
+        }
+    } else {
+        T* O = (T*)p.out;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + s;
+            if (m < p.M) {
+                v8 o0, o1;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    f4 a = acc[ni][mi];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float y = a[r] + bias[ni * 4 + r];
+                        if (EPI == 1) y = gelu_erf(y);
+                        if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
+                    }
+                }
+                T* po = O + (size_t)m * p.ldo + nb;
+                *(v8*)po = o0;
+                *(v8*)(po + 8) = o1;
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_t(const GemmCall& c, hipStream_t stream) {
+    GemmParams p;
+    p.A = c.A; p.W = c.W; p.bias = c.bias; p.gamma = c.gamma; p.out = c.out;
+    p.lda = c.lda; p.ldw = c.ldw; p.ldo = c.ldo;
+    p.M = c.M; p.N = c.N; p.K = c.K;
+    p.tiles_m = (c.M + BM - 1) / BM;
+    p.tiles_n = (c.N + BN - 1) / BN;
+    const int grid = p.tiles_m * p.tiles_n;
+    const double flops = 2.0 * c.M * (double)c.N * c.K;
+    double bytes = 2.0 * c.M * (double)c.K + 2.0 * c.N * (double)c.K;  // operands once
+    int kind;
+    if (c.epilogue == 2) {
+        bytes += 8.0 * c.M * (double)c.N;  // fp32 residual read + write
+        kind = FVIT_K_GEMM_RESID;
+    } else {
+        bytes += 2.0 * c.M * (double)c.N;
+        kind = c.epilogue == 1 ? FVIT_K_GEMM_GELU : FVIT_K_GEMM_BIAS;
+    }
+    ProfScope prof(kind, flops, bytes, stream);
+    switch (c.epilogue) {
+        case 0: hipLaunchKernelGGL((gemm_kernel<T, 0>), dim3(grid), dim3(256), 0, stream, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<T, 1>), dim3(grid), dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<T, 2>), dim3(grid), dim3(256), 0, stream, p); break;
+    }
+    return check_launch("gemm_kernel");
+}
+
+}  // namespace
+
+int launch_gemm(const GemmCall& c, hipStream_t stream) {
+    if (c.M <= 0 || c.N <= 0 || c.K <= 0 || (c.K % BK) != 0 || (c.N % 16) != 0 || (c.lda % 8) != 0 ||
+        (c.ldw % 8) != 0 || (c.ldo % (c.epilogue == 2 ? 4 : 8)) != 0 || c.lda < c.K || c.ldw < c.K) {
+        set_error("gemm: unsupported shape M=%d N=%d K=%d lda=%d ldw=%d ldo=%d (need K%%64==0, N%%16==0)", c.M, c.N,
+                  c.K, c.lda, c.ldw, c.ldo);
+        return FVIT_EINVAL;
+    }
+    if (c.dtype == FVIT_F16) return launch_t<_Float16>(c, stream);
+    if (c.dtype == FVIT_BF16) return launch_t<__bf16>(c, stream);
+    set_error("gemm: operand dtype %d not supported", c.dtype);
+    return FVIT_EINVAL;
+}
+
+}  // namespace fvit

@@ -1,0 +1,220 @@
+/*
+ * fvit_hip.h -- C ABI of libfvit_hip.so: the MI355X (gfx950) FasterViT Hierarchical-Attention path.
+ *
+ * The reference (NVlabs/FasterViT) has no FFI/plugin boundary for this path: it is plain PyTorch
+ * (fastervit/models/faster_vit.py, faster_vit_any_res.py).  The drop-in boundary is therefore the
+ * Python module API (create_model / FasterViT / FasterViTLayer / HAT) and this
+ * C ABI is what those modules bind with ctypes.  Each entry point names the reference code it
+ * replaces ("AR:" = fastervit/models/faster_vit_any_res.py, "FV:" = fastervit/models/faster_vit.py).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - The library never allocates or frees device memory.  Inputs, outputs, packed weights, folded
+ *     constants, index tables and the workspace are caller-owned device allocations.
+ *   - All work is enqueued asynchronously on the caller's hipStream_t; no host synchronisation
+ *     (profiling collection excepted), so calls are capturable in a hipGraph.
+ *   - Return value: 0 on success, negative FVIT_E* otherwise; message via fvit_last_error()
+ *     (thread-local).  No exceptions cross the ABI.
+ *   - One process per GPU; hipSetDevice is the caller's job.
+ *
+ * Numerics: MFMA operands are 16-bit (fp16 by default, bf16 selectable), accumulation fp32, the
+ * residual stream, LayerNorm, softmax and all position terms are fp32.
+ */
+#ifndef FVIT_HIP_H
+#define FVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FVIT_ABI_VERSION 1
+
+/* error codes */
+#define FVIT_OK 0
+#define FVIT_EINVAL (-1)      /* bad descriptor / unsupported geometry */
+#define FVIT_EWORKSPACE (-2)  /* workspace too small */
+#define FVIT_ELAUNCH (-3)     /* hip launch error */
+
+/* element types of caller tensors (feature maps in / out) and of MFMA operands */
+#define FVIT_F32 0
+#define FVIT_F16 1
+#define FVIT_BF16 2
+
+/* GEMM tile constants the packed-weight layout depends on */
+#define FVIT_TILE_N 128 /* weight rows are zero-padded to a multiple of this */
+#define FVIT_TILE_K 64  /* K (columns of weights and activations) is zero-padded to a multiple */
+#define FVIT_MASK_BIAS (-30000.0f) /* additive score bias on padded key columns */
+
+typedef void* fvit_stream_t; /* hipStream_t */
+
+/*
+ * Geometry of one transformer stage (FasterViTLayer with conv=False; AR:753-870 / FV:741-843).
+ * All fields are host values.
+ */
+typedef struct FvitStageDesc {
+    int32_t batch;          /* images B */
+    int32_t C;              /* channels */
+    int32_t heads;          /* attention heads h (head_dim d = C / h) */
+    int32_t dpad;           /* head_dim padded to 32 or 64 (packed q/k/v/proj layout) */
+    int32_t ws;             /* window side */
+    int32_t H, W;           /* feature-map size before padding */
+    int32_t Hp, Wp;         /* padded to a multiple of ws (AR:851-857) */
+    int32_t cw;             /* carrier tokens per window side (ct_size); 0 when hier == 0 */
+    int32_t hier;           /* 1: carrier-token branch active (do_sr_hat, AR:619) */
+    int32_t square;         /* 1: hat_pos_embed present (AR:617,658) */
+    int32_t hidden;         /* MLP hidden width (4C) */
+    int32_t depth;          /* number of HAT blocks */
+    int32_t do_propagation; /* AR:703: last block adds carrier tokens back into the image */
+    int32_t operand_dtype;  /* FVIT_F16 or FVIT_BF16: MFMA operand type of packed weights */
+    int32_t spad;           /* window sequence (ws^2 + cw^2) padded to a multiple of 16 */
+    int32_t gpad;           /* carrier sequence G = cw^2 * nW padded to a multiple of 16 (hier) */
+} FvitStageDesc;
+
+/* One attention sub-block: LayerNorm -> qkv -> softmax(q k^T * scale + bias) v -> proj -> gamma-residual.
+ * Replaces nn.LayerNorm + WindowAttention.forward (AR:558-569) + PosEmbMLPSwinv2D (AR:267-311, folded). */
+typedef struct FvitAttnWeights {
+    const void* w_qkv;   /* op16 [pad128(3*h*dpad)][pad64(C)], rows ordered [q|k|v][head][dpad], zero pad */
+    const float* b_qkv;  /* f32  [3*h*dpad], zero on pad rows */
+    const void* w_proj;  /* op16 [pad128(C)][pad64(h*dpad)], columns ordered [head][dpad], zero pad */
+    const float* b_proj; /* f32  [C] */
+    const float* bias;   /* f32  [h][Spad][Spad]: folded 16*sigmoid(cpb_mlp) bias, 0 on carrier rows/cols,
+                            FVIT_MASK_BIAS on key columns >= S, 0 on query rows >= S */
+    const float* ln_w;   /* f32  [C] */
+    const float* ln_b;   /* f32  [C] */
+    const float* gamma;  /* f32  [C] or NULL (layer_scale None => 1) */
+} FvitAttnWeights;
+
+/* LayerNorm -> fc1 -> GELU(erf) -> fc2 -> gamma-residual.  Replaces Mlp.forward (AR:399-408). */
+typedef struct FvitMlpWeights {
+    const void* w_fc1;   /* op16 [pad128(hidden)][pad64(C)] */
+    const float* b_fc1;  /* f32  [hidden] */
+    const void* w_fc2;   /* op16 [pad128(C)][pad64(hidden)] */
+    const float* b_fc2;  /* f32  [C] */
+    const float* ln_w;
+    const float* ln_b;
+    const float* gamma;  /* f32 [C] or NULL */
+} FvitMlpWeights;
+
+/* One HAT block (AR:572-707 / FV:571-701). */
+typedef struct FvitBlockWeights {
+    FvitAttnWeights attn;     /* norm1 + attn + gamma3 */
+    FvitMlpWeights mlp;       /* norm2 + mlp + gamma4 */
+    FvitAttnWeights hat_attn; /* hat_norm1 + hat_attn + gamma1 (hier only) */
+    FvitMlpWeights hat_mlp;   /* hat_norm2 + hat_mlp + gamma2 (hier only) */
+    const float* pe_x;        /* f32 [ws*ws][C]: folded PosEmbMLPSwinv1D of the window tokens (AR:671) */
+    const float* pe_ct;       /* f32 [G][C] folded hat_pos_embed (AR:682) or NULL */
+    int32_t last;             /* AR:665 */
+    int32_t _pad;
+} FvitBlockWeights;
+
+/* Index tables (device int32), built once per geometry by the host by running the reference's own
+ * view/permute chains on an arange (reproduces the non-square ct_window quirk). */
+typedef struct FvitStageTables {
+    const int32_t* ln1_src;  /* [nW*S]  source row of each window-tensor row for the norm1 pass:
+                                >= 0: row of X (relative to the image), < 0: -(r+1) = row r of the
+                                carrier buffer R (carrier rows after ct_window) */
+    const int32_t* ln1_add;  /* [nW*S]  row of pe_x to add, or -1 */
+    const int32_t* ct_src;   /* [G]     X row (relative to the image) feeding raster carrier r (ct_dewindow) */
+    const int32_t* up_idx;   /* [ws*ws] carrier slot (0..cw^2-1) each window token receives in propagation */
+} FvitStageTables;
+
+/* Strided view of a caller feature map (B, C, H, W) in element units; any memory format. */
+typedef struct FvitMapView {
+    void* data;
+    int64_t stride_b, stride_c, stride_h, stride_w;
+    int32_t dtype; /* FVIT_F32 / FVIT_F16 / FVIT_BF16 */
+    int32_t _pad;
+} FvitMapView;
+
+int fvit_abi_version(void);
+const char* fvit_last_error(void);
+
+/* Padded sequence length (multiple of 16) the attention kernel uses for S tokens; the folded bias
+ * tables must be laid out [heads][spad][spad] with this value (FvitStageDesc.spad / .gpad). */
+int fvit_attention_spad(int32_t S);
+
+/* Bytes of workspace fvit_hat_stage_forward needs for this geometry.  The workspace must be
+ * zero-filled once (fvit_workspace_init or any memset) before its first use with a given
+ * descriptor and must not be shared between different descriptors without re-initialising. */
+size_t fvit_stage_workspace_bytes(const FvitStageDesc* desc);
+int fvit_workspace_init(const FvitStageDesc* desc, void* workspace, size_t bytes, fvit_stream_t stream);
+
+/* Transformer branch of FasterViTLayer.forward without the Downsample (AR:848-869 / FV:832-841):
+ * window_partition (+ carrier tokens in front) -> depth x HAT.forward -> window_reverse (+ crop).
+ *   in       : (B, C, Hp, Wp) padded feature map (the caller applies F.pad, AR:853-854)
+ *   ct_init  : f32 (B, G, C) TokenInitializer output in windowed order (AR:745-750), or NULL
+ *   out      : (B, C, H, W)
+ */
+int fvit_hat_stage_forward(const FvitStageDesc* desc, const FvitBlockWeights* blocks,
+                           const FvitStageTables* tables, const FvitMapView* in,
+                           const float* ct_init, const FvitMapView* out, void* workspace,
+                           size_t workspace_bytes, fvit_stream_t stream);
+
+/* HAT.forward on already-partitioned windows (AR:668-707), for callers that drive blocks
+ * themselves: x f32 (B*nW, ws^2, C) in/out, ct f32 (B, G, C) in/out (NULL when hier == 0).
+ * desc->depth is ignored (one block). */
+int fvit_hat_block_forward(const FvitStageDesc* desc, const FvitBlockWeights* block,
+                           const FvitStageTables* tables, float* x, float* ct, void* workspace,
+                           size_t workspace_bytes, fvit_stream_t stream);
+
+/* window_partition (AR:84-88) / window_reverse (AR:91-94) as standalone ops on f32 token tensors. */
+int fvit_window_partition(const FvitMapView* in, int32_t batch, int32_t C, int32_t Hp, int32_t Wp,
+                          int32_t ws, float* windows, fvit_stream_t stream);
+int fvit_window_reverse(const float* windows, int32_t batch, int32_t C, int32_t Hp, int32_t Wp,
+                        int32_t H, int32_t W, int32_t ws, const FvitMapView* out, fvit_stream_t stream);
+
+/* ---- unit entry points (used by the parity tests to localise failures) ---- */
+
+/* out[m][n] (op16, ld ldo) = epilogue(sum_k A[m][k] * Wt[n][k] + bias[n]); epilogue: 0 none, 1 GELU(erf).
+ * A: op16 [pad128(M)][lda], Wt: op16 [pad128(N)][ldw], K a multiple of 64. */
+int fvit_gemm_bias_act(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw,
+                       const float* bias, void* out, int32_t ldo, int32_t M, int32_t N, int32_t K,
+                       int32_t act, fvit_stream_t stream);
+/* x[m][n] (f32, ld ldx) += gamma[n] * (sum_k A[m][k] * Wt[n][k] + bias[n]); gamma may be NULL (=1). */
+int fvit_gemm_residual(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw,
+                       const float* bias, const float* gamma, float* x, int32_t ldx, int32_t M,
+                       int32_t N, int32_t K, fvit_stream_t stream);
+/* Windowed multi-head attention core on packed qkv (op16 [rows][ldq], columns [q|k|v][head][dpad]):
+ * out (op16 [rows][ldo], columns [head][dpad]) = softmax(q k^T * scale + bias) v per (window, head).
+ * S tokens per window (rows w*S .. w*S+S-1), bias f32 [heads][Spad][Spad] as in FvitAttnWeights. */
+int fvit_window_attention(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo,
+                          const float* bias, int32_t nwin, int32_t S, int32_t heads, int32_t dpad,
+                          float scale, fvit_stream_t stream);
+/* Row gather + optional add + LayerNorm: for row i (image b = i / rows_per_image, p = i % rows_per_image)
+ *   v = (src_idx ? (src_idx[p] >= 0 ? srcA[b*rowsA + src_idx[p]] : srcB[b*rowsB - src_idx[p] - 1]) : srcA[i])
+ *       + (add_idx && add_idx[p] >= 0 ? add[add_idx[p]] : 0)
+ *   if x_out: x_out[i] = v (f32);  n_out[i] (op16, ld ldn, zero-padded to ldn) = LN(v) * ln_w + ln_b  */
+int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB,
+                          int32_t rowsB, const int32_t* src_idx, const int32_t* add_idx,
+                          const float* add, float* x_out, void* n_out, int32_t ldn, const float* ln_w,
+                          const float* ln_b, float eps, int32_t rows, int32_t rows_per_image, int32_t C,
+                          fvit_stream_t stream);
+
+/* ---- built-in kernel timer (HIP events around every launch, on the launch stream) ---- */
+#define FVIT_PROF_KINDS 8
+/* kind ids */
+#define FVIT_K_PARTITION 0
+#define FVIT_K_LAYERNORM 1
+#define FVIT_K_GEMM_BIAS 2
+#define FVIT_K_GEMM_GELU 3
+#define FVIT_K_GEMM_RESID 4
+#define FVIT_K_ATTENTION 5
+#define FVIT_K_REVERSE 6
+#define FVIT_K_OTHER 7
+typedef struct FvitProfEntry {
+    int64_t launches;
+    double ms;     /* summed event-to-event time */
+    double flops;  /* algorithmic FLOPs of those launches (2*M*N*K for GEMMs, 4*S*S*d per head for attention) */
+    double bytes;  /* algorithmic HBM bytes (compulsory reads + writes) */
+} FvitProfEntry;
+int fvit_prof_enable(int on);             /* starts/stops recording; enabling resets the counters */
+int fvit_prof_collect(FvitProfEntry* out); /* synchronises the recorded events; out[FVIT_PROF_KINDS] */
+const char* fvit_prof_kind_name(int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FVIT_HIP_H */

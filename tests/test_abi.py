@@ -1,0 +1,133 @@
+"""C-ABI surface and host logic that do not need a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from fastervit_amd import _lib, hat_runtime
+from oracle import hat_reference as hr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.isfile(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_header_symbols_are_exported(lib):
+    """Every function include/fvit_hip.h declares is exported by libfvit_hip.so (and vice versa for the binding)."""
+    hdr = open(os.path.join(ROOT, "include", "fvit_hip.h")).read()
+    declared = set(re.findall(r"\b(fvit_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("fvit_stream_t")
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared:
+        assert hasattr(raw, s), s
+
+
+def test_abi_version_and_struct_sizes(lib):
+    assert lib.fvit_abi_version() == _lib.FVIT_ABI_VERSION
+    assert ctypes.sizeof(_lib.FvitStageDesc) == 18 * 4
+    assert ctypes.sizeof(_lib.FvitAttnWeights) == 8 * 8
+    assert ctypes.sizeof(_lib.FvitMlpWeights) == 7 * 8
+    assert ctypes.sizeof(_lib.FvitBlockWeights) == 2 * 64 + 2 * 56 + 16 + 8
+    assert ctypes.sizeof(_lib.FvitMapView) == 48
+
+
+def test_attention_spad(lib):
+    for S, want in [(16, 16), (36, 48), (49, 64), (53, 64), (60, 64), (148, 160), (196, 208), (129, 160)]:
+        assert lib.fvit_attention_spad(S) == want
+
+
+def test_workspace_bytes_and_descriptor_validation(lib):
+    d = _lib.FvitStageDesc(batch=256, C=256, heads=8, dpad=32, ws=7, H=14, W=14, Hp=14, Wp=14, cw=2, hier=1, square=1,
+                           hidden=1024, depth=6, do_propagation=0, operand_dtype=_lib.FVIT_F16, spad=64, gpad=16)
+    n = lib.fvit_stage_workspace_bytes(ctypes.byref(d))
+    rows = 256 * 4 * 53
+    assert n >= rows * (256 * 4 + 256 * 2 + 768 * 2 + 256 * 2 + 1024 * 2)
+    assert n < 2 * rows * (256 * 4 + 256 * 2 + 768 * 2 + 256 * 2 + 1024 * 2)
+    d.spad = 48  # inconsistent with fvit_attention_spad
+    assert lib.fvit_stage_workspace_bytes(ctypes.byref(d)) == 0
+    assert b"spad" in lib.fvit_last_error()
+    d.spad, d.dpad = 64, 16  # dpad must be 32 or 64
+    assert lib.fvit_stage_workspace_bytes(ctypes.byref(d)) == 0
+
+
+@pytest.mark.parametrize("sr0,sr1,ws,cw", [(2, 2, 7, 2), (3, 5, 12, 2), (2, 4, 3, 2), (4, 4, 5, 1)])
+def test_index_tables_reproduce_reference_permutations(sr0, sr1, ws, cw):
+    """build_tables vs the oracle's ct_dewindow / ct_window / cat / nearest-upsample on tagged tensors."""
+    tb = hat_runtime.build_tables(sr0, sr1, ws, cw, True)
+    nW, S, G, ncw = tb["nW"], tb["S"], tb["G"], tb["ncw"]
+    # X rows tagged with their own index; carrier rows of X hold windowed carrier p at (p // ncw) * S + p % ncw
+    X = torch.arange(nW * S, dtype=torch.float32).view(nW * S, 1)
+    ct_windowed = torch.stack([X[(p // ncw) * S + p % ncw] for p in range(G)]).view(1, G, 1)
+    raster = hr.ct_dewindow(ct_windowed, cw * sr0, cw * sr1, cw)
+    assert torch.equal(X[tb["ct_src"].long()].view(1, G, 1), raster)
+    # after the carrier branch: R (raster) -> ct_window -> cat in front of the local tokens
+    R = torch.arange(1000, 1000 + G, dtype=torch.float32).view(1, G, 1)
+    ctw = hr.ct_window(R, cw * sr0, cw * sr1, cw).reshape(nW, ncw, 1)
+    xloc = X.view(nW, S, 1)[:, ncw:]
+    cat = torch.cat((ctw, xloc), dim=1).reshape(nW * S)
+    src = tb["ln1_src"].long()
+    got = torch.where(src >= 0, X.view(-1)[src.clamp(min=0)], R.view(-1)[(-src - 1).clamp(min=0)])
+    assert torch.equal(got, cat)
+    add = tb["ln1_add"].view(nW, S)
+    assert (add[:, :ncw] == -1).all() and torch.equal(add[:, ncw:], torch.arange(ws * ws).expand(nW, -1).int())
+    # propagation: nearest upsample cw -> ws
+    img = torch.arange(ncw, dtype=torch.float32).view(1, 1, cw, cw)
+    up = torch.nn.functional.interpolate(img, size=(ws, ws), mode="nearest").reshape(-1)
+    assert torch.equal(tb["up_idx"].float(), up)
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: a transformer stage on a CPU tensor raises, it does not silently compute."""
+    import fastervit_amd
+    m = fastervit_amd.create_model("faster_vit_0_224", depths=[1, 1, 1, 1], dim=16, in_dim=16, num_heads=[1, 1, 2, 4]).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="HIP device"):
+        m(torch.randn(1, 3, 224, 224))
+    blk = m.levels[3].blocks[0]
+    with torch.no_grad(), pytest.raises(RuntimeError, match="HIP device"):
+        blk(torch.randn(1, 49, 128), None)
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package never references oracle/ (it is test infrastructure)."""
+    pkg = os.path.join(ROOT, "fastervit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_registry_api():
+    import fastervit_amd
+    from fastervit_amd.models import registry
+    assert len(fastervit_amd.list_models()) == 22
+    assert fastervit_amd.is_model("faster_vit_4_21k_384_any_res")
+    assert registry.list_models("faster_vit_[0-6]_224") == [f"faster_vit_{i}_224" for i in range(7)]
+    assert registry.is_model_pretrained("faster_vit_0_224")
+    m = fastervit_amd.create_model("faster_vit_0_224", depths=[1, 1, 1, 1], dim=16, in_dim=16, num_heads=[1, 1, 2, 4],
+                                   num_classes=10)
+    assert m.num_classes == 10 and m.head.out_features == 10
+    assert m.pretrained_cfg["input_size"] == (3, 224, 224) and m.default_cfg is m.pretrained_cfg
+    assert m.no_weight_decay_keywords() == {"rpb"}
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    import fastervit_amd
+    kw = dict(depths=[1, 1, 1, 1], dim=16, in_dim=16, num_heads=[1, 1, 2, 4])
+    m = fastervit_amd.create_model("faster_vit_0_224", **kw)
+    path = str(tmp_path / "ck.pth.tar")
+    torch.save({"state_dict": {"module." + k: v for k, v in m.state_dict().items()}}, path)
+    m2 = fastervit_amd.create_model("faster_vit_0_224", checkpoint_path=path, **kw)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    m3 = fastervit_amd.create_model("faster_vit_0_224", **kw)
+    m3._load_state_dict(path, strict=True)
+    assert torch.equal(m3.head.weight, m.head.weight)
