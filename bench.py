@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- FasterViT-0 224x224 inference throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step is one forward pass of faster_vit_0_224 over one synthetic batch of 256 images per GPU
+(BASELINE configs[1]); inputs are resident in HBM before the timed region.  Inference is
+embarrassingly data parallel: every rank runs its own shard, there is no data-path collective
+(SURVEY.md §8e); the only collectives are the barrier and the MAX over ranks of the elapsed time.
+Rank 0 prints one JSON line.  The roofline entry is measured live with HIP events (the library's
+built-in kernel timer, on the launch stream); cpu_baseline times the CPU oracle (a port of the
+reference's fp32 PyTorch path) on a bounded sample on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="faster_vit_0_224")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--operand", default="f16", choices=["f16", "bf16"], help="MFMA operand type of the HAT kernels")
+    ap.add_argument("--conv-dtype", default="f16", choices=["f16", "bf16", "f32"], help="autocast dtype of the PyTorch conv side")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--prof-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    from fastervit_amd import dp
+    rank, local_rank, world = dp.env_world()
+    dist = dp.init_process_group("nccl")  # RCCL on ROCm; None when WORLD_SIZE == 1
+    assert args.gpus == world or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import fastervit_amd
+    from fastervit_amd import _lib
+    torch.manual_seed(0)  # same random-init weights on every rank
+    model = fastervit_amd.create_model(args.model).eval()
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).to(memory_format=torch.channels_last)
+    model.set_hat_operand_dtype(args.operand)
+    H = W = model.pretrained_cfg["input_size"][-1]
+    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    x_cpu = torch.randn(args.batch, 3, H, W, generator=gen)
+    x = x_cpu.to(dev).contiguous(memory_format=torch.channels_last)
+    conv_dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": None}[args.conv_dtype]
+
+    def forward(inp):
+        with torch.no_grad():
+            if conv_dt is None:
+                return model(inp)
+            with torch.autocast("cuda", dtype=conv_dt):
+                return model(inp)
+
+    # warm-up on the eager path (packs weights, allocates workspaces, lets MIOpen pick kernels)
+    for _ in range(2):
+        y = forward(x)
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        try:
+            static_x = x.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    forward(static_x)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()  # a hipGraph on ROCm
+            with torch.cuda.graph(graph):
+                static_y = forward(static_x)
+            torch.cuda.synchronize()
+        except Exception as e:  # report and measure eagerly rather than abort the bench
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            return static_y
+        return forward(x)
+
+    # W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks
+    elapsed = dp.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
+    value = dp.whole_job_rate(args.batch * args.steps, elapsed, dist, dev)
+    logits_gpu = step().float().cpu()
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant HAT kernel: live HIP-event timing of every launch (eager pass) ----
+    _lib.prof_enable(True)
+    for _ in range(args.prof_steps):
+        forward(x)
+    torch.cuda.synchronize()
+    prof = _lib.prof_collect()
+    _lib.prof_enable(False)
+    hat_ms = sum(e["ms"] for e in prof.values()) / args.prof_steps
+    gemm_kinds = [k for k in prof if k.startswith("gemm") and prof[k]["launches"]]
+    dom = max(gemm_kinds, key=lambda k: prof[k]["ms"])
+    e = prof[dom]
+    achieved = e["flops"] / (e["ms"] * 1e-3) / 1e12
+    roofline = {"kernel": f"gemm_kernel<{args.operand}> [{dom}]", "bound": "mfma", "achieved": round(achieved, 2),
+                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": e["launches"] // args.prof_steps,
+                "avg_launch_us": round(e["ms"] * 1e3 / e["launches"], 2),
+                "algorithmic_gflop_per_launch": round(e["flops"] / e["launches"] / 1e9, 3)}
+    kernels = {k: {"launches_per_step": v["launches"] // args.prof_steps, "ms_per_step": round(v["ms"] / args.prof_steps, 4),
+                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
+               for k, v in prof.items() if v["launches"]}
+
+    # ---- CPU baseline: the oracle (port of the reference fp32 CPU path) on a bounded sample ----
+    cpu = None
+    parity = None
+    if not args.no_cpu_baseline:
+        from oracle.model_reference import model_forward
+        from tests.cases import CASES
+        arch = dict(CASES["fvit0_224"]["arch"]) if args.model == "faster_vit_0_224" else None
+        if arch is not None:
+            nb = 8
+            xs = x_cpu[:nb]
+            ncpu = os.cpu_count() or 1
+            # small-batch fp32 inference does not scale to hundreds of threads: pick the fastest of a few
+            # thread counts on one iteration each, then time the bounded sample with that count
+            cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu})
+            torch.set_num_threads(cands[0])
+            ref = model_forward(sd_cpu, xs, arch)  # warm-up + parity reference
+            best_t, best_dt = cands[0], float("inf")
+            for t in cands:
+                torch.set_num_threads(t)
+                model_forward(sd_cpu, xs, arch)
+                t1 = time.perf_counter()
+                model_forward(sd_cpu, xs, arch)
+                dt = time.perf_counter() - t1
+                if dt < best_dt:
+                    best_t, best_dt = t, dt
+            torch.set_num_threads(best_t)
+            n, t_cpu = 0, 0.0
+            while t_cpu < args.cpu_seconds and n < 50:
+                t1 = time.perf_counter()
+                model_forward(sd_cpu, xs, arch)
+                t_cpu += time.perf_counter() - t1
+                n += 1
+            cpu = {"value": round(nb * n / t_cpu, 2), "unit": "images/s", "cores": best_t, "kind": "port",
+                   "sample": f"{args.model} fp32 oracle (port of the reference CPU path), batch {nb}, {n} iterations "
+                             f"({t_cpu:.1f} s), {best_t} of {ncpu} host threads (fastest of {cands})"}
+            err = (logits_gpu[:nb] - ref).abs().max().item()
+            parity = {"logits_max_abs_err": float(f"{err:.3e}"), "logits_abs_max": round(ref.abs().max().item(), 4),
+                      "vs": "CPU oracle fp32, first 8 images of rank 0's batch", "weights": "random init (seed 0)"}
+
+    out = {
+        "metric": "images/sec FasterViT-0 224x224 inference, bs=256/GPU", "value": round(value, 1), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.operand, "data": "synthetic",
+        "config": {"workload": f"{args.model} inference, {H}x{W}, batch {args.batch}/GPU, random-init weights",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world} (independent shards, no data-path collective)",
+                   "hat_operands": args.operand, "conv_side": f"PyTorch-ROCm channels_last autocast {args.conv_dtype}",
+                   "launch": "hipGraph replay" if graph is not None else "eager"},
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        "hat_ms_per_step": round(hat_ms, 4), "hat_kernels": kernels,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

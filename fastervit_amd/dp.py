@@ -1,0 +1,69 @@
+"""Data-parallel inference driver: one process per GPU, independent image shards, no collective on
+the data path (the reference's nn.DataParallel scatter/gather, validate.py:243-244,
+is replaced by per-process shards).  The only collectives are the start/stop barriers and the
+reductions that turn per-rank timings into one whole-job figure; on ROCm backend "nccl" is RCCL
+over xGMI, on CPU tests use "gloo".
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Callable, Optional, Tuple
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_process_group(backend: str = "nccl"):
+    """Initialise torch.distributed from the environment when WORLD_SIZE > 1; returns the module or None."""
+    _, _, world = env_world()
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, init_method="env://")
+    return dist
+
+
+def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced split of ``n_items`` (strong-scaling use: one global batch over N GPUs)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def timed_steps(step: Callable[[], object], steps: int, warmup: int, sync: Callable[[], None], dist=None,
+                device=None) -> float:
+    """Run ``warmup`` untimed then exactly ``steps`` timed steps bracketed by barrier + sync on both
+    sides; returns the MAX elapsed seconds over ranks."""
+    import torch
+    for _ in range(warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def whole_job_rate(items_this_rank: int, elapsed_max: float, dist=None, device=None) -> float:
+    """Aggregate items/s over all ranks: SUM of the items every rank processed / MAX elapsed."""
+    import torch
+    total = float(items_this_rank)
+    if dist is not None:
+        t = torch.tensor([total], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total = float(t.item())
+    return total / elapsed_max

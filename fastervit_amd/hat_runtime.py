@@ -96,14 +96,19 @@ def _gamma(g) -> Optional[torch.Tensor]:
 
 
 class _Keep:
-    """Holds packed device tensors alive and hands out their pointers."""
+    """Holds packed device tensors alive and hands out their pointers (dtype / layout checked:
+    the kernels reinterpret raw pointers, a silently down-cast table would be read out of bounds)."""
 
-    def __init__(self):
+    def __init__(self, op_dtype=None):
         self.tensors = []
+        self.op_dtype = op_dtype
 
-    def ptr(self, t: Optional[torch.Tensor]) -> Optional[int]:
+    def ptr(self, t: Optional[torch.Tensor], op16: bool = False) -> Optional[int]:
         if t is None:
             return None
+        want = self.op_dtype if op16 else torch.float32
+        if t.dtype != want or not t.is_contiguous():
+            raise RuntimeError(f"packed tensor has dtype {t.dtype} / contiguous={t.is_contiguous()}, expected {want}")
         self.tensors.append(t)
         return t.data_ptr()
 
@@ -130,7 +135,7 @@ def pack_attention(attn, norm, gamma, S: int, dpad: int, op_dtype, keep: _Keep) 
     bias[:, :, S:] = FVIT_MASK_BIAS
     bias[:, S:, :] = 0.0
     bias[:, S:, S:] = FVIT_MASK_BIAS if S < spad else 0.0
-    return FvitAttnWeights(keep.ptr(wq.to(op_dtype)), keep.ptr(bq), keep.ptr(wp.to(op_dtype)), keep.ptr(_f32(attn.proj.bias)),
+    return FvitAttnWeights(keep.ptr(wq.to(op_dtype), True), keep.ptr(bq), keep.ptr(wp.to(op_dtype), True), keep.ptr(_f32(attn.proj.bias)),
                            keep.ptr(bias), keep.ptr(_f32(norm.weight)), keep.ptr(_f32(norm.bias)), keep.ptr(_gamma(gamma)))
 
 
@@ -143,7 +148,7 @@ def pack_mlp(mlp, norm, gamma, op_dtype, keep: _Keep) -> FvitMlpWeights:
     w1[:hid, :C_] = _f32(mlp.fc1.weight)
     w2 = torch.zeros(_rup(C_, FVIT_TILE_N), ldh, device=dev, dtype=torch.float32)
     w2[:C_, :hid] = _f32(mlp.fc2.weight)
-    return FvitMlpWeights(keep.ptr(w1.to(op_dtype)), keep.ptr(_f32(mlp.fc1.bias)), keep.ptr(w2.to(op_dtype)),
+    return FvitMlpWeights(keep.ptr(w1.to(op_dtype), True), keep.ptr(_f32(mlp.fc1.bias)), keep.ptr(w2.to(op_dtype), True),
                           keep.ptr(_f32(mlp.fc2.bias)), keep.ptr(_f32(norm.weight)), keep.ptr(_f32(norm.bias)),
                           keep.ptr(_gamma(gamma)))
 
@@ -227,10 +232,12 @@ def _prepare(layer, x_dev, Hp: int, Wp: int):
     tb, _, ctables = st.tables[tkey]
     sig = _signature(layer.blocks, x_dev, op_name) + (tb["S"], tb["G"])
     if st.sig != sig:
-        keep = _Keep()
+        keep = _Keep(op_dtype)
         arr = (FvitBlockWeights * len(layer.blocks))()
-        for i, blk in enumerate(layer.blocks):
-            arr[i] = pack_block(blk, tb["S"], tb["G"], dpad, op_dtype, keep)
+        # constant folding must not run under the caller's autocast: the tables are fp32 by contract
+        with torch.autocast(device_type="cuda", enabled=False):
+            for i, blk in enumerate(layer.blocks):
+                arr[i] = pack_block(blk, tb["S"], tb["G"], dpad, op_dtype, keep)
         st.keep, st.blocks_c, st.sig = keep, arr, sig
     lib = _lib.lib()
     desc_common = dict(C=Cdim, heads=heads, dpad=dpad, ws=ws, Hp=Hp, Wp=Wp, cw=cw if hier else 0, hier=int(hier),

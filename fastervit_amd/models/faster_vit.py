@@ -26,11 +26,27 @@ import torch.nn.functional as F
 
 from .registry import register_pip_model
 
-try:  # optional: the reference registers its entrypoints with timm as well (FV:975-976)
-    from timm.models.registry import register_model as _timm_register
-except Exception:  # timm absent: our own registry is the only one
-    def _timm_register(fn):
-        return fn
+_TIMM_PENDING = []  # entrypoints to (re-)register with timm, see register_with_timm()
+
+
+def _timm_register(fn):
+    """The reference also registers every entrypoint with timm (FV:975-976: @register_model) so that
+    timm.models.create_model -- what validate.py calls -- finds it.  timm is optional here."""
+    _TIMM_PENDING.append(fn)
+    try:
+        from timm.models.registry import register_model
+        register_model(fn)
+    except Exception:
+        pass
+    return fn
+
+
+def register_with_timm():
+    """(Re-)register all entrypoints with whatever `timm` is importable now; returns how many."""
+    from timm.models.registry import register_model
+    for fn in _TIMM_PENDING:
+        register_model(fn)
+    return len(_TIMM_PENDING)
 
 
 def _pair(v):
@@ -158,8 +174,9 @@ class PosEmbMLPSwinv1D(nn.Module):
         ax = torch.arange(L, device=w0.device, dtype=torch.float32)
         grid = torch.stack(torch.meshgrid(ax, ax, indexing="ij")).reshape(2, L * L).t()
         grid = (grid - (L // 2)) / (L // 2)
-        h = torch.relu(F.linear(grid, w0.float(), self.cpb_mlp[0].bias.float()))
-        return F.linear(h, self.cpb_mlp[2].weight.float()).contiguous()
+        with torch.autocast(device_type=w0.device.type, enabled=False):  # fp32 by contract (the kernels read f32)
+            h = torch.relu(F.linear(grid, w0.float(), self.cpb_mlp[0].bias.float()))
+            return F.linear(h, self.cpb_mlp[2].weight.float()).float().contiguous()
 
 
 class PosEmbMLPSwinv2D(nn.Module):
@@ -201,8 +218,9 @@ class PosEmbMLPSwinv2D(nn.Module):
         """(heads, S, S) fp32: bias on the trailing window block, zeros on the first S - w0*w1 rows/cols."""
         n = self.window_size[0] * self.window_size[1]
         w0 = self.cpb_mlp[0].weight
-        h = torch.relu(F.linear(self.relative_coords_table.float(), w0.float(), self.cpb_mlp[0].bias.float()))
-        t = F.linear(h, self.cpb_mlp[2].weight.float()).view(-1, self.num_heads)
+        with torch.autocast(device_type=w0.device.type, enabled=False):
+            h = torch.relu(F.linear(self.relative_coords_table.float(), w0.float(), self.cpb_mlp[0].bias.float()))
+            t = F.linear(h, self.cpb_mlp[2].weight.float()).float().view(-1, self.num_heads)
         b = t[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1)
         b = 16 * torch.sigmoid(b)
         pad = S - n

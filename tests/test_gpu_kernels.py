@@ -1,0 +1,194 @@
+"""Kernel-level parity through the C ABI (needs an MI355X): each HIP kernel against a plain
+PyTorch fp32 statement of the same op on the same (16-bit rounded) operands."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fastervit_amd import _lib, hat_runtime
+from oracle import hat_reference as hr
+
+pytestmark = pytest.mark.gpu
+
+OPS = [("f16", torch.float16, 1), ("bf16", torch.bfloat16, 2)]
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _padded(t, rows, cols):
+    out = torch.zeros(rows, cols, dtype=t.dtype, device=t.device)
+    out[:t.shape[0], :t.shape[1]] = t
+    return out
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("M,N,K", [(300, 768, 256), (128, 256, 1024), (1000, 784, 784), (77, 3136, 784), (54272, 1024, 256),
+                                   (4096, 16, 64)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_gemm_bias_act(opname, dt, code, M, N, K, act):
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g)).to(dt).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Kp = _rup(K, 64)
+    Ap, Wp = _padded(A, _rup(M, 128), Kp), _padded(W, _rup(N, 128), Kp)
+    ldo = _rup(N, 64)
+    out = torch.full((_rup(M, 128), ldo), float("nan"), dtype=dt, device="cuda")
+    rc = lib.fvit_gemm_bias_act(code, Ap.data_ptr(), Kp, Wp.data_ptr(), Kp, bias.data_ptr(), out.data_ptr(), ldo, M, N, Kp, act,
+                                _stream())
+    _lib.check(rc, "gemm")
+    torch.cuda.synchronize()
+    ref = A.float() @ W.float().t() + bias
+    if act:
+        ref = F.gelu(ref)
+    got = out[:M, :N].float()
+    tol = (4e-3 if dt == torch.float16 else 2e-2) * max(ref.abs().max().item(), 1.0)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < tol
+    # rows beyond M and columns beyond N are never written
+    assert torch.isnan(out[M:].float()).all() and torch.isnan(out[:M, N:].float()).all()
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("M,N,K,use_gamma", [(300, 256, 256, True), (212, 784, 3136, True), (1000, 512, 2048, False),
+                                              (54272, 256, 1024, True)])
+def test_gemm_residual(opname, dt, code, M, N, K, use_gamma):
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M * 3 + N + K)
+    A = torch.randn(M, K, generator=g).to(dt).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    gamma = (torch.rand(N, generator=g) + 0.5).cuda() if use_gamma else None
+    x0 = torch.randn(M, N, generator=g).cuda()
+    x = x0.clone()
+    Kp = _rup(K, 64)
+    Ap, Wp = _padded(A, _rup(M, 128), Kp), _padded(W, _rup(N, 128), Kp)
+    rc = lib.fvit_gemm_residual(code, Ap.data_ptr(), Kp, Wp.data_ptr(), Kp, bias.data_ptr(),
+                                gamma.data_ptr() if use_gamma else None, x.data_ptr(), N, M, N, Kp, _stream())
+    _lib.check(rc, "gemm_residual")
+    torch.cuda.synchronize()
+    y = A.float() @ W.float().t() + bias
+    ref = x0 + (gamma * y if use_gamma else y)
+    assert (x - ref).abs().max().item() < 2e-4 * max(ref.abs().max().item(), 1.0) * (K / 256) ** 0.5
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("S,dpad,d,heads,nwin", [(53, 32, 32, 8, 7), (49, 32, 32, 16, 5), (16, 32, 32, 8, 6), (53, 64, 49, 16, 3),
+                                                  (148, 64, 49, 4, 3), (36, 64, 49, 3, 5), (60, 64, 49, 4, 2),
+                                                  (196, 32, 16, 2, 2), (13, 32, 24, 4, 9), (32, 32, 32, 2, 4)])
+def test_window_attention(opname, dt, code, S, dpad, d, heads, nwin):
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(S * 7 + d)
+    rows = nwin * S
+    q, k, v = (torch.randn(nwin, heads, S, d, generator=g).to(dt) for _ in range(3))
+    bias = torch.randn(heads, S, S, generator=g) * 2
+    spad = lib.fvit_attention_spad(S)
+    ldq = 3 * heads * dpad
+    ldo = _rup(heads * dpad, 64)
+    qkv = torch.zeros(_rup(rows, 128), ldq, dtype=dt)
+    for si, t in enumerate((q, k, v)):
+        qkv[:rows].view(nwin, S, 3, heads, dpad)[:, :, si, :, :d] = t.permute(0, 2, 1, 3)
+    bp = torch.zeros(heads, spad, spad)
+    bp[:, :S, :S] = bias
+    bp[:, :, S:] = _lib.FVIT_MASK_BIAS
+    qkv, bp = qkv.cuda(), bp.cuda()
+    out = torch.zeros(_rup(rows, 128), ldo, dtype=dt, device="cuda")
+    scale = d ** -0.5
+    rc = lib.fvit_window_attention(code, qkv.data_ptr(), ldq, out.data_ptr(), ldo, bp.data_ptr(), nwin, S, heads, dpad,
+                                   ctypes.c_float(scale), _stream())
+    _lib.check(rc, "attention")
+    torch.cuda.synchronize()
+    att = (q.float() @ k.float().transpose(-1, -2)) * scale + bias
+    ref = att.softmax(-1) @ v.float()                       # (nwin, heads, S, d)
+    got = out[:rows, :heads * dpad].float().cpu().view(nwin, S, heads, dpad).permute(0, 2, 1, 3)
+    assert torch.isfinite(got).all()
+    assert (got[..., :d] - ref).abs().max().item() < (4e-3 if dt == torch.float16 else 2.5e-2) * max(ref.abs().max().item(), 1.0)
+    assert got[..., d:].abs().max().item() == 0.0 if d < dpad else True
+
+
+@pytest.mark.parametrize("C", [256, 784, 1568, 64, 2560])
+def test_gather_layernorm_plain(C):
+    lib = _lib.lib()
+    rows = 203
+    g = torch.Generator(device="cpu").manual_seed(C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).cuda()
+    w = (torch.rand(C, generator=g) + 0.5).cuda()
+    b = torch.randn(C, generator=g).cuda()
+    ldn = _rup(C, 64)
+    n = torch.full((rows, ldn), float("nan"), dtype=torch.float16, device="cuda")
+    rc = lib.fvit_gather_layernorm(1, x.data_ptr(), 0, None, 0, None, None, None, None, n.data_ptr(), ldn, w.data_ptr(),
+                                   b.data_ptr(), ctypes.c_float(1e-5), rows, 1, C, _stream())
+    _lib.check(rc, "layernorm")
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x, (C,), w, b, 1e-5)
+    assert (n[:, :C].float() - ref).abs().max().item() < 4e-3 * ref.abs().max().item()
+    if ldn > C:
+        assert (n[:, C:] == 0).all()
+
+
+def test_gather_layernorm_tables():
+    """The norm1 pass of a hierarchical block: gather carrier rows from R, add pe to local rows, write X back."""
+    lib = _lib.lib()
+    sr0, sr1, ws, cw, C, B = 2, 4, 3, 2, 64, 3
+    tb = hat_runtime.build_tables(sr0, sr1, ws, cw, True)
+    nW, S, G = tb["nW"], tb["S"], tb["G"]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    X = torch.randn(B, nW * S, C, generator=g).cuda()
+    R = torch.randn(B, G, C, generator=g).cuda()
+    pe = torch.randn(ws * ws, C, generator=g).cuda()
+    w = (torch.rand(C, generator=g) + 0.5).cuda()
+    b = torch.randn(C, generator=g).cuda()
+    src, add = tb["ln1_src"].cuda(), tb["ln1_add"].cuda()
+    xo = X.clone()
+    n = torch.zeros(B * nW * S, 64, dtype=torch.float16, device="cuda")
+    rc = lib.fvit_gather_layernorm(1, xo.data_ptr(), nW * S, R.data_ptr(), G, src.data_ptr(), add.data_ptr(), pe.data_ptr(),
+                                   xo.data_ptr(), n.data_ptr(), 64, w.data_ptr(), b.data_ptr(), ctypes.c_float(1e-5),
+                                   B * nW * S, nW * S, C, _stream())
+    _lib.check(rc, "layernorm")
+    torch.cuda.synchronize()
+    srcl, addl = src.long(), add.long()
+    gathered = torch.where((srcl >= 0)[None, :, None], X[:, srcl.clamp(min=0)], R[:, (-srcl - 1).clamp(min=0)])
+    gathered = gathered + torch.where((addl >= 0)[:, None], pe[addl.clamp(min=0)], torch.zeros_like(pe[:1]))[None]
+    assert torch.equal(xo, gathered)
+    ref = F.layer_norm(gathered, (C,), w, b, 1e-5).view(-1, C)
+    assert (n.float() - ref).abs().max().item() < 4e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("fmt", ["nchw", "nhwc"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,C,Hp,Wp,H,W,ws", [(3, 64, 14, 14, 14, 14, 7), (2, 48, 6, 12, 6, 10, 3), (1, 784, 36, 60, 36, 60, 12)])
+def test_window_partition_reverse(fmt, dt, B, C, Hp, Wp, H, W, ws):
+    lib = _lib.lib()
+    x = torch.randn(B, C, Hp, Wp).to(dt).cuda()
+    if fmt == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    win = torch.full((B * (Hp // ws) * (Wp // ws), ws * ws, C), float("nan"), device="cuda")
+    v = hat_runtime._map_view(x)
+    _lib.check(lib.fvit_window_partition(ctypes.byref(v), B, C, Hp, Wp, ws, win.data_ptr(), _stream()), "partition")
+    torch.cuda.synchronize()
+    assert torch.equal(win, hr.window_partition(x.float(), ws))  # bit exact: pure data movement
+    out = torch.full((B, C, H, W), float("nan"), dtype=dt, device="cuda")
+    if fmt == "nhwc":
+        out = out.contiguous(memory_format=torch.channels_last)
+    vo = hat_runtime._map_view(out)
+    _lib.check(lib.fvit_window_reverse(win.data_ptr(), B, C, Hp, Wp, H, W, ws, ctypes.byref(vo), _stream()), "reverse")
+    torch.cuda.synchronize()
+    assert torch.equal(out, x[:, :, :H, :W])
+
+
+def test_errors_are_reported_not_swallowed():
+    lib = _lib.lib()
+    rc = lib.fvit_gemm_bias_act(1, None, 100, None, 100, None, None, 64, 10, 10, 100, 0, _stream())
+    assert rc == -1 and b"gemm" in lib.fvit_last_error()
+    with pytest.raises(RuntimeError, match="gemm"):
+        _lib.check(rc, "gemm")
+    rc = lib.fvit_window_attention(1, None, 96, None, 64, None, 1, 300, 1, 32, ctypes.c_float(1.0), _stream())
+    assert rc == -1 and b"no kernel instance" in lib.fvit_last_error()
