@@ -17,14 +17,15 @@ FVIT_ABI_VERSION = 1
 FVIT_F32, FVIT_F16, FVIT_BF16 = 0, 1, 2
 FVIT_TILE_N, FVIT_TILE_K = 128, 64
 FVIT_MASK_BIAS = -30000.0
-FVIT_PROF_KINDS = 8
+FVIT_PROF_KINDS = 9
 
 # every symbol include/fvit_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = (
     "fvit_abi_version", "fvit_last_error", "fvit_attention_spad", "fvit_stage_workspace_bytes",
     "fvit_workspace_init", "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_window_partition",
     "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_window_attention",
-    "fvit_gather_layernorm", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_kind_name",
+    "fvit_gather_layernorm", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl",
+    "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_kind_name",
 )
 
 
@@ -39,7 +40,7 @@ class FvitAttnWeights(C.Structure):
 
 
 class FvitMlpWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w_fc1", "b_fc1", "w_fc2", "b_fc2", "ln_w", "ln_b", "gamma")]
+    _fields_ = [(n, C.c_void_p) for n in ("w_fc1", "b_fc1", "w_fc2", "b_fc2", "ln_w", "ln_b", "gamma", "w_fc1_frag", "w_fc2_frag")]
 
 
 class FvitBlockWeights(C.Structure):
@@ -104,6 +105,18 @@ def _declare(lib):
     lib.fvit_window_attention.argtypes = [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, vp]
     lib.fvit_gather_layernorm.restype = C.c_int
     lib.fvit_gather_layernorm.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, f32, i32, i32, i32, vp]
+    lib.fvit_mlp_fused_supported.restype = C.c_int
+    lib.fvit_mlp_fused_supported.argtypes = [i32, i32]
+    lib.fvit_mlp_fused.restype = C.c_int
+    lib.fvit_mlp_fused.argtypes = [i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp]
+    lib.fvit_bias_act_cl.restype = C.c_int
+    lib.fvit_bias_act_cl.argtypes = [i32, vp, vp, C.c_int64, i32, i32, vp]
+    lib.fvit_bias_residual_cl.restype = C.c_int
+    lib.fvit_bias_residual_cl.argtypes = [i32, vp, vp, vp, C.c_int64, i32, vp]
+    lib.fvit_layernorm2d_cl.restype = C.c_int
+    lib.fvit_layernorm2d_cl.argtypes = [i32, vp, vp, vp, vp, f32, C.c_int64, i32, vp]
+    lib.fvit_tune.restype = C.c_int
+    lib.fvit_tune.argtypes = [C.c_char_p, i32]
     lib.fvit_prof_enable.restype = C.c_int
     lib.fvit_prof_enable.argtypes = [C.c_int]
     lib.fvit_prof_collect.restype = C.c_int
@@ -139,6 +152,10 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().fvit_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def tune(key: str, value: int) -> None:
+    check(lib().fvit_tune(key.encode(), int(value)), "fvit_tune")
 
 
 def prof_enable(on: bool) -> None:

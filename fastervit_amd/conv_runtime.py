@@ -1,0 +1,172 @@
+"""Deploy-mode plan for the conv side of FasterViT.
+
+The convolutions stay PyTorch-ROCm / MIOpen (north_star), but everything around them that is
+input-independent or elementwise is removed from the per-forward path:
+
+  * BatchNorm (eval) is folded into the preceding conv's weights and bias at load:
+        PatchEmbed  conv(no bias)+BN(eps 1e-4)          (FV:458-463)
+        ConvBlock   conv1+BN1, conv2+BN2 (+gamma)        (FV:490-512)
+        final BN + AdaptiveAvgPool2d(1) + head           (FV:925-927, 953-960) -> one fp32 Linear on the pooled map
+    exact in real arithmetic; weights are kept as 16-bit channels_last tensors, so there is no autocast
+    and no per-forward cast of parameters.
+  * conv bias + activation, conv bias + residual and timm's LayerNorm2d run as single HBM passes in
+    hand-written HIP kernels (csrc/fvit_glue.hip) instead of MIOpen BN / OpTensor + several ATen kernels.
+  * The transformer stages are the same `fvit_hat_stage_forward` calls as in module mode.
+
+Enabled by `FasterViT.switch_to_deploy()`; module mode (plain nn.Module forward, any dtype / autocast)
+remains the default so that the reference's scripts run unchanged.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, hat_runtime
+
+_CODE = {torch.float16: _lib.FVIT_F16, torch.bfloat16: _lib.FVIT_BF16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bn_scale_shift(bn):
+    s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+    t = bn.bias.float() - bn.running_mean.float() * s
+    return s, t
+
+
+def _fold(conv, bn, extra_scale=None):
+    """conv (+ optional bias) followed by eval-mode BN (and an optional per-channel scale) -> (w, b) fp32."""
+    s, t = _bn_scale_shift(bn)
+    w = conv.weight.float() * s.view(-1, 1, 1, 1)
+    b = t if conv.bias is None else conv.bias.float() * s + t
+    if extra_scale is not None:
+        w = w * extra_scale.float().view(-1, 1, 1, 1)
+        b = b * extra_scale.float()
+    return w, b
+
+
+class DeployPlan:
+    def __init__(self, model, dtype=torch.float16):
+        if dtype not in _CODE:
+            raise ValueError("deploy dtype must be torch.float16 or torch.bfloat16")
+        self.model = model
+        self.dtype = dtype
+        self.code = _CODE[dtype]
+        self.sig = None
+        self.t = None
+
+    # ---- folding -------------------------------------------------------------------------
+    def _signature(self):
+        m = self.model
+        sig = []
+        for name, p in list(m.named_parameters()) + list(m.named_buffers()):
+            if ".blocks." in name and name.startswith(("levels.2.", "levels.3.")):
+                continue  # HAT parameters are tracked by hat_runtime
+            sig.append((p.data_ptr(), p._version))
+        return tuple(sig)
+
+    def _cw(self, w):
+        return w.to(self.dtype).contiguous(memory_format=torch.channels_last)
+
+    @torch.no_grad()
+    def _build(self):
+        m = self.model
+        t = {}
+        pe = m.patch_embed.conv_down
+        w0, b0 = _fold(pe[0], pe[1])
+        w1, b1 = _fold(pe[3], pe[4])
+        t["stem"] = (self._cw(w0), b0.contiguous(), self._cw(w1), b1.contiguous())
+        t["levels"] = []
+        for lvl in m.levels:
+            e = {}
+            if not lvl.transformer_block:
+                blocks = []
+                for blk in lvl.blocks:
+                    wa, ba = _fold(blk.conv1, blk.norm1)
+                    wb, bb = _fold(blk.conv2, blk.norm2, blk.gamma if blk.layer_scale else None)
+                    blocks.append((self._cw(wa), ba.contiguous(), self._cw(wb), bb.contiguous()))
+                e["blocks"] = blocks
+            elif getattr(lvl, "do_gt", False):
+                tk = lvl.global_tokenizer
+                e["tok"] = (self._cw(tk.pos_embed.weight.float()), tk.pos_embed.bias.to(self.dtype).contiguous(),
+                            tk.to_global_feature.pool.kernel_size, tk.to_global_feature.pool.stride, tk.window_size)
+            if lvl.downsample is not None:
+                ds = lvl.downsample
+                e["down"] = (ds.norm.weight.float().contiguous(), ds.norm.bias.float().contiguous(), float(ds.norm.eps),
+                             self._cw(ds.reduction[0].weight.float()))
+            t["levels"].append(e)
+        hw, hb = m.head.weight.float(), m.head.bias.float()
+        if isinstance(m.norm, torch.nn.BatchNorm2d):
+            s, sh = _bn_scale_shift(m.norm)
+            t["head"] = ((hw * s.view(1, -1)).contiguous(), (hb + hw @ sh).contiguous(), None)
+        else:  # layer_norm_last: LayerNorm2d kernel, then pool + head
+            t["head"] = (hw.contiguous(), hb.contiguous(),
+                         (m.norm.weight.float().contiguous(), m.norm.bias.float().contiguous(), float(m.norm.eps)))
+        self.t = t
+
+    # ---- kernels -------------------------------------------------------------------------
+    def _bias_act(self, x, bias, act):
+        B, C, H, W = x.shape
+        assert x.is_contiguous(memory_format=torch.channels_last) and x.dtype == self.dtype
+        _lib.check(_lib.lib().fvit_bias_act_cl(self.code, x.data_ptr(), bias.data_ptr(), B * H * W, C, act, _stream()),
+                   "fvit_bias_act_cl")
+        return x
+
+    def _bias_residual(self, x, y, bias):
+        B, C, H, W = x.shape
+        assert x.is_contiguous(memory_format=torch.channels_last) and y.is_contiguous(memory_format=torch.channels_last)
+        _lib.check(_lib.lib().fvit_bias_residual_cl(self.code, x.data_ptr(), y.data_ptr(), bias.data_ptr(), B * H * W, C,
+                                                    _stream()), "fvit_bias_residual_cl")
+        return x
+
+    def _ln2d(self, x, w, b, eps):
+        B, C, H, W = x.shape
+        if C % 8 or not x.is_contiguous(memory_format=torch.channels_last):
+            y = F.layer_norm(x.permute(0, 2, 3, 1).float(), (C,), w, b, eps).permute(0, 3, 1, 2)
+            return y.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().fvit_layernorm2d_cl(self.code, x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(), eps,
+                                                  B * H * W, C, _stream()), "fvit_layernorm2d_cl")
+        return out
+
+    def _tokenizer(self, tok):
+        w, b, ks, st, cw = tok
+
+        def fn(xp):
+            y = F.avg_pool2d(F.conv2d(xp, w, b, padding=1, groups=xp.shape[1]), ks, st)
+            B, C, H, W = y.shape
+            y = y.reshape(B, C, H // cw, cw, W // cw, cw).permute(0, 2, 4, 3, 5, 1).reshape(B, H * W, C)
+            return y.float().contiguous()
+        return fn
+
+    # ---- forward -------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x):
+        sig = self._signature()
+        if sig != self.sig:
+            with torch.autocast(device_type="cuda", enabled=False):
+                self._build()
+            self.sig = sig
+        t = self.t
+        with torch.autocast(device_type="cuda", enabled=False):
+            x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+            w0, b0, w1, b1 = t["stem"]
+            x = self._bias_act(F.conv2d(x, w0, None, 2, 1), b0, 1)
+            x = self._bias_act(F.conv2d(x, w1, None, 2, 1), b1, 1)
+            for lvl, e in zip(self.model.levels, t["levels"]):
+                if "blocks" in e:
+                    for wa, ba, wb, bb in e["blocks"]:
+                        y = self._bias_act(F.conv2d(x, wa, None, 1, 1), ba, 2)
+                        x = self._bias_residual(x, F.conv2d(y, wb, None, 1, 1), bb)
+                else:
+                    x = hat_runtime.stage_forward(lvl, x, self._tokenizer(e["tok"]) if "tok" in e else None)
+                if "down" in e:
+                    lw, lb, eps, wd = e["down"]
+                    x = F.conv2d(self._ln2d(x, lw, lb, eps), wd, None, 2, 1)
+            hw, hb, ln = t["head"]
+            if ln is not None:
+                x = self._ln2d(x, *ln)
+            feat = x.float().mean(dim=(2, 3))
+            return F.linear(feat, hw, hb)

@@ -11,6 +11,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <string>
 #include <vector>
 
 #include "fvit_common.h"
@@ -36,6 +38,19 @@ int check_launch(const char* what) {
         return FVIT_ELAUNCH;
     }
     return FVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// tuning knobs
+// ------------------------------------------------------------------------------------------
+static std::map<std::string, int>& tune_map() {
+    static std::map<std::string, int> m;
+    return m;
+}
+int tune_get(const char* key, int dflt) {
+    auto& m = tune_map();
+    auto it = m.find(key);
+    return it == m.end() ? dflt : it->second;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -150,6 +165,13 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
 static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWeights& w, float* x, int64_t rows, void* xn, void* h,
                    hipStream_t st) {
     const int dt = d.operand_dtype;
+    // the fused kernel streams all MLP weights per 128-row workgroup: it wins once the launch fills the chip
+    // (>= ~16k rows; 104 vs 137 us at 54k rows) and loses on the latency-bound carrier branch (4k rows: 83 vs 31 us)
+    if (w.w_fc1_frag && w.w_fc2_frag && mlp_fused_supported(d.C, d.hidden) && rows >= tune_get("mlp_fused_min_rows", 16384) &&
+        tune_get("mlp_fused", 1)) {
+        MlpFusedCall mc = {dt, x, (int)rows, d.C, d.hidden, w.ln_w, w.ln_b, 1e-5f, w.w_fc1_frag, w.b_fc1, w.w_fc2_frag, w.b_fc2, w.gamma};
+        return launch_mlp_fused(mc, st);
+    }
     LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
     FVIT_TRY(launch_gather_layernorm(ln, st));
     GemmCall g1 = {dt, xn, L.ldn, w.w_fc1, L.ldn, w.b_fc1, nullptr, h, L.ldh, (int)rows, d.hidden, L.ldn, 1};
@@ -334,6 +356,21 @@ int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rows
     return launch_gather_layernorm(c, (hipStream_t)stream);
 }
 
+int fvit_mlp_fused_supported(int32_t C, int32_t hidden) { return mlp_fused_supported(C, hidden) ? 1 : 0; }
+
+int fvit_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,
+                   float eps, const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2,
+                   const float* gamma, fvit_stream_t stream) {
+    MlpFusedCall mc = {operand_dtype, x, M, C, hidden, ln_w, ln_b, eps, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma};
+    return launch_mlp_fused(mc, (hipStream_t)stream);
+}
+
+int fvit_tune(const char* key, int32_t value) {
+    if (!key) return FVIT_EINVAL;
+    tune_map()[key] = value;
+    return FVIT_OK;
+}
+
 int fvit_prof_enable(int on) {
     g_prof_on = on != 0;
     if (g_prof_on) g_recs.clear();
@@ -363,7 +400,8 @@ int fvit_prof_collect(FvitProfEntry* out) {
 
 const char* fvit_prof_kind_name(int kind) {
     static const char* names[FVIT_PROF_KINDS] = {"window_partition", "gather_layernorm", "gemm_bias", "gemm_gelu",
-                                                 "gemm_residual",    "window_attention", "window_reverse", "other"};
+                                                 "gemm_residual",    "window_attention", "window_reverse", "other",
+                                                 "mlp_fused"};
     return (kind >= 0 && kind < FVIT_PROF_KINDS) ? names[kind] : "?";
 }
 

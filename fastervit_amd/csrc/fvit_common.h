@@ -31,12 +31,49 @@ template <> struct Op16<__bf16> {
     }
 };
 
+// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): far below the 16-bit rounding of any GELU
+// output here, branch-free and much cheaper than libm erff inside fused epilogues.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    float y = 1.061405429f;
+    y = y * t - 1.453152027f;
+    y = y * t + 1.421413741f;
+    y = y * t - 0.284496736f;
+    y = y * t + 0.254829592f;
+    y = 1.0f - y * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+// nn.GELU() (exact-erf form, AR:403) without transcendentals: erf(z) ~ z * Q(z^2) on |z| <= 3 (degree-8 minimax fit,
+// |erf error| <= 2.6e-5 incl. the clamp tail 1 - erf(3) = 2.2e-5), GELU absolute error <= 5.4e-5 for all x -- an order of
+// magnitude below the 16-bit rounding of the value it feeds (scripts/fit_gelu.py reproduces the fit and the bound).
+// 14 plain VALU ops (SLP-packable into v_pk_fma_f32) instead of ~23 issue-cycle equivalents with rcp + exp: the fused
+// epilogues are VALU-bound, not MFMA-bound, on this term.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = __builtin_amdgcn_fmed3f(x * 0.70710678118654752f, -3.0f, 3.0f);
+    const float u = z * z;
+    float q = 4.075095461e-08f;
+    q = q * u - 1.945139275e-06f;
+    q = q * u + 4.106515917e-05f;
+    q = q * u - 5.110726343e-04f;
+    q = q * u + 4.235583358e-03f;
+    q = q * u - 2.510324307e-02f;
+    q = q * u + 1.110798195e-01f;
+    q = q * u - 3.753151596e-01f;
+    q = q * u + 1.128268480e+00f;
+    const float hx = 0.5f * x;
+    return hx * (z * q) + hx;
+}
+
 __host__ __device__ constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // ---- error plumbing (thread-local message, negative return codes) ----
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+
+// ---- tuning knobs (A/B experiments inside one process; see fvit_tune in fvit_hip.h) ----
+int tune_get(const char* key, int dflt);
 
 // ---- built-in kernel timer ----
 struct ProfScope {
@@ -61,6 +98,22 @@ struct GemmCall {
     int epilogue;        // 0 bias, 1 bias+gelu, 2 gamma-residual into f32
 };
 int launch_gemm(const GemmCall& c, hipStream_t stream);
+
+struct MlpFusedCall {
+    int dtype;
+    float* x;  // [M][C] f32 in place
+    int M, C, hidden;
+    const float* ln_w;
+    const float* ln_b;
+    float eps;
+    const void* w1f;  // fragment-major fc1 weight
+    const float* b1;
+    const void* w2f;  // fragment-major fc2 weight
+    const float* b2;
+    const float* gamma;
+};
+bool mlp_fused_supported(int C, int hidden);
+int launch_mlp_fused(const MlpFusedCall& c, hipStream_t stream);
 
 struct AttnCall {
     int dtype;

@@ -66,7 +66,6 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
     }
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float y = a[r] + bias[ni * 4 + r];
-                        if (EPI == 1) y = gelu_erf(y);
+                        if (EPI == 1) y = gelu_fast(y);
                         if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
                     }
                 }

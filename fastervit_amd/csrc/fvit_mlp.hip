@@ -1,0 +1,266 @@
+// fvit_mlp.hip -- fused MLP sub-block of HAT (gfx950):
+//
+//     x += gamma * ( fc2( GELU( fc1( LayerNorm(x) ) ) ) )            (AR:697 with AR:399-408; FV:691)
+//
+// in ONE kernel.  The unfused path moves the 4C-wide hidden activation through HBM twice and the
+// fp32 residual stream three times (LayerNorm, fc1, fc2 launches); here a workgroup reads its X
+// rows once, keeps LayerNorm(x) and both accumulators in registers, streams the weights from L2
+// through LDS, and writes X once: HBM traffic per row drops from ~18 C to 8 C bytes (+weights
+// once per XCD L2), which moves the sub-block from the HBM roof to the MFMA roof.
+//
+// How the hidden activation stays in registers ("transposed chaining"):
+//   GEMM1 is issued as H^T = W1 . Xn^T with v_mfma_f32_16x16x32 (A = W1 rows = hidden units,
+//   B = normalised activation rows).  Its accumulator layout -- lane (g = lane>>4, s = lane&15)
+//   holds H^T[unit = 4g + r][row = s] -- is exactly the B-operand layout of GEMM2
+//   OUT^T = W2 . H^T (k index = hidden unit, column = row) up to a permutation of the k slots,
+//   and an MFMA is invariant under any permutation of k applied to both operands.  So GELU(acc1)
+//   is converted to 16 bit and fed straight back as the B operand; W2 is pre-packed with its k
+//   slots in the matching order (fragment-major, see fvit_hip.h: w_fc1_frag / w_fc2_frag).
+//
+// Work split: 4 wave64 per workgroup, each wave owns RB*16 rows for the whole kernel (RB = 2 for
+// C = 256: 32 rows/wave, 128 rows/workgroup).  The hidden dimension is walked in chunks of 32
+// units: per chunk a wave issues RB*2*C/32 MFMAs for GEMM1 and RB*C/16 for GEMM2 against
+// 2*C/32 + C/16 ds_read_b128 of the shared weight chunk (0.5 KiB LDS per MFMA).  The chunk's
+// W1 (32 x C) and W2 (C x 32) slices arrive by 16-byte global_load_lds into a double-buffered
+// LDS image (2 x 2 x 16 KiB at C = 256; two workgroups per CU).  Both are pre-packed in MFMA
+// fragment order, so the copy is linear and every read is a conflict-free lane-linear
+// ds_read_b128 at an immediate offset; one barrier per chunk.
+#include "fvit_common.h"
+
+namespace fvit {
+
+namespace {
+
+struct MlpParams {
+    float* x;            // [M][C] fp32 residual stream, updated in place
+    const float* ln_w;
+    const float* ln_b;
+    const void* w1f;     // op16 fc1 weight, fragment-major: [hidden/32][2][C/32][64 lanes][8]
+    const float* b1;     // [hidden]
+    const void* w2f;     // op16 fc2 weight, fragment-major: [hidden/32][C/16][64 lanes][8]
+    const float* b2;     // [C]
+    const float* gamma;  // [C] or null
+    float eps;
+    int M, hidden;
+    int stagger;  // 1: workgroup b walks the hidden chunks starting at chunk b % nchunk (spreads the L2 channel load)
+    int ablate;   // timing experiments only (results are wrong): bit 0 = GELU -> identity, bit 1 = skip weight staging
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// Weights are static, so they are pre-packed in the exact MFMA fragment order (hat_runtime.frag_pack_*):
+// one fragment = 64 lanes x 16 bytes = 1 KiB = one global_load_lds instruction = one conflict-free
+// lane-linear ds_read_b128.  The HBM image of a 32-unit chunk IS its LDS image: staging is a linear copy and
+// every fragment address is (buffer base + lane*16 + compile-time immediate) -- one address register.
+template <typename T, int C, int RB, int NW, int MINW>
+__global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
+    constexpr int NBUF = 2;
+    typedef typename Op16<T>::v8 v8;
+    constexpr int KK = C / 32;             // GEMM1 k-steps
+    constexpr int CB = C / 16;             // output channel blocks
+    constexpr int W1_FRAGS = 2 * KK;       // fragments (KiB) of one W1 chunk: 32 hidden units x C
+    constexpr int W2_FRAGS = CB;           // fragments of one W2 chunk: C channels x 32 hidden units
+    constexpr int W1_BYTES = W1_FRAGS * 1024, W2_BYTES = W2_FRAGS * 1024;
+    constexpr int BUF_BYTES = W1_BYTES + W2_BYTES;
+    constexpr int ROWS_PER_WAVE = RB * 16;
+    constexpr int MAX_HIDDEN = 4 * C;      // fc1 bias staged in LDS once: no ordinary global loads inside the chunk loop
+                                           // (they queue behind the LDS-DMA prefetch in the in-order vmcnt counter and drain it)
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES + MAX_HIDDEN * 4];
+    float* b1s = (float*)(smem + NBUF * BUF_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, s = lane & 15;
+    const int row0 = blockIdx.x * (NW * ROWS_PER_WAVE) + wave * ROWS_PER_WAVE;
+    const int nchunk = p.hidden / 32;
+    const int jofs = p.stagger ? (int)(blockIdx.x % (unsigned)nchunk) : 0;
+    auto chunk_of = [&](int it) { int j = it + jofs; return j >= nchunk ? j - nchunk : j; };
+
+    const char* __restrict__ W1 = (const char*)p.w1f;
+    const char* __restrict__ W2 = (const char*)p.w2f;
+    const int lane16 = lane * 16;
+
+    // wave w copies fragments w, w+NW, w+2NW, ... of the chunk (W1 fragments first, then W2)
+    auto stage = [&](int j, char* buf) {
+        const char* s1 = W1 + (size_t)j * W1_BYTES + lane16;
+        const char* s2 = W2 + (size_t)j * W2_BYTES + lane16;
+#pragma unroll
+        for (int i = 0; i < W1_FRAGS / NW; ++i) glds16(s1 + (wave + NW * i) * 1024, buf + (wave + NW * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < W2_FRAGS / NW; ++i) glds16(s2 + (wave + NW * i) * 1024, buf + W1_BYTES + (wave + NW * i) * 1024);
+    };
+
+    for (int i = tid; i < p.hidden; i += 64 * NW) b1s[i] = p.b1[i];
+    stage(chunk_of(0), smem);
+
+    // ---- LayerNorm of this wave's rows straight into B-operand fragments ----
+    // lane (g, s) holds channels kk*32 + g*8 .. +8 (kk = 0..KK-1) of row rb*16 + s
+    v8 xf[RB][KK];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int row = min(row0 + rb * 16 + s, p.M - 1);  // tail rows recompute the last row; never stored
+        const float* xr = p.x + (size_t)row * C + g * 8;
+        f4 v[KK][2];
+        float sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            v[kk][0] = *(const f4*)(xr + kk * 32);
+            v[kk][1] = *(const f4*)(xr + kk * 32 + 4);
+            sum += (v[kk][0][0] + v[kk][0][1]) + (v[kk][0][2] + v[kk][0][3]) + (v[kk][1][0] + v[kk][1][1]) + (v[kk][1][2] + v[kk][1][3]);
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f4 d = v[kk][h] - mean;
+                sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq / (float)C + p.eps);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const float* lw = p.ln_w + kk * 32 + g * 8;
+            const float* lb = p.ln_b + kk * 32 + g * 8;
+            v8 o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f4 w = *(const f4*)(lw + h * 4);
+                const f4 b = *(const f4*)(lb + h * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[h * 4 + r] = (T)((v[kk][h][r] - mean) * rstd * w[r] + b[r]);
+            }
+            xf[rb][kk] = o;
+        }
+    }
+
+    f4 acc2[CB][RB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc2[cb][rb] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    for (int it = 0; it < nchunk; ++it) {
+        const int j = chunk_of(it);
+        const char* buf = smem + (NBUF == 2 ? (it & 1) : 0) * BUF_BYTES + lane16;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (NBUF == 2) {
+            if (it + 1 < nchunk && !(p.ablate & 2)) stage(chunk_of(it + 1), smem + ((it + 1) & 1) * BUF_BYTES);
+        }
+        // ---- GEMM1: H^T[unit][row], 2 unit blocks x RB row blocks; unit = hb*16 + 4g + r ----
+        f4 acc1[2][RB];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc1[hb][rb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const v8 wf = *(const v8*)(buf + (hb * KK + kk) * 1024);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc1[hb][rb] = Op16<T>::mfma(wf, xf[rb][kk], acc1[hb][rb]);
+            }
+        }
+        // ---- bias + GELU, straight into GEMM2's B operand (k slot 8g + i <-> unit (i>>2)*16 + 4g + (i&3)) ----
+        const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
+        const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
+        v8 pf[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u0 = acc1[0][rb][r] + bA[r], u1 = acc1[1][rb][r] + bB[r];
+                pf[rb][r] = (T)((p.ablate & 1) ? u0 : gelu_fast(u0));
+                pf[rb][4 + r] = (T)((p.ablate & 1) ? u1 : gelu_fast(u1));
+            }
+        }
+        // ---- GEMM2: OUT^T[channel][row] += W2[channel][chunk units] . H^T ----
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const v8 wf = *(const v8*)(buf + W1_BYTES + cb * 1024);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc2[cb][rb] = Op16<T>::mfma(wf, pf[rb], acc2[cb][rb]);
+        }
+        if (NBUF == 1) {
+            __syncthreads();
+            if (it + 1 < nchunk) stage(chunk_of(it + 1), smem);
+        }
+    }
+
+    // ---- epilogue: x[row][c] += gamma[c] * (acc2 + b2[c]) ----
+    // fragment cb, A-row slot 4g + r <-> channel (cb>>2)*64 + 16g + (cb&3)*4 + r: a lane owns 16 consecutive channels per 4 blocks
+#pragma unroll
+    for (int cg = 0; cg < CB / 4; ++cg) {
+        const int c0 = cg * 64 + g * 16;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int row = row0 + rb * 16 + s;
+            if (row < p.M) {
+                float* px = p.x + (size_t)row * C + c0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f4 bv = *(const f4*)(p.b2 + c0 + q * 4);
+                    const f4 gv = p.gamma ? *(const f4*)(p.gamma + c0 + q * 4) : (f4){1.f, 1.f, 1.f, 1.f};
+                    f4 xv = *(f4*)(px + q * 4);
+                    const f4 a = acc2[cg * 4 + q][rb];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xv[r] += gv[r] * (a[r] + bv[r]);
+                    *(f4*)(px + q * 4) = xv;
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_t(const MlpFusedCall& c, hipStream_t stream) {
+    MlpParams p;
+    p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma;
+    p.eps = c.eps; p.M = c.M; p.hidden = c.hidden;
+    p.stagger = tune_get("mlp_stagger", 1);
+    p.ablate = tune_get("mlp_ablate", 0);
+    const double flops = 4.0 * c.M * (double)c.C * c.hidden;
+    const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
+    ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
+    if (c.C == 256) {
+        // variants for within-process A/B (fvit_tune "mlp_variant"); 0 is the default
+        switch (tune_get("mlp_variant", 0)) {
+            case 1: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p); break;
+            case 2: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 8, 2>), dim3((c.M + 127) / 128), dim3(512), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 1>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;
+            case 4: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 8, 2>), dim3((c.M + 255) / 256), dim3(512), 0, stream, p); break;
+            default: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;
+        }
+    } else {
+        set_error("mlp_fused: C=%d has no fused instance", c.C);
+        return FVIT_EINVAL;
+    }
+    return check_launch("mlp_fused_kernel");
+}
+
+}  // namespace
+
+bool mlp_fused_supported(int C, int hidden) { return C == 256 && hidden % 32 == 0 && hidden > 0 && hidden <= 4 * C; }
+
+int launch_mlp_fused(const MlpFusedCall& c, hipStream_t stream) {
+    if (!mlp_fused_supported(c.C, c.hidden) || c.M <= 0 || !c.x || !c.w1f || !c.w2f) {
+        set_error("mlp_fused: unsupported arguments C=%d hidden=%d M=%d", c.C, c.hidden, c.M);
+        return FVIT_EINVAL;
+    }
+    if (c.dtype == FVIT_F16) return launch_t<_Float16>(c, stream);
+    if (c.dtype == FVIT_BF16) return launch_t<__bf16>(c, stream);
+    set_error("mlp_fused: operand dtype %d not supported", c.dtype);
+    return FVIT_EINVAL;
+}
+
+}  // namespace fvit

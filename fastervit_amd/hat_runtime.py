@@ -148,9 +148,37 @@ def pack_mlp(mlp, norm, gamma, op_dtype, keep: _Keep) -> FvitMlpWeights:
     w1[:hid, :C_] = _f32(mlp.fc1.weight)
     w2 = torch.zeros(_rup(C_, FVIT_TILE_N), ldh, device=dev, dtype=torch.float32)
     w2[:C_, :hid] = _f32(mlp.fc2.weight)
+    w1f = w2f = None
+    if _lib.lib().fvit_mlp_fused_supported(C_, hid):
+        w1f = frag_pack_fc1(_f32(mlp.fc1.weight)).to(op_dtype)
+        w2f = frag_pack_fc2(_f32(mlp.fc2.weight)).to(op_dtype)
     return FvitMlpWeights(keep.ptr(w1.to(op_dtype), True), keep.ptr(_f32(mlp.fc1.bias)), keep.ptr(w2.to(op_dtype), True),
                           keep.ptr(_f32(mlp.fc2.bias)), keep.ptr(_f32(norm.weight)), keep.ptr(_f32(norm.bias)),
-                          keep.ptr(_gamma(gamma)))
+                          keep.ptr(_gamma(gamma)), keep.ptr(w1f, True), keep.ptr(w2f, True))
+
+
+def frag_pack_fc1(w1: torch.Tensor) -> torch.Tensor:
+    """fc1.weight (hidden, C) -> [hidden/32][2][C/32][64][8] in MFMA A-fragment order (include/fvit_hip.h: w_fc1_frag):
+    element e of lane 16g + s of fragment (j, hb, kk) = w1[j*32 + hb*16 + s][kk*32 + 8g + e]."""
+    hid, C_ = w1.shape
+    t = w1.view(hid // 32, 2, 16, C_ // 32, 4, 8)       # j, hb, s, kk, g, e
+    return t.permute(0, 1, 3, 4, 2, 5).contiguous()      # j, hb, kk, g, s, e
+
+
+def frag_pack_fc2(w2: torch.Tensor) -> torch.Tensor:
+    """fc2.weight (C, hidden) -> [hidden/32][C/16][64][8] (include/fvit_hip.h: w_fc2_frag): element e of lane 16g + s of
+    fragment (j, cb) = w2[ch(cb, s)][j*32 + (e>>2)*16 + 4g + (e&3)], ch(cb, s) = (cb>>2)*64 + (s>>2)*16 + (cb&3)*4 + (s&3)."""
+    C_, hid = w2.shape
+    dev = w2.device
+    cb = torch.arange(C_ // 16, device=dev).view(-1, 1)
+    s = torch.arange(16, device=dev).view(1, -1)
+    ch = ((cb >> 2) * 64 + (s >> 2) * 16 + (cb & 3) * 4 + (s & 3)).reshape(-1)          # (CB*16,)
+    g = torch.arange(4, device=dev).view(-1, 1)
+    e = torch.arange(8, device=dev).view(1, -1)
+    col = ((e >> 2) * 16 + 4 * g + (e & 3)).reshape(-1)                                   # (32,) indexed by 8g + e
+    t = w2.view(C_, hid // 32, 32)[ch][:, :, col]                                          # (CB*16, nch, 32)
+    t = t.view(C_ // 16, 16, hid // 32, 4, 8)                                              # cb, s, j, g, e
+    return t.permute(2, 0, 3, 1, 4).contiguous()                                           # j, cb, g, s, e
 
 
 def pack_block(blk, S: int, G: int, dpad: int, op_dtype, keep: _Keep) -> FvitBlockWeights:
@@ -269,8 +297,11 @@ def _check_mode(layer):
 
 
 @torch.no_grad()
-def stage_forward(layer, x: torch.Tensor) -> torch.Tensor:
-    """Transformer branch of FasterViTLayer.forward (AR:848-869) minus the Downsample."""
+def stage_forward(layer, x: torch.Tensor, tokenizer=None) -> torch.Tensor:
+    """Transformer branch of FasterViTLayer.forward (AR:848-869) minus the Downsample.
+
+    ``tokenizer`` (optional) replaces the layer's TokenInitializer module with an equivalent callable
+    returning f32 (B, G, C) carrier tokens (deploy mode passes a 16-bit channels_last version)."""
     _check_mode(layer)
     _require_gpu(x, "FasterViTLayer")
     lib = _lib.lib()
@@ -286,7 +317,10 @@ def stage_forward(layer, x: torch.Tensor) -> torch.Tensor:
         return x
     if layer.do_gt and blk0.do_sr_hat:
         # TokenInitializer stays a PyTorch-ROCm dwconv + pool (north_star); runs in the model's dtype
-        ct = layer.global_tokenizer(xp.to(layer.global_tokenizer.pos_embed.weight.dtype)).float().contiguous()
+        if tokenizer is not None:
+            ct = tokenizer(xp)
+        else:
+            ct = layer.global_tokenizer(xp.to(layer.global_tokenizer.pos_embed.weight.dtype)).float().contiguous()
     st, tb, ctables, dc = _prepare(layer, x.device, Hp, Wp)
     desc, ws_t = _workspace(st, dc, B, H, W, x.device)
     out = torch.empty_like(x)  # keeps dtype and memory format (NCHW or channels_last)

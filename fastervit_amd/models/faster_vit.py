@@ -421,6 +421,17 @@ class FasterViT(nn.Module):
             lvl.hat_operand_dtype = name
         return self
 
+    def switch_to_deploy(self, dtype=torch.float16):
+        """Opt-in inference plan for the conv side (fastervit_amd/conv_runtime.py): BatchNorm folded into the conv
+        weights, 16-bit channels_last activations, fused bias/activation/residual/LayerNorm2d HIP passes.
+        ``forward`` then returns fp32 logits for GPU inputs; ``switch_to_deploy(None)`` goes back to module mode."""
+        if dtype is None:
+            self.__dict__.pop("_deploy_plan", None)
+            return self
+        from ..conv_runtime import DeployPlan
+        self.__dict__["_deploy_plan"] = DeployPlan(self, dtype)
+        return self
+
     def forward_features(self, x):
         x = self.patch_embed(x)
         for level in self.levels:
@@ -431,6 +442,9 @@ class FasterViT(nn.Module):
         return self.head(torch.flatten(self.avgpool(x), 1))
 
     def forward(self, x):
+        plan = self.__dict__.get("_deploy_plan")
+        if plan is not None and x.is_cuda and not self.training:
+            return plan.forward(x)
         return self.forward_head(self.forward_features(x))
 
     def _load_state_dict(self, pretrained, strict: bool = False):

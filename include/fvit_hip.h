@@ -96,6 +96,14 @@ typedef struct FvitMlpWeights {
     const float* ln_w;
     const float* ln_b;
     const float* gamma;  /* f32 [C] or NULL */
+    /* Optional (both NULL => unfused path): weights pre-packed in MFMA fragment order for the fused MLP kernel
+     * (csrc/fvit_mlp.hip).  One fragment = 64 lanes x 8 elements (1 KiB); lane = 16*g + s (g = 0..3, s = 0..15), e = 0..7:
+     *   w_fc1_frag [hidden/32][2 (hb)][C/32 (kk)][64][8]:  fc1.weight[j*32 + hb*16 + s][kk*32 + 8g + e]
+     *   w_fc2_frag [hidden/32][C/16 (cb)][64][8]:          fc2.weight[ch(cb, s)][j*32 + (e>>2)*16 + 4g + (e&3)]
+     *                                                       ch(cb, s) = (cb>>2)*64 + (s>>2)*16 + (cb&3)*4 + (s&3)
+     * (the k-slot order of w_fc2_frag is the order in which GELU(fc1) leaves the first MFMA's accumulator) */
+    const void* w_fc1_frag;
+    const void* w_fc2_frag;
 } FvitMlpWeights;
 
 /* One HAT block (AR:572-707 / FV:571-701). */
@@ -193,8 +201,33 @@ int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rows
                           const float* ln_b, float eps, int32_t rows, int32_t rows_per_image, int32_t C,
                           fvit_stream_t stream);
 
+/* Fused MLP sub-block: x[m][:] += gamma * fc2(GELU(fc1(LayerNorm(x[m][:])))) in one kernel (AR:697, AR:399-408).
+ * x f32 [M][C] in place; w_fc1_frag / w_fc2_frag as in FvitMlpWeights.
+ * Supported: C == 256, hidden % 32 == 0, hidden <= 4C (fvit_mlp_fused_supported); otherwise FVIT_EINVAL. */
+int fvit_mlp_fused_supported(int32_t C, int32_t hidden);
+int fvit_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w,
+                   const float* ln_b, float eps, const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag,
+                   const float* b_fc2, const float* gamma, fvit_stream_t stream);
+
+/* ---- conv-side glue (deploy mode), channels-last 16-bit maps: x[pixel][c], C contiguous ----
+ * With BatchNorm folded into the conv weights at load, the PyTorch-ROCm convolutions of PatchEmbed /
+ * ConvBlock / Downsample run bias-free and these three HBM-bound passes do the rest. */
+/* x = act(x + bias[c]) in place; act 0 none, 1 ReLU (PatchEmbed FV:460-464), 2 GELU-erf (ConvBlock FV:507). */
+int fvit_bias_act_cl(int32_t dtype, void* x, const float* bias, int64_t n_pixels, int32_t C, int32_t act,
+                     fvit_stream_t stream);
+/* x = x + y + bias[c] in place (ConvBlock residual, FV:512, with conv2's bias and norm2/gamma folded). */
+int fvit_bias_residual_cl(int32_t dtype, void* x, const void* y, const float* bias, int64_t n_pixels, int32_t C,
+                          fvit_stream_t stream);
+/* Per-pixel LayerNorm over C (timm LayerNorm2d of Downsample, FV:432,438; eps 1e-6), fp32 statistics. */
+int fvit_layernorm2d_cl(int32_t dtype, const void* in, void* out, const float* weight, const float* bias, float eps,
+                        int64_t n_pixels, int32_t C, fvit_stream_t stream);
+
+/* Performance-experiment knob (never changes results beyond fp32 summation order): e.g. "mlp_fused" 0/1,
+ * "mlp_stagger" 0/1, "mlp_rb" 1/2.  Not thread safe; meant for A/B runs inside one process. */
+int fvit_tune(const char* key, int32_t value);
+
 /* ---- built-in kernel timer (HIP events around every launch, on the launch stream) ---- */
-#define FVIT_PROF_KINDS 8
+#define FVIT_PROF_KINDS 9
 /* kind ids */
 #define FVIT_K_PARTITION 0
 #define FVIT_K_LAYERNORM 1
@@ -204,6 +237,7 @@ int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rows
 #define FVIT_K_ATTENTION 5
 #define FVIT_K_REVERSE 6
 #define FVIT_K_OTHER 7
+#define FVIT_K_MLP_FUSED 8
 typedef struct FvitProfEntry {
     int64_t launches;
     double ms;     /* summed event-to-event time */

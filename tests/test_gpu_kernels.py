@@ -192,3 +192,64 @@ def test_errors_are_reported_not_swallowed():
         _lib.check(rc, "gemm")
     rc = lib.fvit_window_attention(1, None, 96, None, 64, None, 1, 300, 1, 32, ctypes.c_float(1.0), _stream())
     assert rc == -1 and b"no kernel instance" in lib.fvit_last_error()
+
+
+@pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
+@pytest.mark.parametrize("C", [64, 196, 256])
+def test_glue_kernels(dt, code, C):
+    """bias+activation, bias+residual, LayerNorm2d on channels_last 16-bit maps vs PyTorch."""
+    lib = _lib.lib()
+    B, H, W = 3, 14, 9
+    g = torch.Generator(device="cpu").manual_seed(C)
+    x = torch.randn(B, C, H, W, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    y = torch.randn(B, C, H, W, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(C, generator=g).cuda()
+    tol = 1e-2 if dt == torch.float16 else 6e-2
+    for act, fn in [(0, lambda t: t), (1, torch.relu), (2, F.gelu)]:
+        z = x.clone()
+        _lib.check(lib.fvit_bias_act_cl(code, z.data_ptr(), bias.data_ptr(), B * H * W, C, act, _stream()), "bias_act")
+        ref = fn(x.float() + bias.view(1, -1, 1, 1))
+        assert (z.float() - ref).abs().max().item() < tol
+    z = x.clone()
+    _lib.check(lib.fvit_bias_residual_cl(code, z.data_ptr(), y.data_ptr(), bias.data_ptr(), B * H * W, C, _stream()), "bias_res")
+    assert (z.float() - (x.float() + y.float() + bias.view(1, -1, 1, 1))).abs().max().item() < 2 * tol
+    if C % 8 == 0:
+        w = (torch.rand(C, generator=g) + 0.5).cuda()
+        out = torch.empty_like(x)
+        _lib.check(lib.fvit_layernorm2d_cl(code, x.data_ptr(), out.data_ptr(), w.data_ptr(), bias.data_ptr(),
+                                           ctypes.c_float(1e-6), B * H * W, C, _stream()), "ln2d")
+        ref = F.layer_norm(x.float().permute(0, 2, 3, 1), (C,), w, bias, 1e-6).permute(0, 3, 1, 2)
+        assert (out.float() - ref).abs().max().item() < 4 * tol
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("M,use_gamma", [(128, True), (300, False), (54272, True), (4096, True), (17, True)])
+def test_mlp_fused(opname, dt, code, M, use_gamma):
+    """x += gamma * fc2(GELU(fc1(LN(x)))) in one kernel vs PyTorch fp32 on 16-bit-rounded weights."""
+    lib = _lib.lib()
+    C, hid = 256, 1024
+    assert lib.fvit_mlp_fused_supported(C, hid) == 1 and lib.fvit_mlp_fused_supported(784, 3136) == 0
+    g = torch.Generator(device="cpu").manual_seed(M)
+    x0 = (torch.randn(M, C, generator=g) * 1.5 + 0.3).cuda()
+    lnw = (torch.rand(C, generator=g) + 0.5).cuda()
+    lnb = (torch.randn(C, generator=g) * 0.2).cuda()
+    w1 = (torch.randn(hid, C, generator=g) / C ** 0.5).to(dt).cuda()
+    b1 = (torch.randn(hid, generator=g) * 0.3).cuda()
+    w2 = (torch.randn(C, hid, generator=g) / hid ** 0.5).to(dt).cuda()
+    b2 = (torch.randn(C, generator=g) * 0.3).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda() if use_gamma else None
+    w1p = hat_runtime.frag_pack_fc1(w1.float()).to(dt).contiguous()
+    w2c = hat_runtime.frag_pack_fc2(w2.float()).to(dt).contiguous()
+    x = x0.clone()
+    rc = lib.fvit_mlp_fused(code, x.data_ptr(), M, C, hid, lnw.data_ptr(), lnb.data_ptr(), ctypes.c_float(1e-5), w1p.data_ptr(),
+                            b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(), gamma.data_ptr() if use_gamma else None, _stream())
+    _lib.check(rc, "mlp_fused")
+    torch.cuda.synchronize()
+    xn = F.layer_norm(x0, (C,), lnw, lnb, 1e-5).to(dt).float()
+    h = F.gelu(xn @ w1.float().t() + b1).to(dt).float()
+    y = h @ w2.float().t() + b2
+    ref = x0 + (gamma * y if use_gamma else y)
+    tol = (3e-3 if dt == torch.float16 else 2e-2) * ref.abs().max().item()
+    assert torch.isfinite(x).all()
+    assert (x - ref).abs().max().item() < tol

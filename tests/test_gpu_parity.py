@@ -184,3 +184,25 @@ def test_oracle_on_gpu_box_matches_goldens():
     _, sd = build_product_model(name)
     logits = model_forward(sd, case_input(name), CASES[name]["arch"])
     assert max_abs(logits, g["logits"]) < 2e-4 * np.abs(g["logits"]).max()
+
+
+@pytest.mark.parametrize("name,tol", [("fvit0_224", 4e-3), ("tiny_hier", None), ("tiny_anyres", None), ("tiny_w14", None)])
+def test_deploy_mode_vs_reference(name, tol):
+    """switch_to_deploy(): BN folded into the convs, fp16 channels_last conv side, fused glue kernels."""
+    g = load_golden(name)
+    model, _ = build_product_model(name, "cuda")
+    model.switch_to_deploy(torch.float16)
+    with torch.no_grad():
+        logits = model(case_input(name).cuda()).float().cpu()
+    err, rel = max_abs(logits, g["logits"]), rel_err(logits, g["logits"])
+    print(f"{name} deploy-mode (fp16 conv side) logits max-abs err {err:.3e}, relative {rel:.3e}")
+    assert (err < tol) if tol is not None else (rel < 1e-2)
+    # a weight update is picked up (plan is rebuilt from the new parameter versions)
+    with torch.no_grad():
+        model.head.bias.add_(1.0)
+        logits2 = model(case_input(name).cuda()).float().cpu()
+    assert max_abs(logits2 - 1.0, logits) < 1e-3
+    model.switch_to_deploy(None)
+    with torch.no_grad():
+        logits3 = model(case_input(name).cuda()).float().cpu()
+    assert rel_err(logits3 - 1.0, g["logits"]) < 5e-3
