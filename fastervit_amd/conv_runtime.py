@@ -56,6 +56,8 @@ class DeployPlan:
         self.code = _CODE[dtype]
         self.sig = None
         self.t = None
+        self.zeros = None
+        self.use_hip_conv = True  # fused implicit-GEMM conv kernel where the shape allows; False = MIOpen + glue passes
 
     # ---- folding -------------------------------------------------------------------------
     def _signature(self):
@@ -68,7 +70,35 @@ class DeployPlan:
         return tuple(sig)
 
     def _cw(self, w):
-        return w.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        """(MIOpen weight, HIP-kernel weight): the channels_last 16-bit tensor for F.conv2d, and -- when the fused
+        implicit-GEMM kernel supports the shape (3x3, Cin and Cout multiples of 64) -- its [Cout][3][3][Cin] matrix view."""
+        wcl = w.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        co, ci, kh, kw = w.shape
+        wk = None
+        if self.use_hip_conv and kh == 3 and kw == 3 and ci % 64 == 0 and co % 64 == 0:
+            wk = wcl.permute(0, 2, 3, 1).contiguous()
+        return wcl, wk
+
+    def _conv(self, x, w, bias, stride, act, residual=None):
+        """act(conv3x3(x, w) + bias) (+ residual): one fused HIP kernel when supported, else MIOpen conv + glue passes."""
+        wcl, wk = w
+        B, Ci, Hi, Wi = x.shape
+        if wk is not None and x.is_contiguous(memory_format=torch.channels_last):
+            Co = wk.shape[0]
+            Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+            out = residual if residual is not None else torch.empty((B, Co, Ho, Wo), dtype=self.dtype, device=x.device,
+                                                                    memory_format=torch.channels_last)
+            if self.zeros is None or self.zeros.device != x.device:
+                self.zeros = torch.zeros(256, dtype=self.dtype, device=x.device)
+            rc = _lib.lib().fvit_conv3x3_nhwc(self.code, x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                              residual.data_ptr() if residual is not None else None, out.data_ptr(), B, Hi, Wi,
+                                              Ci, Co, stride, act, self.zeros.data_ptr(), _stream())
+            _lib.check(rc, "fvit_conv3x3_nhwc")
+            return out
+        y = F.conv2d(x, wcl, None, stride, 1)
+        if residual is not None:
+            return self._bias_residual(residual, y, bias)
+        return self._bias_act(y, bias, act) if bias is not None else y
 
     @torch.no_grad()
     def _build(self):
@@ -90,7 +120,7 @@ class DeployPlan:
                 e["blocks"] = blocks
             elif getattr(lvl, "do_gt", False):
                 tk = lvl.global_tokenizer
-                e["tok"] = (self._cw(tk.pos_embed.weight.float()), tk.pos_embed.bias.to(self.dtype).contiguous(),
+                e["tok"] = (self._cw(tk.pos_embed.weight.float())[0], tk.pos_embed.bias.to(self.dtype).contiguous(),
                             tk.to_global_feature.pool.kernel_size, tk.to_global_feature.pool.stride, tk.window_size)
             if lvl.downsample is not None:
                 ds = lvl.downsample
@@ -153,18 +183,18 @@ class DeployPlan:
         with torch.autocast(device_type="cuda", enabled=False):
             x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
             w0, b0, w1, b1 = t["stem"]
-            x = self._bias_act(F.conv2d(x, w0, None, 2, 1), b0, 1)
-            x = self._bias_act(F.conv2d(x, w1, None, 2, 1), b1, 1)
+            x = self._conv(x, w0, b0, 2, 1)
+            x = self._conv(x, w1, b1, 2, 1)
             for lvl, e in zip(self.model.levels, t["levels"]):
                 if "blocks" in e:
                     for wa, ba, wb, bb in e["blocks"]:
-                        y = self._bias_act(F.conv2d(x, wa, None, 1, 1), ba, 2)
-                        x = self._bias_residual(x, F.conv2d(y, wb, None, 1, 1), bb)
+                        y = self._conv(x, wa, ba, 1, 2)
+                        x = self._conv(y, wb, bb, 1, 0, residual=x)
                 else:
                     x = hat_runtime.stage_forward(lvl, x, self._tokenizer(e["tok"]) if "tok" in e else None)
                 if "down" in e:
                     lw, lb, eps, wd = e["down"]
-                    x = F.conv2d(self._ln2d(x, lw, lb, eps), wd, None, 2, 1)
+                    x = self._conv(self._ln2d(x, lw, lb, eps), wd, None, 2, 0)
             hw, hb, ln = t["head"]
             if ln is not None:
                 x = self._ln2d(x, *ln)

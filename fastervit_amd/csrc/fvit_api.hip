@@ -401,7 +401,7 @@ int fvit_prof_collect(FvitProfEntry* out) {
 const char* fvit_prof_kind_name(int kind) {
     static const char* names[FVIT_PROF_KINDS] = {"window_partition", "gather_layernorm", "gemm_bias", "gemm_gelu",
                                                  "gemm_residual",    "window_attention", "window_reverse", "other",
-                                                 "mlp_fused"};
+                                                 "mlp_fused",        "conv3x3"};
     return (kind >= 0 && kind < FVIT_PROF_KINDS) ? names[kind] : "?";
 }
 

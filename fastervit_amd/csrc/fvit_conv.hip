@@ -1,0 +1,243 @@
+// fvit_conv.hip -- 3x3 convolution (pad 1, stride 1 or 2) on channels-last 16-bit maps as an implicit
+// GEMM on the MFMA cores, with the whole conv-side epilogue fused (gfx950):
+//
+//   out[b,yo,xo,co] = act( sum_{ky,kx,ci} in[b, yo*s+ky-1, xo*s+kx-1, ci] * w[co,ky,kx,ci] + bias[co] ) (+ res[b,yo,xo,co])
+//
+// Replaces, in deploy mode, the MIOpen convolution + bias/BatchNorm + ReLU/GELU + residual passes of
+// PatchEmbed.conv_down[3..5] (FV:462-464), ConvBlock (FV:502-512) and Downsample.reduction (FV:435):
+// BatchNorm (eval) and the layer scale are folded into w/bias at load (conv_runtime.py), so one kernel does
+// what PyTorch-ROCm spreads over a conv, an OpTensor pass and one or two elementwise passes.
+//
+// Design: it is the GEMM of fvit_gemm.hip (M = B*Ho*Wo output pixels, N = Cout, K = 9*Cin) whose A tile
+// is gathered on the fly: with channels-last input one (ky,kx) tap of one pixel is a contiguous run of
+// Cin 16-bit values, so a K step of 64 channels is one 128-byte row per output pixel.  The gather is done
+// by the per-lane SOURCE address of the 16-byte global_load_lds (no im2col buffer, no VGPR round trip);
+// out-of-image taps read a caller-provided zero page.  Weights in channels-last layout [Cout][3][3][Cin]
+// are already the K-major B^T matrix.  Tiles: 64*WM pixels x 64*WN channels per workgroup of 4 waves
+// (WM x WN = 2x2 for Cout % 128 == 0, 4x1 = 256 pixels x 64 channels otherwise), BK = 64, double-buffered
+// LDS, one barrier per K step, swizzled fragment reads, XCD-aware tile order, 16 consecutive output channels
+// per lane in the epilogue (32-byte stores, 16-byte residual loads).
+#include "fvit_common.h"
+
+namespace fvit {
+
+namespace {
+
+constexpr int BK = 64;
+
+struct ConvParams {
+    const void* in;
+    const void* w;       // [Cout][9*Cin]
+    const float* bias;   // [Cout] or null
+    const void* res;     // [M][Cout] or null
+    void* out;           // [M][Cout]
+    const void* zeros;   // >= 128 bytes of zeros
+    int B, Hi, Wi, Cin, Cout, Ho, Wo, stride, act;
+    int M, tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int swz_x(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int swz_w(int r) { return ((0x78 >> (2 * ((r >> 4) & 3))) & 3) | ((r & 2) << 1); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <typename T, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
+    typedef typename Op16<T>::v8 v8;
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int X_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
+    constexpr int XP = BM / 8 / 4;  // 1-KiB pieces (8 rows) of the X tile each wave stages per K step
+    constexpr int WP = BN / 8 / 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (X_BYTES + W_BYTES)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, rr = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const int v = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const T* __restrict__ In = (const T*)p.in;
+    const T* __restrict__ W = (const T*)p.w;
+    const T* __restrict__ Z = (const T*)p.zeros;
+    const int ldw = 9 * p.Cin;
+
+    // ---- per-lane gather state for the rows this lane stages (fixed for the whole K loop) ----
+    const T* rowbase[XP];   // &in[b][yo*s-1][xo*s-1][0] (may point outside the image; only used when the tap is valid)
+    int rowmask[XP];        // bit ky*3+kx set <=> tap inside the image
+    int rowchunk[XP];       // swizzled 16-byte chunk this lane copies
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int r = (wave * XP + i) * 8 + (lane >> 3);
+        const int m = m0 + r;
+        int mask = 0;
+        const T* base = Z;
+        if (m < p.M) {
+            const int hw = p.Ho * p.Wo;
+            const int bb = m / hw, rem = m - bb * hw;
+            const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+            const int yi = yo * p.stride - 1, xi = xo * p.stride - 1;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    if (yi + ky >= 0 && yi + ky < p.Hi && xi + kx >= 0 && xi + kx < p.Wi) mask |= 1 << (ky * 3 + kx);
+            base = In + (((int64_t)bb * p.Hi + yi) * p.Wi + xi) * p.Cin;
+        }
+        rowbase[i] = base;
+        rowmask[i] = mask;
+        rowchunk[i] = ((lane & 7) ^ swz_x(r)) * 8;
+    }
+
+    const int cpt = p.Cin / BK;  // K steps per tap
+    auto stage = [&](int kt, char* xbuf, char* wbuf) {
+        const int tap = kt / cpt, ci0 = (kt - tap * cpt) * BK;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int toff = (ky * p.Wi + kx) * p.Cin + ci0;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const T* src = ((rowmask[i] >> tap) & 1) ? rowbase[i] + toff + rowchunk[i] : Z + rowchunk[i];
+            glds16(src, xbuf + (wave * XP + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            const int piece = wave * WP + i;
+            const int r = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ swz_w(r);
+            glds16(W + (size_t)(n0 + r) * ldw + kt * BK + c * 8, wbuf + piece * 1024);
+        }
+    };
+
+    f4 acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = 9 * cpt;
+    stage(0, smem, smem + 2 * X_BYTES);
+
+    const int g = lane >> 4, s = lane & 15;
+    int xrow[4], wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xrow[i] = wm * 64 + i * 16 + s;
+        wrow[i] = wn * 64 + (s >> 2) * 16 + i * 4 + (s & 3);
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, smem + (cur ^ 1) * X_BYTES, smem + 2 * X_BYTES + (cur ^ 1) * W_BYTES);
+        const char* xt = smem + cur * X_BYTES;
+        const char* wt = smem + 2 * X_BYTES + cur * W_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int c = kk * 4 + g;
+            v8 xf[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xf[i] = *(const v8*)(xt + xrow[i] * 128 + ((c ^ swz_x(xrow[i])) << 4));
+                wf[i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[ni], xf[mi], acc[ni][mi]);
+        }
+    }
+
+    // ---- epilogue: lane holds out[m][nb .. nb+15] for 4 pixels m ----
+    const int nb = n0 + wn * 64 + g * 16;
+    float bias[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f4 t = p.bias ? *(const f4*)(p.bias + nb + j * 4) : (f4){0.f, 0.f, 0.f, 0.f};
+        bias[j * 4 + 0] = t[0]; bias[j * 4 + 1] = t[1]; bias[j * 4 + 2] = t[2]; bias[j * 4 + 3] = t[3];
+    }
+    T* O = (T*)p.out;
+    const T* R = (const T*)p.res;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + s;
+        if (m < p.M) {
+            v8 r0, r1;
+            if (R) {
+                r0 = *(const v8*)(R + (size_t)m * p.Cout + nb);
+                r1 = *(const v8*)(R + (size_t)m * p.Cout + nb + 8);
+            }
+            v8 o0, o1;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const f4 a = acc[ni][mi];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float y = a[r] + bias[ni * 4 + r];
+                    if (p.act == 1) y = fmaxf(y, 0.f);
+                    else if (p.act == 2) y = gelu_fast(y);
+                    if (R) y += (float)(ni < 2 ? r0[ni * 4 + r] : r1[(ni - 2) * 4 + r]);
+                    if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
+                }
+            }
+            T* po = O + (size_t)m * p.Cout + nb;
+            *(v8*)po = o0;
+            *(v8*)(po + 8) = o1;
+        }
+    }
+}
+
+template <typename T>
+int launch_t(ConvParams& p, hipStream_t stream) {
+    const double flops = 2.0 * p.M * (double)p.Cout * 9.0 * p.Cin;
+    const double bytes = 2.0 * ((double)p.B * p.Hi * p.Wi * p.Cin + (double)p.M * p.Cout * (p.res ? 2.0 : 1.0) + 9.0 * p.Cin * p.Cout);
+    ProfScope prof(FVIT_K_CONV, flops, bytes, stream);
+    if (p.Cout % 128 == 0) {
+        p.tiles_m = (p.M + 127) / 128;
+        p.tiles_n = p.Cout / 128;
+        hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+    } else {
+        p.tiles_m = (p.M + 255) / 256;
+        p.tiles_n = p.Cout / 64;
+        hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+    }
+    return check_launch("conv3x3_kernel");
+}
+
+}  // namespace
+}  // namespace fvit
+
+using namespace fvit;
+
+extern "C" int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual, void* out,
+                                 int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride, int32_t act,
+                                 const void* zeros, fvit_stream_t stream) {
+    if (!in || !weight || !out || !zeros || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 64) ||
+        (stride != 1 && stride != 2) || act < 0 || act > 2) {
+        set_error("conv3x3: unsupported arguments Cin=%d Cout=%d stride=%d act=%d (need Cin %% 64 == 0, Cout %% 64 == 0, stride 1|2)",
+                  Cin, Cout, stride, act);
+        return FVIT_EINVAL;
+    }
+    ConvParams p;
+    p.in = in; p.w = weight; p.bias = bias; p.res = residual; p.out = out; p.zeros = zeros;
+    p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.act = act;
+    p.Ho = (Hi + 2 - 3) / stride + 1;
+    p.Wo = (Wi + 2 - 3) / stride + 1;
+    const int64_t M = (int64_t)B * p.Ho * p.Wo;
+    if (M > 0x7fffffff) {
+        set_error("conv3x3: %lld output pixels exceed the 32-bit row index", (long long)M);
+        return FVIT_EINVAL;
+    }
+    p.M = (int)M;
+    if (dtype == FVIT_F16) return launch_t<_Float16>(p, (hipStream_t)stream);
+    if (dtype == FVIT_BF16) return launch_t<__bf16>(p, (hipStream_t)stream);
+    set_error("conv3x3: dtype %d not supported (16-bit maps only)", dtype);
+    return FVIT_EINVAL;
+}

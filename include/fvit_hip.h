@@ -222,12 +222,23 @@ int fvit_bias_residual_cl(int32_t dtype, void* x, const void* y, const float* bi
 int fvit_layernorm2d_cl(int32_t dtype, const void* in, void* out, const float* weight, const float* bias, float eps,
                         int64_t n_pixels, int32_t C, fvit_stream_t stream);
 
+/* 3x3 convolution, pad 1, stride 1 or 2, on channels-last 16-bit maps as an implicit GEMM on the MFMA cores with the
+ * epilogue fused: out = act(conv(in, weight) + bias) (+ residual).  Replaces (deploy mode, BatchNorm folded into
+ * weight/bias) conv + BN + ReLU of PatchEmbed (FV:462-464), conv-BN-GELU / conv-BN-gamma-residual of ConvBlock
+ * (FV:502-512) and Downsample.reduction (FV:435).
+ *   in [B][Hi][Wi][Cin], weight [Cout][3][3][Cin] (= channels_last storage of the PyTorch weight), bias f32 [Cout] or
+ *   NULL, residual [B][Ho][Wo][Cout] or NULL (may alias out), out [B][Ho][Wo][Cout]; act 0 none / 1 ReLU / 2 GELU;
+ *   zeros: >= 128 bytes of zeros (padding taps read it).  Needs Cin % 64 == 0 and Cout % 64 == 0. */
+int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual,
+                      void* out, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride,
+                      int32_t act, const void* zeros, fvit_stream_t stream);
+
 /* Performance-experiment knob (never changes results beyond fp32 summation order): e.g. "mlp_fused" 0/1,
  * "mlp_stagger" 0/1, "mlp_rb" 1/2.  Not thread safe; meant for A/B runs inside one process. */
 int fvit_tune(const char* key, int32_t value);
 
 /* ---- built-in kernel timer (HIP events around every launch, on the launch stream) ---- */
-#define FVIT_PROF_KINDS 9
+#define FVIT_PROF_KINDS 10
 /* kind ids */
 #define FVIT_K_PARTITION 0
 #define FVIT_K_LAYERNORM 1
@@ -238,6 +249,7 @@ int fvit_tune(const char* key, int32_t value);
 #define FVIT_K_REVERSE 6
 #define FVIT_K_OTHER 7
 #define FVIT_K_MLP_FUSED 8
+#define FVIT_K_CONV 9
 typedef struct FvitProfEntry {
     int64_t launches;
     double ms;     /* summed event-to-event time */

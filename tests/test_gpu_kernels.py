@@ -253,3 +253,39 @@ def test_mlp_fused(opname, dt, code, M, use_gamma):
     tol = (3e-3 if dt == torch.float16 else 2e-2) * ref.abs().max().item()
     assert torch.isfinite(x).all()
     assert (x - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
+@pytest.mark.parametrize("B,Ci,Co,H,W,stride,act,res", [
+    (2, 64, 64, 14, 14, 1, 2, False), (3, 64, 64, 9, 13, 1, 0, True), (2, 64, 64, 16, 16, 2, 1, False),
+    (2, 64, 128, 12, 10, 2, 0, False), (2, 128, 128, 7, 9, 1, 2, False), (1, 128, 128, 28, 28, 1, 0, True),
+    (2, 128, 256, 14, 14, 2, 0, False), (1, 256, 512, 14, 14, 2, 0, False), (5, 64, 64, 56, 56, 1, 0, True)])
+def test_conv3x3_fused(dt, code, B, Ci, Co, H, W, stride, act, res):
+    """Implicit-GEMM 3x3 conv + bias + activation (+ residual) on channels_last 16-bit maps vs F.conv2d in fp32."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5).to(dt).cuda()
+    bias = torch.randn(Co, generator=g).cuda()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(B, Co, Ho, Wo, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last) if res else None
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    zeros = torch.zeros(256, dtype=dt, device="cuda")
+    out = torch.full((B, Co, Ho, Wo), float("nan"), dtype=dt, device="cuda").contiguous(memory_format=torch.channels_last)
+    rc = lib.fvit_conv3x3_nhwc(code, x.data_ptr(), wk.data_ptr(), bias.data_ptr(), r.data_ptr() if res else None, out.data_ptr(), B, H, W,
+                               Ci, Co, stride, act, zeros.data_ptr(), _stream())
+    _lib.check(rc, "conv3x3")
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float(), w.float(), bias, stride, 1)
+    ref = [lambda t: t, torch.relu, F.gelu][act](ref)
+    if res:
+        ref = ref + r.float()
+    assert torch.isfinite(out.float()).all()
+    tol = (5e-3 if dt == torch.float16 else 3e-2) * max(ref.abs().max().item(), 1.0)
+    assert (out.float() - ref).abs().max().item() < tol
+    if res:  # in place into the residual buffer
+        r2 = r.clone()
+        _lib.check(lib.fvit_conv3x3_nhwc(code, x.data_ptr(), wk.data_ptr(), bias.data_ptr(), r2.data_ptr(), r2.data_ptr(), B, H, W, Ci, Co,
+                                         stride, act, zeros.data_ptr(), _stream()), "conv3x3 in place")
+        torch.cuda.synchronize()
+        assert torch.equal(r2, out)
