@@ -108,6 +108,11 @@ class DeployPlan:
         w0, b0 = _fold(pe[0], pe[1])
         w1, b1 = _fold(pe[3], pe[4])
         t["stem"] = (self._cw(w0), b0.contiguous(), self._cw(w1), b1.contiguous())
+        t["stem_k"] = None
+        if self.use_hip_conv and tuple(w0.shape) == (64, 3, 3, 3) and pe[0].stride == (2, 2):
+            wk = torch.zeros(64, 32, device=w0.device, dtype=torch.float32)
+            wk[:, :27] = w0.permute(0, 2, 3, 1).reshape(64, 27)       # k = ky*9 + kx*3 + c
+            t["stem_k"] = wk.to(self.dtype).contiguous()
         t["levels"] = []
         for lvl in m.levels:
             e = {}
@@ -181,9 +186,18 @@ class DeployPlan:
             self.sig = sig
         t = self.t
         with torch.autocast(device_type="cuda", enabled=False):
-            x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
             w0, b0, w1, b1 = t["stem"]
-            x = self._conv(x, w0, b0, 2, 1)
+            if t["stem_k"] is not None and x.shape[1] == 3 and x.dtype in hat_runtime._DT:
+                B, _, Hi, Wi = x.shape   # fused stem kernel reads the caller's image in place (any strides, fp32/16-bit)
+                y = torch.empty((B, 64, (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1), dtype=self.dtype, device=x.device,
+                                memory_format=torch.channels_last)
+                view = hat_runtime._map_view(x)
+                _lib.check(_lib.lib().fvit_stem_conv3x3s2(self.code, view, t["stem_k"].data_ptr(), b0.data_ptr(), y.data_ptr(),
+                                                          B, Hi, Wi, _stream()), "fvit_stem_conv3x3s2")
+                x = y
+            else:
+                x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+                x = self._conv(x, w0, b0, 2, 1)
             x = self._conv(x, w1, b1, 2, 1)
             for lvl, e in zip(self.model.levels, t["levels"]):
                 if "blocks" in e:

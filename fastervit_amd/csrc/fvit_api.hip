@@ -9,6 +9,7 @@
 // The fp32 residual stream X holds the carrier tokens of every window in front of its ws^2 local
 // tokens for the whole stage, so torch.cat / split (AR:693,701) cost nothing.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -50,7 +51,13 @@ static std::map<std::string, int>& tune_map() {
 int tune_get(const char* key, int dflt) {
     auto& m = tune_map();
     auto it = m.find(key);
-    return it == m.end() ? dflt : it->second;
+    if (it != m.end()) return it->second;
+    // environment override FVIT_TUNE_<key>=<int>, read once per key
+    std::string env = std::string("FVIT_TUNE_") + key;
+    const char* v = getenv(env.c_str());
+    const int val = v ? atoi(v) : dflt;
+    m[key] = val;
+    return val;
 }
 
 // ------------------------------------------------------------------------------------------

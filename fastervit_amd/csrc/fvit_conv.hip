@@ -44,13 +44,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <typename T, int WM, int WN>
+// per-wave tile: 64 pixels x 16*NI channels; workgroup tile: 64*WM pixels x 16*NI*WN channels (WM*WN = 4 waves)
+template <typename T, int WM, int WN, int NI>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     typedef typename Op16<T>::v8 v8;
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 64 * WM, BN = 16 * NI * WN;
     constexpr int X_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
     constexpr int XP = BM / 8 / 4;  // 1-KiB pieces (8 rows) of the X tile each wave stages per K step
-    constexpr int WP = BN / 8 / 4;
+    constexpr int WPIECES = BN / 8;             // 1-KiB pieces of the W tile (8 rows each)
+    constexpr int WP = (WPIECES + 3) / 4;       // per wave (waves beyond WPIECES stage nothing)
     __shared__ __attribute__((aligned(16))) char smem[2 * (X_BYTES + W_BYTES)];
 
     const int tid = threadIdx.x;
@@ -109,15 +111,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < WP; ++i) {
             const int piece = wave * WP + i;
-            const int r = piece * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ swz_w(r);
-            glds16(W + (size_t)(n0 + r) * ldw + kt * BK + c * 8, wbuf + piece * 1024);
+            if (piece < WPIECES) {
+                const int r = piece * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ swz_w(r);
+                glds16(W + (size_t)(n0 + r) * ldw + kt * BK + c * 8, wbuf + piece * 1024);
+            }
         }
     };
 
-    f4 acc[4][4];  // [ni][mi]
+    f4 acc[NI][4];  // [ni][mi]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
@@ -125,12 +129,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     stage(0, smem, smem + 2 * X_BYTES);
 
     const int g = lane >> 4, s = lane & 15;
-    int xrow[4], wrow[4];
+    // weight row for A-row slot s of fragment i: wn*16*NI + (s>>2)*4*NI + i*4 + (s&3)  => lane (g, .) owns the 4*NI
+    // consecutive channels wn*16*NI + g*4*NI .. ; with NI = 4 this is the layout of fvit_gemm.hip
+    int xrow[4], wrow[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        xrow[i] = wm * 64 + i * 16 + s;
-        wrow[i] = wn * 64 + (s >> 2) * 16 + i * 4 + (s & 3);
-    }
+    for (int i = 0; i < 4; ++i) xrow[i] = wm * 64 + i * 16 + s;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wrow[i] = wn * 16 * NI + (s >> 2) * 4 * NI + i * 4 + (s & 3);
 
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -142,24 +147,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int c = kk * 4 + g;
-            v8 xf[4], wf[4];
+            v8 xf[4], wf[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xf[i] = *(const v8*)(xt + xrow[i] * 128 + ((c ^ swz_x(xrow[i])) << 4));
-                wf[i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
-            }
+            for (int i = 0; i < 4; ++i) xf[i] = *(const v8*)(xt + xrow[i] * 128 + ((c ^ swz_x(xrow[i])) << 4));
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int i = 0; i < NI; ++i) wf[i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[ni], xf[mi], acc[ni][mi]);
         }
     }
 
-    // ---- epilogue: lane holds out[m][nb .. nb+15] for 4 pixels m ----
-    const int nb = n0 + wn * 64 + g * 16;
-    float bias[16];
+    // ---- epilogue: lane holds out[m][nb .. nb + 4*NI - 1] for 4 pixels m ----
+    constexpr int NC = 4 * NI;  // consecutive channels per lane (16 or 8)
+    typedef T vout __attribute__((ext_vector_type(NC)));
+    const int nb = n0 + wn * 16 * NI + g * NC;
+    float bias[NC];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NI; ++j) {
         const f4 t = p.bias ? *(const f4*)(p.bias + nb + j * 4) : (f4){0.f, 0.f, 0.f, 0.f};
         bias[j * 4 + 0] = t[0]; bias[j * 4 + 1] = t[1]; bias[j * 4 + 2] = t[2]; bias[j * 4 + 3] = t[3];
     }
@@ -169,25 +175,100 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + s;
         if (m < p.M) {
-            v8 r0, r1;
-            if (R) {
-                r0 = *(const v8*)(R + (size_t)m * p.Cout + nb);
-                r1 = *(const v8*)(R + (size_t)m * p.Cout + nb + 8);
-            }
-            v8 o0, o1;
+            vout rv;
+            if (R) rv = *(const vout*)(R + (size_t)m * p.Cout + nb);
+            vout ov;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < NI; ++ni) {
                 const f4 a = acc[ni][mi];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float y = a[r] + bias[ni * 4 + r];
                     if (p.act == 1) y = fmaxf(y, 0.f);
                     else if (p.act == 2) y = gelu_fast(y);
-                    if (R) y += (float)(ni < 2 ? r0[ni * 4 + r] : r1[(ni - 2) * 4 + r]);
-                    if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
+                    if (R) y += (float)rv[ni * 4 + r];
+                    ov[ni * 4 + r] = (T)y;
                 }
             }
-            T* po = O + (size_t)m * p.Cout + nb;
+            *(vout*)(O + (size_t)m * p.Cout + nb) = ov;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Stem convolution: 3x3, stride 2, pad 1, Cin = 3 -> Cout = 64, + folded BatchNorm bias + ReLU (PatchEmbed.conv_down[0..2],
+// FV:458-460).  K = 27 is padded to one 32-deep MFMA step: lane (g, s) gathers k slots 8g..8g+7 of pixel s's 3x3x3 patch
+// straight from the caller's image (any strides / fp32, fp16 or bf16: the NCHW fp32 input of the model needs no
+// conversion pass), the 64x32 weight matrix lives in registers (4 fragments), and the 16-bit channels-last output --
+// the largest tensor of the network (B x 112 x 112 x 64) -- is written exactly once.  HBM-bound on that write.
+// ------------------------------------------------------------------------------------------------------------
+struct StemParams {
+    FvitMapView in;      // (B, 3, Hi, Wi)
+    const void* w;       // op16 [64][32]: k = ky*9 + kx*3 + c, zero for k >= 27
+    const float* bias;   // [64]
+    void* out;           // [B][Ho][Wo][64]
+    int B, Hi, Wi, Ho, Wo, M;
+};
+
+__device__ __forceinline__ float stem_load(const FvitMapView& v, int64_t off) {
+    if (v.dtype == FVIT_F32) return ((const float*)v.data)[off];
+    if (v.dtype == FVIT_F16) return (float)((const _Float16*)v.data)[off];
+    return (float)((const __bf16*)v.data)[off];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
+    typedef typename Op16<T>::v8 v8;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, s = lane & 15;
+    // weights: fragment ni, A-row slot s -> channel (s>>2)*16 + ni*4 + (s&3): lane (g, .) owns channels 16g .. 16g+15
+    const T* __restrict__ W = (const T*)p.w;
+    v8 wf[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const v8*)(W + ((s >> 2) * 16 + ni * 4 + (s & 3)) * 32 + g * 8);
+    float bias[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f4 t = *(const f4*)(p.bias + g * 16 + j * 4);
+        bias[j * 4 + 0] = t[0]; bias[j * 4 + 1] = t[1]; bias[j * 4 + 2] = t[2]; bias[j * 4 + 3] = t[3];
+    }
+    T* __restrict__ O = (T*)p.out;
+    const int hw = p.Ho * p.Wo;
+    const int nblk16 = (p.M + 15) >> 4;
+    // grid-stride over blocks of 16 output pixels; one wave per block
+    for (int blk = blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk16; blk += gridDim.x * 4) {
+        const int m = blk * 16 + s;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : p.M - 1;
+        const int bb = mm / hw, rem = mm - bb * hw;
+        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+        const int yi = yo * 2 - 1, xi = xo * 2 - 1;
+        const int64_t base = bb * p.in.stride_b;
+        v8 xf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = g * 8 + e;           // ky*9 + kx*3 + c
+            const int ky = k / 9, r9 = k - ky * 9, kx = r9 / 3, c = r9 - kx * 3;
+            const int y = yi + ky, x = xi + kx;
+            float v = 0.f;
+            if (k < 27 && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi)
+                v = stem_load(p.in, base + c * p.in.stride_c + y * p.in.stride_h + x * p.in.stride_w);
+            xf[e] = (T)v;
+        }
+        f4 acc[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = Op16<T>::mfma(wf[ni], xf, (f4){0.f, 0.f, 0.f, 0.f});
+        if (ok) {
+            v8 o0, o1;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y = fmaxf(acc[ni][r] + bias[ni * 4 + r], 0.f);
+                    if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
+                }
+            T* po = O + (size_t)m * 64 + g * 16;
             *(v8*)po = o0;
             *(v8*)(po + 8) = o1;
         }
@@ -199,14 +280,19 @@ int launch_t(ConvParams& p, hipStream_t stream) {
     const double flops = 2.0 * p.M * (double)p.Cout * 9.0 * p.Cin;
     const double bytes = 2.0 * ((double)p.B * p.Hi * p.Wi * p.Cin + (double)p.M * p.Cout * (p.res ? 2.0 : 1.0) + 9.0 * p.Cin * p.Cout);
     ProfScope prof(FVIT_K_CONV, flops, bytes, stream);
+    const int variant = tune_get("conv64_variant", 0);
     if (p.Cout % 128 == 0) {
         p.tiles_m = (p.M + 127) / 128;
         p.tiles_n = p.Cout / 128;
-        hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
-    } else {
+        hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+    } else if (variant == 1) {  // 256 pixels x 64 channels, 80 KiB LDS
         p.tiles_m = (p.M + 255) / 256;
         p.tiles_n = p.Cout / 64;
-        hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+    } else {  // 128 pixels x 64 channels, 48 KiB LDS: three workgroups per CU
+        p.tiles_m = (p.M + 127) / 128;
+        p.tiles_n = p.Cout / 64;
+        hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
     }
     return check_launch("conv3x3_kernel");
 }
@@ -240,4 +326,34 @@ extern "C" int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weig
     if (dtype == FVIT_BF16) return launch_t<__bf16>(p, (hipStream_t)stream);
     set_error("conv3x3: dtype %d not supported (16-bit maps only)", dtype);
     return FVIT_EINVAL;
+}
+
+extern "C" int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const void* weight, const float* bias, void* out, int32_t B,
+                                   int32_t Hi, int32_t Wi, fvit_stream_t stream) {
+    if (!in || !in->data || !weight || !bias || !out || B <= 0 || Hi <= 0 || Wi <= 0) {
+        set_error("stem_conv: null or empty argument");
+        return FVIT_EINVAL;
+    }
+    StemParams p;
+    p.in = *in; p.w = weight; p.bias = bias; p.out = out; p.B = B; p.Hi = Hi; p.Wi = Wi;
+    p.Ho = (Hi - 1) / 2 + 1;
+    p.Wo = (Wi - 1) / 2 + 1;
+    const int64_t M = (int64_t)B * p.Ho * p.Wo;
+    if (M > 0x7fffffff) {
+        set_error("stem_conv: too many output pixels");
+        return FVIT_EINVAL;
+    }
+    p.M = (int)M;
+    const int nblk16 = (p.M + 15) / 16;
+    int grid = (nblk16 + 3) / 4;
+    if (grid > 256 * 32) grid = 256 * 32;
+    const double bytes = (double)B * 3 * Hi * Wi * (in->dtype == FVIT_F32 ? 4 : 2) + 2.0 * M * 64;
+    ProfScope prof(FVIT_K_CONV, 2.0 * M * 64 * 27, bytes, (hipStream_t)stream);
+    if (dtype == FVIT_F16) hipLaunchKernelGGL((stem_conv_kernel<_Float16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (dtype == FVIT_BF16) hipLaunchKernelGGL((stem_conv_kernel<__bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else {
+        set_error("stem_conv: dtype %d not supported (16-bit output only)", dtype);
+        return FVIT_EINVAL;
+    }
+    return check_launch("stem_conv_kernel");
 }

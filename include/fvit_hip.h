@@ -233,6 +233,12 @@ int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weight, const f
                       void* out, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride,
                       int32_t act, const void* zeros, fvit_stream_t stream);
 
+/* Stem convolution of PatchEmbed (FV:458-460): 3x3, stride 2, pad 1, 3 -> 64 channels, + bias (folded BatchNorm) + ReLU.
+ * in: strided view of the (B, 3, Hi, Wi) image in fp32 / fp16 / bf16 (the model's NCHW fp32 input needs no conversion);
+ * weight: op16 [64][32], column k = ky*9 + kx*3 + c, zero for k >= 27; out: op16 [B][Ho][Wo][64] channels-last. */
+int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const void* weight, const float* bias, void* out,
+                        int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream);
+
 /* Performance-experiment knob (never changes results beyond fp32 summation order): e.g. "mlp_fused" 0/1,
  * "mlp_stagger" 0/1, "mlp_rb" 1/2.  Not thread safe; meant for A/B runs inside one process. */
 int fvit_tune(const char* key, int32_t value);

@@ -289,3 +289,29 @@ def test_conv3x3_fused(dt, code, B, Ci, Co, H, W, stride, act, res):
                                          stride, act, zeros.data_ptr(), _stream()), "conv3x3 in place")
         torch.cuda.synchronize()
         assert torch.equal(r2, out)
+
+
+@pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
+@pytest.mark.parametrize("in_dt,fmt", [(torch.float32, "nchw"), (torch.float16, "nhwc"), (torch.float32, "nhwc")])
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (3, 30, 22), (1, 224, 224)])
+def test_stem_conv(dt, code, in_dt, fmt, B, H, W):
+    """Fused stem: conv3x3 s2 (3 -> 64) + bias + ReLU straight from the caller's image, vs F.conv2d."""
+    import ctypes as C
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(H + W)
+    x = torch.randn(B, 3, H, W, generator=g).to(in_dt).cuda()
+    if fmt == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 3, 3, generator=g) / 27 ** 0.5).cuda()
+    bias = torch.randn(64, generator=g).cuda()
+    wk = torch.zeros(64, 32, device="cuda")
+    wk[:, :27] = w.permute(0, 2, 3, 1).reshape(64, 27)
+    wk = wk.to(dt).contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.full((B, 64, Ho, Wo), float("nan"), dtype=dt, device="cuda").contiguous(memory_format=torch.channels_last)
+    view = hat_runtime._map_view(x)
+    _lib.check(lib.fvit_stem_conv3x3s2(code, C.byref(view), wk.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, _stream()), "stem")
+    torch.cuda.synchronize()
+    ref = torch.relu(F.conv2d(x.float().to(dt).float(), wk[:, :27].float().view(64, 3, 3, 3).permute(0, 3, 1, 2), bias, 2, 1))
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - ref).abs().max().item() < (4e-3 if dt == torch.float16 else 3e-2) * max(ref.abs().max().item(), 1.0)
