@@ -22,7 +22,7 @@ FVIT_PROF_KINDS = 10
 # every symbol include/fvit_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = (
     "fvit_abi_version", "fvit_last_error", "fvit_attention_spad", "fvit_stage_workspace_bytes",
-    "fvit_workspace_init", "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_window_partition",
+    "fvit_workspace_init", "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_token_init", "fvit_window_partition",
     "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_window_attention",
     "fvit_gather_layernorm", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl", "fvit_conv3x3_nhwc", "fvit_stem_conv3x3s2",
     "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_kind_name",
@@ -93,6 +93,8 @@ def _declare(lib):
     lib.fvit_hat_block_forward.restype = C.c_int
     lib.fvit_hat_block_forward.argtypes = [C.POINTER(FvitStageDesc), C.POINTER(FvitBlockWeights),
                                            C.POINTER(FvitStageTables), vp, vp, vp, C.c_size_t, vp]
+    lib.fvit_token_init.restype = C.c_int
+    lib.fvit_token_init.argtypes = [C.POINTER(FvitMapView), vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.fvit_window_partition.restype = C.c_int
     lib.fvit_window_partition.argtypes = [C.POINTER(FvitMapView), i32, i32, i32, i32, i32, vp, vp]
     lib.fvit_window_reverse.restype = C.c_int

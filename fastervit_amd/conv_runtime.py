@@ -205,7 +205,7 @@ class DeployPlan:
                         y = self._conv(x, wa, ba, 1, 2)
                         x = self._conv(y, wb, bb, 1, 0, residual=x)
                 else:
-                    x = hat_runtime.stage_forward(lvl, x, self._tokenizer(e["tok"]) if "tok" in e else None)
+                    x = hat_runtime.stage_forward(lvl, x)  # TokenInitializer runs in fvit_token_init (HIP) in both modes
                 if "down" in e:
                     lw, lb, eps, wd = e["down"]
                     x = self._conv(self._ln2d(x, lw, lb, eps), wd, None, 2, 0)

@@ -322,6 +322,12 @@ int fvit_hat_block_forward(const FvitStageDesc* desc, const FvitBlockWeights* bl
     return FVIT_OK;
 }
 
+int fvit_token_init(const FvitMapView* in, const float* weight, const float* bias, float* ct_out, int32_t batch, int32_t C, int32_t Hp,
+                    int32_t Wp, int32_t pool_kh, int32_t pool_kw, int32_t pool_sh, int32_t pool_sw, int32_t cw, fvit_stream_t stream) {
+    if (!in || !weight || !bias || !ct_out) { set_error("null argument"); return FVIT_EINVAL; }
+    return launch_token_init(*in, weight, bias, ct_out, batch, C, Hp, Wp, pool_kh, pool_kw, pool_sh, pool_sw, cw, (hipStream_t)stream);
+}
+
 int fvit_window_partition(const FvitMapView* in, int32_t batch, int32_t C, int32_t Hp, int32_t Wp, int32_t ws, float* windows,
                           fvit_stream_t stream) {
     if (!in || !windows) { set_error("null argument"); return FVIT_EINVAL; }

@@ -170,6 +170,9 @@ int launch_reverse(const ReverseCall& c, hipStream_t stream);
 // copy f32 rows [rows][C] out of / into the windowed tensor's carrier slots (block-level API)
 int launch_ct_copy(float* x, int rows_per_win, int row_off, int ncw, float* ct, int nwin_total, int C, int to_x,
                    hipStream_t stream);
+// TokenInitializer: depthwise conv3x3 + bias + AvgPool2d + per-window reorder -> f32 (B, G, C)
+int launch_token_init(const FvitMapView& in, const float* w, const float* bias, float* out, int B, int C, int Hp, int Wp, int kh, int kw,
+                      int sh, int sw, int cw, hipStream_t stream);
 // x[win][ncw + t] += gamma * x[win][up_idx[t]] (block-level API; the stage API fuses this into window_reverse)
 int launch_propagate(float* x, const float* gamma, const int32_t* up_idx, int rows_per_win, int ncw, int nloc,
                      int nwin_total, int C, hipStream_t stream);

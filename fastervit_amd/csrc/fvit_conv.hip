@@ -236,6 +236,17 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
     T* __restrict__ O = (T*)p.out;
     const int hw = p.Ho * p.Wo;
     const int nblk16 = (p.M + 15) >> 4;
+    // this lane's 8 taps (k = 8g + e = ky*9 + kx*3 + c): offsets are pixel independent, computed once
+    int64_t toff[8];
+    int tky[8], tkx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = g * 8 + e;
+        const int ky = k / 9, r9 = k - ky * 9, kx = r9 / 3, c = r9 - kx * 3;
+        tky[e] = k < 27 ? ky : -100000;  // padded k slots can never be in range
+        tkx[e] = kx;
+        toff[e] = c * p.in.stride_c + ky * p.in.stride_h + kx * p.in.stride_w;
+    }
     // grid-stride over blocks of 16 output pixels; one wave per block
     for (int blk = blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk16; blk += gridDim.x * 4) {
         const int m = blk * 16 + s;
@@ -244,17 +255,16 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
         const int bb = mm / hw, rem = mm - bb * hw;
         const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
         const int yi = yo * 2 - 1, xi = xo * 2 - 1;
-        const int64_t base = bb * p.in.stride_b;
+        const int64_t base = bb * p.in.stride_b + yi * p.in.stride_h + xi * p.in.stride_w;
         v8 xf;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int k = g * 8 + e;           // ky*9 + kx*3 + c
-            const int ky = k / 9, r9 = k - ky * 9, kx = r9 / 3, c = r9 - kx * 3;
-            const int y = yi + ky, x = xi + kx;
-            float v = 0.f;
-            if (k < 27 && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi)
-                v = stem_load(p.in, base + c * p.in.stride_c + y * p.in.stride_h + x * p.in.stride_w);
-            xf[e] = (T)v;
+            const int y = yi + tky[e], x = xi + tkx[e];
+            const bool inb = y >= 0 && y < p.Hi && x >= 0 && x < p.Wi;
+            // always issue the load (clamped to the pixel's own centre tap, which is always inside), then mask
+            const int64_t off = inb ? base + toff[e] : base + p.in.stride_h + p.in.stride_w;
+            const float v = stem_load(p.in, off);
+            xf[e] = (T)(inb ? v : 0.f);
         }
         f4 acc[4];
 #pragma unroll

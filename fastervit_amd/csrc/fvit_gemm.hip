@@ -67,10 +67,14 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
 }
 
 
-template <typename T, int EPI>
+// NSTAGE = 2: double buffer, one drained barrier per K step, two workgroups per CU -- for grids that fill the chip.
+// NSTAGE = 3: three-deep ring with a COUNTED s_waitcnt vmcnt (the tile after the current one stays in flight across
+//             the raw s_barrier), one workgroup per CU -- for small grids (<= ~1.5 workgroups per CU), where a K step is
+//             otherwise one full LDS-DMA round trip (~1.3 us) because nothing else on the CU hides it.
+template <typename T, int EPI, int NSTAGE>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     typedef typename Op16<T>::v8 v8;
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // X0 X1 W0 W1
+    __shared__ __attribute__((aligned(16))) char smem[2 * NSTAGE * TILE_BYTES];  // X ring, then W ring
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -94,8 +98,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    stage_tile<T, false>(A, p.lda, m0, 0, smem, wave, lane);
-    stage_tile<T, true>(W, p.ldw, n0, 0, smem + 2 * TILE_BYTES, wave, lane);
+    char* const xring = smem;
+    char* const wring = smem + NSTAGE * TILE_BYTES;
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st) {
+        if (st < nk) {
+            stage_tile<T, false>(A, p.lda, m0, st * BK, xring + st * TILE_BYTES, wave, lane);
+            stage_tile<T, true>(W, p.ldw, n0, st * BK, wring + st * TILE_BYTES, wave, lane);
+        }
+    }
 
     // per-lane fragment addressing (bytes inside a tile)
     const int g = lane >> 4, s = lane & 15;
@@ -106,16 +117,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         wrow[i] = wn * 64 + (s >> 2) * 16 + i * 4 + (s & 3);      // weight row for A-row slot s of fragment i
     }
 
+    int cur = 0;  // ring slot of tile kt
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            stage_tile<T, false>(A, p.lda, m0, (kt + 1) * BK, smem + (cur ^ 1) * TILE_BYTES, wave, lane);
-            stage_tile<T, true>(W, p.ldw, n0, (kt + 1) * BK, smem + (2 + (cur ^ 1)) * TILE_BYTES, wave, lane);
+        if (NSTAGE == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            // each wave issues 8 LDS-DMA instructions per stage (4 X + 4 W pieces): tile kt has landed once at most the
+            // 8 of tile kt+1 are still outstanding.  Raw barrier: __syncthreads() would drain the queue (vmcnt(0)).
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        const char* xt = smem + cur * TILE_BYTES;
-        const char* wt = smem + (2 + cur) * TILE_BYTES;
+        {
+            // refill the slot that was read in iteration kt-1 (every wave is past that: it arrived at this barrier)
+            const int nxt = kt + NSTAGE - 1;
+            int slot = cur + NSTAGE - 1;
+            if (slot >= NSTAGE) slot -= NSTAGE;
+            if (nxt < nk) {
+                stage_tile<T, false>(A, p.lda, m0, nxt * BK, xring + slot * TILE_BYTES, wave, lane);
+                stage_tile<T, true>(W, p.ldw, n0, nxt * BK, wring + slot * TILE_BYTES, wave, lane);
+            }
+        }
+        const char* xt = xring + cur * TILE_BYTES;
+        const char* wt = wring + cur * TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int c = kk * 4 + g;
@@ -130,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[ni], xf[mi], acc[ni][mi]);
         }
+        if (++cur == NSTAGE) cur = 0;
     }
 
     // ---- epilogue: lane holds out[m][nb .. nb+15] for 4 rows m (one per mi) ----
@@ -209,10 +234,20 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
         kind = c.epilogue == 1 ? FVIT_K_GEMM_GELU : FVIT_K_GEMM_BIAS;
     }
     ProfScope prof(kind, flops, bytes, stream);
-    switch (c.epilogue) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<T, 0>), dim3(grid), dim3(256), 0, stream, p); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<T, 1>), dim3(grid), dim3(256), 0, stream, p); break;
-        default: hipLaunchKernelGGL((gemm_kernel<T, 2>), dim3(grid), dim3(256), 0, stream, p); break;
+    // measured r01: no gain over the 2-stage kernel at 64..392 workgroups (0.868 vs 0.820 ms per step) => opt-in only
+    const bool deep = grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
+    if (deep) {
+        switch (c.epilogue) {
+            case 0: hipLaunchKernelGGL((gemm_kernel<T, 0, 3>), dim3(grid), dim3(256), 0, stream, p); break;
+            case 1: hipLaunchKernelGGL((gemm_kernel<T, 1, 3>), dim3(grid), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((gemm_kernel<T, 2, 3>), dim3(grid), dim3(256), 0, stream, p); break;
+        }
+    } else {
+        switch (c.epilogue) {
+            case 0: hipLaunchKernelGGL((gemm_kernel<T, 0, 2>), dim3(grid), dim3(256), 0, stream, p); break;
+            case 1: hipLaunchKernelGGL((gemm_kernel<T, 1, 2>), dim3(grid), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((gemm_kernel<T, 2, 2>), dim3(grid), dim3(256), 0, stream, p); break;
+        }
     }
     return check_launch("gemm_kernel");
 }

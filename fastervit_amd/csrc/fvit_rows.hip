@@ -282,6 +282,61 @@ __global__ __launch_bounds__(256) void propagate_kernel(float* x, const float* g
     *px = *px + gv * cv;
 }
 
+// ------------------------------------------------------------------------------------------
+// TokenInitializer (AR:715-750 / FV:709-738) in one pass: depthwise 3x3 conv (pad 1) + bias, AvgPool2d(k, s), and the
+// view/permute into per-window carrier order, written as the f32 (B, G, C) tensor the stage kernel takes as ct_init.
+// One thread per (image, carrier token, channel), channels fastest (coalesced on channels-last maps).
+// ------------------------------------------------------------------------------------------
+struct TokParams {
+    FvitMapView in;      // (B, C, Hp, Wp) padded map
+    const float* w;      // [C][3][3]
+    const float* bias;   // [C]
+    float* out;          // [B][G][C]
+    int B, C, Hp, Wp, kh, kw, sh, sw, Ho, Wo, cw;
+};
+
+__global__ __launch_bounds__(256) void token_init_kernel(TokParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int G = p.Ho * p.Wo;
+    if (i >= (int64_t)p.B * G * p.C) return;
+    const int c = (int)(i % p.C);
+    const int64_t t = i / p.C;
+    const int tok = (int)(t % G), b = (int)(t / G);
+    // windowed order: tok = ((a * (Wo/cw) + bb) * cw + ii) * cw + kk  <->  pooled pixel (a*cw + ii, bb*cw + kk)
+    const int kk = tok % p.cw, r1 = tok / p.cw, ii = r1 % p.cw, r2 = r1 / p.cw, nbw = p.Wo / p.cw, bb = r2 % nbw, a = r2 / nbw;
+    const int oy = a * p.cw + ii, ox = bb * p.cw + kk;
+    float wv[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) wv[j] = p.w[c * 9 + j];
+    const int64_t base = b * p.in.stride_b + c * p.in.stride_c;
+    // sum over the pooling window of the 3x3 depthwise responses == weighted sum over the (kh+2) x (kw+2) input patch
+    float acc = 0.f;
+    const int y0 = oy * p.sh - 1, x0 = ox * p.sw - 1;
+    for (int dy = 0; dy < p.kh + 2; ++dy) {
+        const int y = y0 + dy;
+        if (y < 0 || y >= p.Hp) continue;
+        for (int dx = 0; dx < p.kw + 2; ++dx) {
+            const int x = x0 + dx;
+            if (x < 0 || x >= p.Wp) continue;
+            // input (y, x) feeds conv output (y - ky + 1, x - kx + 1); count the taps whose output lies inside the pool window
+            float wsum = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int py = dy - ky;  // conv-output row relative to the window start
+                if (py < 0 || py >= p.kh) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int px = dx - kx;
+                    if (px < 0 || px >= p.kw) continue;
+                    wsum += wv[ky * 3 + kx];
+                }
+            }
+            acc += wsum * load_elem(p.in.data, base + y * p.in.stride_h + x * p.in.stride_w, p.in.dtype);
+        }
+    }
+    p.out[i] = acc / (float)(p.kh * p.kw) + p.bias[c];
+}
+
 int launch_map(const MapParams& p, bool reverse, hipStream_t stream) {
     const int hh = reverse ? p.H : p.Hp, wwid = reverse ? p.W : p.Wp;
     if (p.map.stride_c == 1) {
@@ -366,6 +421,23 @@ int launch_ct_copy(float* x, int rows_per_win, int row_off, int ncw, float* ct, 
     hipLaunchKernelGGL(ct_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ct, rows_per_win, row_off, ncw,
                        nrows, C4, to_x);
     return check_launch("ct_rows_kernel");
+}
+
+int launch_token_init(const FvitMapView& in, const float* w, const float* bias, float* out, int B, int C, int Hp, int Wp, int kh, int kw,
+                      int sh, int sw, int cw, hipStream_t stream) {
+    TokParams p;
+    p.in = in; p.w = w; p.bias = bias; p.out = out; p.B = B; p.C = C; p.Hp = Hp; p.Wp = Wp;
+    p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.cw = cw;
+    p.Ho = (Hp - kh) / sh + 1;
+    p.Wo = (Wp - kw) / sw + 1;
+    if (kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || cw <= 0 || p.Ho <= 0 || p.Wo <= 0 || (p.Ho % cw) || (p.Wo % cw)) {
+        set_error("token_init: bad pooling geometry k=%dx%d s=%dx%d on %dx%d (cw=%d)", kh, kw, sh, sw, Hp, Wp, cw);
+        return FVIT_EINVAL;
+    }
+    const int64_t n = (int64_t)B * p.Ho * p.Wo * C;
+    ProfScope prof(FVIT_K_OTHER, 0.0, (double)B * C * Hp * Wp * 2.0 + 4.0 * n, stream);
+    hipLaunchKernelGGL(token_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
+    return check_launch("token_init_kernel");
 }
 
 int launch_propagate(float* x, const float* gamma, const int32_t* up_idx, int rows_per_win, int ncw, int nloc, int nwin_total,

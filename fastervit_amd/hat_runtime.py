@@ -290,6 +290,32 @@ def _workspace(st: StageState, desc_common: dict, B: int, H: int, W: int, device
     return desc, ws_t
 
 
+@torch.no_grad()
+def token_init(tok, xp: torch.Tensor) -> torch.Tensor:
+    """TokenInitializer.forward (AR:745-750) through fvit_token_init: depthwise conv + bias + avg-pool + per-window reorder
+    in one HIP kernel, f32 (B, G, C) out.  (MIOpen runs this depthwise conv on its naive path: ~150 us at B = 256.)"""
+    _require_gpu(xp, "TokenInitializer")
+    st = tok.__dict__.get("_fvit_tok")
+    sig = (tok.pos_embed.weight.data_ptr(), tok.pos_embed.weight._version, tok.pos_embed.bias._version, str(xp.device))
+    if st is None or st[0] != sig:
+        w = tok.pos_embed.weight.detach().float().reshape(-1, 9).contiguous().to(xp.device)
+        b = tok.pos_embed.bias.detach().float().contiguous().to(xp.device)
+        st = (sig, w, b)
+        tok.__dict__["_fvit_tok"] = st
+    _, w, b = st
+    pool = tok.to_global_feature.pool
+    kh, kw = pool.kernel_size if isinstance(pool.kernel_size, (tuple, list)) else (pool.kernel_size,) * 2
+    sh, sw = pool.stride if isinstance(pool.stride, (tuple, list)) else (pool.stride,) * 2
+    B, Cc, Hp, Wp = xp.shape
+    Ho, Wo = (Hp - kh) // sh + 1, (Wp - kw) // sw + 1
+    ct = torch.empty((B, Ho * Wo, Cc), dtype=torch.float32, device=xp.device)
+    view = _map_view(xp)
+    rc = _lib.lib().fvit_token_init(C.byref(view), w.data_ptr(), b.data_ptr(), ct.data_ptr(), B, Cc, Hp, Wp, kh, kw, sh, sw,
+                                    tok.window_size, _stream_ptr())
+    _lib.check(rc, "fvit_token_init")
+    return ct
+
+
 def _check_mode(layer):
     if layer.training and torch.is_grad_enabled():
         raise RuntimeError("the MI355X HAT path is inference-only (forward kernels); call model.eval() and run under "
@@ -320,7 +346,7 @@ def stage_forward(layer, x: torch.Tensor, tokenizer=None) -> torch.Tensor:
         if tokenizer is not None:
             ct = tokenizer(xp)
         else:
-            ct = layer.global_tokenizer(xp.to(layer.global_tokenizer.pos_embed.weight.dtype)).float().contiguous()
+            ct = token_init(layer.global_tokenizer, xp)
     st, tb, ctables, dc = _prepare(layer, x.device, Hp, Wp)
     desc, ws_t = _workspace(st, dc, B, H, W, x.device)
     out = torch.empty_like(x)  # keeps dtype and memory format (NCHW or channels_last)

@@ -168,6 +168,13 @@ int fvit_hat_block_forward(const FvitStageDesc* desc, const FvitBlockWeights* bl
                            const FvitStageTables* tables, float* x, float* ct, void* workspace,
                            size_t workspace_bytes, fvit_stream_t stream);
 
+/* TokenInitializer.forward (AR:745-750 with AR:737-741 / FV:733-738): depthwise 3x3 conv (pad 1, f32 weight [C][3][3] + bias [C]),
+ * AvgPool2d((pool_kh, pool_kw), (pool_sh, pool_sw)) and the view/permute into per-window carrier order, in one kernel.
+ * in: (B, C, Hp, Wp) padded map, any strides / fp32, fp16, bf16; ct_out: f32 (B, G, C), G = pooled H * pooled W. */
+int fvit_token_init(const FvitMapView* in, const float* weight, const float* bias, float* ct_out, int32_t batch, int32_t C,
+                    int32_t Hp, int32_t Wp, int32_t pool_kh, int32_t pool_kw, int32_t pool_sh, int32_t pool_sw, int32_t cw,
+                    fvit_stream_t stream);
+
 /* window_partition (AR:84-88) / window_reverse (AR:91-94) as standalone ops on f32 token tensors. */
 int fvit_window_partition(const FvitMapView* in, int32_t batch, int32_t C, int32_t Hp, int32_t Wp,
                           int32_t ws, float* windows, fvit_stream_t stream);

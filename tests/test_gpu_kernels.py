@@ -315,3 +315,26 @@ def test_stem_conv(dt, code, in_dt, fmt, B, H, W):
     ref = torch.relu(F.conv2d(x.float().to(dt).float(), wk[:, :27].float().view(64, 3, 3, 3).permute(0, 3, 1, 2), bias, 2, 1))
     assert torch.isfinite(out.float()).all()
     assert (out.float() - ref).abs().max().item() < (4e-3 if dt == torch.float16 else 3e-2) * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("fmt,dt", [("nchw", torch.float32), ("nhwc", torch.float16), ("nhwc", torch.bfloat16)])
+@pytest.mark.parametrize("C,res,ws,cw", [(64, (14, 14), 7, 2), (48, (6, 12), 3, 2), (32, (36, 60), 12, 2), (16, (8, 8), 4, 1)])
+def test_token_init(fmt, dt, C, res, ws, cw):
+    """fvit_token_init vs the oracle's TokenInitializer (depthwise conv + avg-pool + per-window reorder)."""
+    import ctypes as Ct
+    from fastervit_amd.models.faster_vit import TokenInitializer
+    lib = _lib.lib()
+    tok = TokenInitializer(C, list(res), ws, ct_size=cw).cuda()
+    g = torch.Generator(device="cpu").manual_seed(C)
+    with torch.no_grad():
+        tok.pos_embed.weight.copy_(torch.randn(C, 1, 3, 3, generator=g))
+        tok.pos_embed.bias.copy_(torch.randn(C, generator=g))
+    x = torch.randn(3, C, res[0], res[1], generator=g).to(dt).cuda()
+    if fmt == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    got = hat_runtime.token_init(tok, x)
+    torch.cuda.synchronize()
+    sd = {"t.pos_embed.weight": tok.pos_embed.weight.detach().cpu(), "t.pos_embed.bias": tok.pos_embed.bias.detach().cpu()}
+    ref = hr.token_initializer(x.float().cpu(), sd, "t.", res, ws, cw)
+    assert got.shape == ref.shape
+    assert (got.cpu() - ref).abs().max().item() < 2e-4 * max(ref.abs().max().item(), 1.0)
