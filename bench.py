@@ -131,7 +131,7 @@ def main():
     hat_ms = sum(e["ms"] for k, e in prof.items() if k not in ("other", "conv3x3")) / args.prof_steps
     # dominant HAT kernel = the MFMA kernel family with the largest summed time per step; its roof follows from its
     # algorithmic intensity (FLOP per compulsory HBM byte) against the ridge 2.5e15 / 8e12 = 312 FLOP/B
-    mfma_kinds = [k for k in prof if (k.startswith("gemm") or k == "mlp_fused") and prof[k]["launches"]]
+    mfma_kinds = [k for k in prof if (k.startswith("gemm") or k in ("mlp_fused", "attn_block_fused")) and prof[k]["launches"]]
     dom = max(mfma_kinds, key=lambda k: prof[k]["ms"])
     e = prof[dom]
     sec = e["ms"] * 1e-3

@@ -168,6 +168,13 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
     return FVIT_OK;
 }
 
+// the fused attention block wins once the launch fills the chip (92 vs 117 us at 54k rows); on the carrier branch (4k rows,
+// 32 workgroups) it is latency-bound and loses (38 vs 30 us)
+static bool fused_attn_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S, int64_t rows) {
+    return w.w_qkv_frag && w.b_qkv_heads && w.w_proj_frag && d.dpad == 32 && d.C / d.heads == 32 && attnblk_supported(d.C, d.heads, S) &&
+           rows >= tune_get("attn_fused_min_rows", 16384) && tune_get("attn_fused", 1);
+}
+
 // LN -> fc1 + GELU -> fc2 + gamma-residual
 static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWeights& w, float* x, int64_t rows, void* xn, void* h,
                    hipStream_t st) {
@@ -203,18 +210,36 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         void* RQKV = ws + L.off_RQKV;
         void* RAO = ws + L.off_RAO;
         void* RH = ws + L.off_RH;
-        // ct_dewindow gather (+ hat_pos_embed) -> R, LN(hat_norm1) -> Rn
-        LnCall ln = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), R, Rn, L.ldn,
-                     w.hat_attn.ln_w, w.hat_attn.ln_b, 1e-5f, (int)L.Mc, L.G, d.C};
-        FVIT_TRY(launch_gather_layernorm(ln, st));
-        FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st));
+        const float scale = 1.0f / sqrtf((float)(d.C / d.heads));
+        if (fused_attn_ok(d, w.hat_attn, L.G, L.Mc)) {
+            // ct_dewindow gather (+ hat_pos_embed), LN, qkv, attention over the G carrier tokens, proj, gamma1-residual -> R
+            AttnBlkCall ab = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), w.hat_attn.ln_w, w.hat_attn.ln_b,
+                              1e-5f, L.G, w.hat_attn.w_qkv_frag, w.hat_attn.b_qkv_heads, w.hat_attn.w_proj_frag, w.hat_attn.b_proj,
+                              w.hat_attn.gamma, w.hat_attn.bias, R, d.batch, L.G, d.heads, d.C, scale};
+            FVIT_TRY(launch_attnblk(ab, st));
+        } else {
+            // ct_dewindow gather (+ hat_pos_embed) -> R, LN(hat_norm1) -> Rn
+            LnCall ln = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), R, Rn, L.ldn,
+                         w.hat_attn.ln_w, w.hat_attn.ln_b, 1e-5f, (int)L.Mc, L.G, d.C};
+            FVIT_TRY(launch_gather_layernorm(ln, st));
+            FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st));
+        }
         FVIT_TRY(run_mlp(d, L, w.hat_mlp, R, L.Mc, Rn, RH, st));
     }
-    // cat(ct_window(ct), x + pos_embed) gather -> X, LN(norm1) -> Xn
-    LnCall ln1 = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, X, Xn, L.ldn,
-                  w.attn.ln_w, w.attn.ln_b, 1e-5f, (int)L.Mx, rpi, d.C};
-    FVIT_TRY(launch_gather_layernorm(ln1, st));
-    FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st));
+    if (fused_attn_ok(d, w.attn, L.S, L.Mx)) {
+        // cat(ct_window(ct), x + pos_embed) gather, LN(norm1), qkv, window attention, proj, gamma3-residual -> X, one kernel
+        const float scale = 1.0f / sqrtf((float)(d.C / d.heads));
+        AttnBlkCall ab = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, w.attn.ln_w, w.attn.ln_b, 1e-5f, rpi,
+                          w.attn.w_qkv_frag, w.attn.b_qkv_heads, w.attn.w_proj_frag, w.attn.b_proj, w.attn.gamma, w.attn.bias, X,
+                          d.batch * L.nW, L.S, d.heads, d.C, scale};
+        FVIT_TRY(launch_attnblk(ab, st));
+    } else {
+        // cat(ct_window(ct), x + pos_embed) gather -> X, LN(norm1) -> Xn
+        LnCall ln1 = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, X, Xn, L.ldn,
+                      w.attn.ln_w, w.attn.ln_b, 1e-5f, (int)L.Mx, rpi, d.C};
+        FVIT_TRY(launch_gather_layernorm(ln1, st));
+        FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st));
+    }
     FVIT_TRY(run_mlp(d, L, w.mlp, X, L.Mx, Xn, Hb, st));
     return FVIT_OK;
 }
@@ -369,6 +394,18 @@ int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rows
     return launch_gather_layernorm(c, (hipStream_t)stream);
 }
 
+int fvit_attn_block_supported(int32_t C, int32_t heads, int32_t S) { return attnblk_supported(C, heads, S) ? 1 : 0; }
+
+int fvit_attn_block_fused(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                          const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
+                          int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
+                          const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
+                          int32_t heads, int32_t C, float scale, fvit_stream_t stream) {
+    AttnBlkCall ab = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, ln_w, ln_b, eps, rows_per_image, w_qkv_frag,
+                      b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
+    return launch_attnblk(ab, (hipStream_t)stream);
+}
+
 int fvit_mlp_fused_supported(int32_t C, int32_t hidden) { return mlp_fused_supported(C, hidden) ? 1 : 0; }
 
 int fvit_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,
@@ -414,7 +451,7 @@ int fvit_prof_collect(FvitProfEntry* out) {
 const char* fvit_prof_kind_name(int kind) {
     static const char* names[FVIT_PROF_KINDS] = {"window_partition", "gather_layernorm", "gemm_bias", "gemm_gelu",
                                                  "gemm_residual",    "window_attention", "window_reverse", "other",
-                                                 "mlp_fused",        "conv3x3"};
+                                                 "mlp_fused",        "conv3x3",          "attn_block_fused"};
     return (kind >= 0 && kind < FVIT_PROF_KINDS) ? names[kind] : "?";
 }
 

@@ -1,0 +1,374 @@
+// fvit_attnblk.hip -- fused attention sub-block of HAT for head_dim 32, C = 256 (gfx950):
+//
+//   x_out = x_in + gamma * proj( softmax( q k^T * scale + bias ) v ),   [q|k|v] = qkv( LayerNorm(x_in) )
+//   x_in  = gathered source row (+ position embedding row)              (AR:671-696 / FV:665-690)
+//
+// ONE kernel instead of gather-LayerNorm + qkv GEMM + attention + proj GEMM: the unfused path moves the
+// normalised activations, the 3C-wide qkv tensor and the attention output through HBM and reads / writes the
+// fp32 residual stream twice; here a workgroup reads its rows once and writes them once.
+//
+// Work split: a workgroup of 8 wave64 owns 8 row blocks of 16 tokens = 8 / NRB windows (NRB = 4: windows of up
+// to 64 tokens, the 53-token HAT windows; NRB = 1: windows of up to 16 tokens, the carrier-token attention).
+// Each wave keeps LayerNorm(x) of its 16 rows as MFMA fragments (32 VGPR) and the proj accumulator of its 16
+// rows x 256 channels (64 VGPR) for the whole kernel, and walks the heads:
+//   P1  q^T, k^T (A = weight fragments, B = x fragments) and v (A = x fragments, B = weight fragments): 48 MFMAs.
+//       In these orientations the accumulators ARE the operands the next MFMAs need ("transposed chaining"):
+//       q^T -> B operand of S^T = K.Q^T, k^T -> A operand of S^T, v -> half an A operand of O^T = V^T.P^T.
+//   X   k and v fragments are exchanged between the NRB waves of a window through LDS (2 x 1 KiB per wave).
+//   P2  S^T = K.Q^T * scale + bias (folded table, staged in LDS), softmax down the key axis (in-lane + 2 xor
+//       shuffles), O^T = V^T.P^T: 8 MFMAs; the normalised O^T accumulator is the B operand of
+//   P3  out^T += Wproj[:, head] . O^T: 16 MFMAs.
+// Per head a workgroup needs 48 KiB of qkv weights, 16 KiB of proj weights and the head's bias table; all are
+// pre-packed in MFMA fragment order (HBM image = LDS image) and arrive by 16-byte global_load_lds: the proj /
+// bias slices of head h while P1(h) runs, the qkv slice of head h+1 while P2/P3(h) run.  Two barriers per head,
+// no ordinary global loads inside the head loop (they would queue behind the DMA in the in-order vmcnt counter).
+#include "fvit_common.h"
+
+namespace fvit {
+
+namespace {
+
+struct AttnBlkParams {
+    // gather + LayerNorm (same semantics as fvit_gather_layernorm)
+    const float* srcA;
+    const float* srcB;
+    const int32_t* src_idx;
+    const int32_t* add_idx;
+    const float* add;
+    const float* ln_w;
+    const float* ln_b;
+    float eps;
+    int rowsA, rowsB, rows_per_image;
+    // weights (fragment-major) and folded bias
+    const void* wqkv_f;   // op16 [heads][6][C/32][64][8]
+    const float* bqkv;    // f32  [heads][96]  (q 32, k 32, v 32)
+    const void* wproj_f;  // op16 [heads][C/16][64][8]
+    const float* bproj;   // f32  [C]
+    const float* gamma;   // f32  [C] or null
+    const float* bias;    // f32  [heads][SP][SP]
+    float* x_out;         // f32  [rows][C]
+    int nwin, S, heads;
+    float scale;
+    int ablate;  // timing experiments only (wrong results): 1 = no weight DMA inside the head loop, 2 = skip P1 MFMAs,
+                 // 4 = skip exchange + P2, 8 = skip P3
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// NRB: row blocks (of 16 tokens) per window: 4 (S <= 64) or 1 (S <= 16); NW: waves per workgroup (8 or 4);
+// BIAS_LDS: stage the head's bias table in LDS (else read it from L2 with ordinary loads issued ahead of the DMA)
+template <typename T, int NRB, int NW, bool BIAS_LDS>
+__global__ __launch_bounds__(64 * NW, 2) void attnblk_kernel(AttnBlkParams p) {
+    typedef typename Op16<T>::v8 v8;
+    typedef typename Op16<T>::v4 v4;
+    constexpr int C = 256, KK = C / 32, CB = C / 16;
+    constexpr int SP = NRB * 16;              // padded window length
+    constexpr int WPW = NW / NRB;             // windows per workgroup
+    constexpr int NKB32 = (NRB + 1) / 2;      // 32-key groups per window
+    constexpr int QKV_FRAGS = 6 * KK;         // 48 KiB
+    constexpr int QKV_BYTES = QKV_FRAGS * 1024, PROJ_BYTES = CB * 1024, BIAS_BYTES = BIAS_LDS ? SP * SP * 4 : 0;
+    constexpr int KX_BYTES = NW * 1024;       // one 1-KiB k fragment per wave
+    constexpr int VX_BYTES = WPW * 2 * NKB32 * 1024;
+    constexpr int OFF_PROJ = QKV_BYTES, OFF_BIAS = OFF_PROJ + PROJ_BYTES, OFF_KX = OFF_BIAS + ((BIAS_BYTES + 1023) / 1024) * 1024;
+    constexpr int OFF_VX = OFF_KX + KX_BYTES, OFF_BQ = OFF_VX + VX_BYTES;
+    constexpr int MAX_HEADS = 8;
+    __shared__ __attribute__((aligned(16))) char smem[OFF_BQ + MAX_HEADS * 96 * 4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, s = lane & 15;
+    const int lane16 = lane * 16;
+    const int wi = wave / NRB, qb = wave - wi * NRB;           // window inside the workgroup, row block inside the window
+    const int win = blockIdx.x * WPW + wi;
+    const bool win_ok = win < p.nwin;
+    const int tok = qb * 16 + s;                                // token inside the window
+    const bool row_ok = win_ok && tok < p.S;
+    const int64_t row = (int64_t)(win_ok ? win : p.nwin - 1) * p.S + (tok < p.S ? tok : p.S - 1);   // clamped: always a real row
+    float* bqs = (float*)(smem + OFF_BQ);
+
+    const char* __restrict__ Wq = (const char*)p.wqkv_f;
+    const char* __restrict__ Wp = (const char*)p.wproj_f;
+
+    auto dma_qkv = [&](int h) {   // 48 fragments
+        const char* src = Wq + (size_t)h * QKV_BYTES + lane16;
+#pragma unroll
+        for (int i = 0; i < QKV_FRAGS / NW; ++i) glds16(src + (wave + NW * i) * 1024, smem + (wave + NW * i) * 1024);
+    };
+    auto dma_proj_bias = [&](int h) {   // 16 proj fragments + (BIAS_LDS) the head's bias table
+        const char* src = Wp + (size_t)h * PROJ_BYTES + lane16;
+#pragma unroll
+        for (int i = 0; i < CB / NW; ++i) glds16(src + (wave + NW * i) * 1024, smem + OFF_PROJ + (wave + NW * i) * 1024);
+        if (BIAS_LDS) {
+            const char* bsrc = (const char*)(p.bias + (size_t)h * SP * SP) + lane16;
+            constexpr int BP = (BIAS_BYTES + 1023) / 1024;   // 16 (SP = 64) or 1 (SP = 16)
+#pragma unroll
+            for (int i = 0; i < (BP + NW - 1) / NW; ++i) {
+                const int piece = wave + NW * i;
+                if (piece < BP) glds16(bsrc + piece * 1024, smem + OFF_BIAS + piece * 1024);
+            }
+        }
+    };
+
+    // ---- prologue: qkv bias to LDS, first weight slice in flight, gather + LayerNorm into B/A fragments ----
+    for (int i = tid; i < p.heads * 96; i += 64 * NW) bqs[i] = p.bqkv[i];
+    if (NRB == 1) {   // the upper half of every 32-key group never gets written: keep it finite
+        for (int i = tid; i < VX_BYTES / 4; i += 64 * NW) ((float*)(smem + OFF_VX))[i] = 0.f;
+    }
+    dma_qkv(0);
+
+    const float* src;
+    const float* addp = nullptr;
+    {
+        const int b = (int)(row / p.rows_per_image), pr = (int)(row - (int64_t)b * p.rows_per_image);
+        if (p.src_idx) {
+            const int si = p.src_idx[pr];
+            src = si >= 0 ? p.srcA + ((size_t)b * p.rowsA + si) * C : p.srcB + ((size_t)b * p.rowsB + (-si - 1)) * C;
+        } else {
+            src = p.srcA + (size_t)row * C;
+        }
+        if (p.add) {
+            const int ai = p.add_idx ? p.add_idx[pr] : pr;
+            if (ai >= 0) addp = p.add + (size_t)ai * C;
+        }
+    }
+    v8 xf[KK];
+    {
+        f4 v[KK][2];
+        float sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f4 t = *(const f4*)(src + kk * 32 + g * 8 + h2 * 4);
+                if (addp) t += *(const f4*)(addp + kk * 32 + g * 8 + h2 * 4);
+                v[kk][h2] = t;
+                sum += (t[0] + t[1]) + (t[2] + t[3]);
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f4 d = v[kk][h2] - mean;
+                sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq / (float)C + p.eps);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            v8 o;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f4 w = *(const f4*)(p.ln_w + kk * 32 + g * 8 + h2 * 4);
+                const f4 b = *(const f4*)(p.ln_b + kk * 32 + g * 8 + h2 * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)((v[kk][h2][r] - mean) * rstd * w[r] + b[r]);
+            }
+            xf[kk] = o;
+        }
+    }
+
+    f4 oacc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) oacc[cb] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const char* wq_l = smem + lane16;                 // qkv fragments: + (ub * KK + kk) * 1024
+    const char* wp_l = smem + OFF_PROJ + lane16;      // proj fragments: + cb * 1024
+    const float* bias_l = (const float*)(smem + OFF_BIAS);
+    char* kx = smem + OFF_KX;
+    char* vx = smem + OFF_VX;
+
+    for (int h = 0; h < p.heads; ++h) {
+        // ---- barrier A: qkv slice of head h landed; every wave is done with P2/P3 of head h-1 ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f4 bzg[NRB];
+        if (!BIAS_LDS) {   // ordinary loads are issued AHEAD of this head's DMA, so waiting for them never drains the DMA queue
+            const float* bg = p.bias + ((size_t)h * SP + tok) * SP + g * 4;
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb) bzg[kb] = *(const f4*)(bg + kb * 16);
+        }
+        if (!(p.ablate & 1)) dma_proj_bias(h);
+
+        // ---- P1: q^T, k^T, v ----
+        f4 acc[6];
+#pragma unroll
+        for (int ub = 0; ub < 6; ++ub) acc[ub] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (!(p.ablate & 2))
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+            for (int ub = 0; ub < 4; ++ub) {   // q0 q1 k0 k1: weights are the A operand
+                const v8 wf = *(const v8*)(wq_l + (ub * KK + kk) * 1024);
+                acc[ub] = Op16<T>::mfma(wf, xf[kk], acc[ub]);
+            }
+#pragma unroll
+            for (int ub = 4; ub < 6; ++ub) {   // v0 v1: activations are the A operand => D[key][dim]
+                const v8 wf = *(const v8*)(wq_l + (ub * KK + kk) * 1024);
+                acc[ub] = Op16<T>::mfma(xf[kk], wf, acc[ub]);
+            }
+        }
+        const float* bq = bqs + h * 96;
+        v8 qf, kf;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const f4 bqv = *(const f4*)(bq + blk * 16 + g * 4);
+            const f4 bkv = *(const f4*)(bq + 32 + blk * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                qf[blk * 4 + r] = (T)(acc[blk][r] + bqv[r]);
+                kf[blk * 4 + r] = (T)(acc[2 + blk][r] + bkv[r]);
+            }
+        }
+        // exchange: this wave's k fragment and its half of the v fragments
+        *(v8*)(kx + wave * 1024 + lane16) = kf;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const float bv = bq[64 + db * 16 + s];
+            v4 vh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vh[r] = (T)(acc[4 + db][r] + bv);
+            *(v4*)(vx + ((wi * 2 + db) * NKB32 + (qb >> 1)) * 1024 + lane16 + (qb & 1) * 8) = vh;
+        }
+
+        // ---- barrier B: proj / bias slices landed, k / v visible, qkv buffer free ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (h + 1 < p.heads && !(p.ablate & 1)) dma_qkv(h + 1);
+
+        // ---- P2: scores^T, softmax over keys, O^T ----
+        f4 sc[NRB];
+        float mx = -3.0e38f;
+        if (p.ablate & 4) {
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb) sc[kb] = (f4){(float)qf[0], (float)kf[1], 0.f, 0.f};
+        } else
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb) {
+            const v8 kfa = *(const v8*)(kx + (wi * NRB + kb) * 1024 + lane16);
+            f4 a = Op16<T>::mfma(kfa, qf, (f4){0.f, 0.f, 0.f, 0.f});
+            const f4 bz = BIAS_LDS ? *(const f4*)(bias_l + tok * SP + kb * 16 + g * 4) : bzg[kb];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a[r] = a[r] * p.scale + bz[r];
+                mx = fmaxf(mx, a[r]);
+            }
+            sc[kb] = a;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(sc[kb][r] - mx);
+                sc[kb][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        f4 o[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int k32 = 0; k32 < NKB32; ++k32) {
+            v8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (T)sc[2 * k32][r];
+                pf[4 + r] = (2 * k32 + 1 < NRB) ? (T)sc[(2 * k32 + 1 < NRB) ? 2 * k32 + 1 : 0][r] : (T)0.f;
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const v8 vf = *(const v8*)(vx + ((wi * 2 + db) * NKB32 + k32) * 1024 + lane16);
+                o[db] = Op16<T>::mfma(vf, pf, o[db]);
+            }
+        }
+        v8 of;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            of[r] = (T)(o[0][r] * inv);
+            of[4 + r] = (T)(o[1][r] * inv);
+        }
+        // ---- P3: out^T += Wproj[:, head h] . O^T ----
+        if (!(p.ablate & 8))
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const v8 wf = *(const v8*)(wp_l + cb * 1024);
+            oacc[cb] = Op16<T>::mfma(wf, of, oacc[cb]);
+        }
+    }
+
+    // ---- epilogue: x_out[row] = x_in + gamma * (out + bproj); fragment cb, slot 4g + r <-> channel (cb>>2)*64 + 16g + (cb&3)*4 + r ----
+    if (row_ok) {
+        float* px = p.x_out + (size_t)row * C;
+#pragma unroll
+        for (int cg = 0; cg < CB / 4; ++cg) {
+            const int c0 = cg * 64 + g * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f4 xv = *(const f4*)(src + c0 + q * 4);
+                if (addp) xv += *(const f4*)(addp + c0 + q * 4);
+                const f4 bv = *(const f4*)(p.bproj + c0 + q * 4);
+                const f4 gv = p.gamma ? *(const f4*)(p.gamma + c0 + q * 4) : (f4){1.f, 1.f, 1.f, 1.f};
+                const f4 a = oacc[cg * 4 + q];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xv[r] += gv[r] * (a[r] + bv[r]);
+                *(f4*)(px + c0 + q * 4) = xv;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// S <= 16 uses the 16-token instance (bias tables padded to 16), 48 < S <= 64 the 64-token one (padded to 64)
+bool attnblk_supported(int C, int heads, int S) { return C == 256 && heads == 8 && ((S >= 1 && S <= 16) || (S > 48 && S <= 64)); }
+
+int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
+    if (!attnblk_supported(c.C, c.heads, c.S) || c.nwin <= 0 || !c.wqkv_f || !c.wproj_f || !c.x_out) {
+        set_error("attn_block: unsupported arguments C=%d heads=%d S=%d nwin=%d", c.C, c.heads, c.S, c.nwin);
+        return FVIT_EINVAL;
+    }
+    AttnBlkParams p;
+    p.srcA = c.srcA; p.srcB = c.srcB; p.src_idx = c.src_idx; p.add_idx = c.add_idx; p.add = c.add; p.ln_w = c.ln_w; p.ln_b = c.ln_b;
+    p.eps = c.eps; p.rowsA = c.rowsA; p.rowsB = c.rowsB; p.rows_per_image = c.rows_per_image > 0 ? c.rows_per_image : 1;
+    p.wqkv_f = c.wqkv_f; p.bqkv = c.bqkv; p.wproj_f = c.wproj_f; p.bproj = c.bproj; p.gamma = c.gamma; p.bias = c.bias;
+    p.x_out = c.x_out; p.nwin = c.nwin; p.S = c.S; p.heads = c.heads; p.scale = c.scale;
+    p.ablate = tune_get("ab_ablate", 0);
+    const double rows = (double)c.nwin * c.S;
+    const double flops = 2.0 * rows * c.C * 4.0 * c.C + 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * 32.0;
+    const double bytes = 8.0 * rows * c.C + 8.0 * c.C * c.C;
+    ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
+    const bool small = c.S <= 16;
+    // 1 (default): 8 waves / 2 windows per workgroup, bias table in LDS, one workgroup per CU;
+    // 0: 4 waves / 1 window, bias from L2, two workgroups per CU -- measured equal (99.9 vs 96.7 us): the sub-block is bound by
+    //    its three fp32 passes over X (gather read, epilogue re-read, write), not by occupancy
+    const int variant = tune_get("ab_variant", 1);
+#define FVIT_AB(T, NRB, NW, BL) hipLaunchKernelGGL((attnblk_kernel<T, NRB, NW, BL>), dim3((c.nwin + (NW / NRB) - 1) / (NW / NRB)), \
+                                                   dim3(64 * NW), 0, stream, p)
+    if (c.dtype == FVIT_F16) {
+        if (small) FVIT_AB(_Float16, 1, 8, true);
+        else if (variant == 1) FVIT_AB(_Float16, 4, 8, true);
+        else FVIT_AB(_Float16, 4, 4, false);
+    } else if (c.dtype == FVIT_BF16) {
+        if (small) FVIT_AB(__bf16, 1, 8, true);
+        else if (variant == 1) FVIT_AB(__bf16, 4, 8, true);
+        else FVIT_AB(__bf16, 4, 4, false);
+    } else {
+        set_error("attn_block: operand dtype %d not supported", c.dtype);
+        return FVIT_EINVAL;
+    }
+#undef FVIT_AB
+    return check_launch("attnblk_kernel");
+}
+
+}  // namespace fvit

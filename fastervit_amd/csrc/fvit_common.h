@@ -115,6 +115,34 @@ struct MlpFusedCall {
 bool mlp_fused_supported(int C, int hidden);
 int launch_mlp_fused(const MlpFusedCall& c, hipStream_t stream);
 
+struct AttnBlkCall {
+    int dtype;
+    // gather + LayerNorm source (fvit_gather_layernorm semantics)
+    const float* srcA;
+    int rowsA;
+    const float* srcB;
+    int rowsB;
+    const int32_t* src_idx;
+    const int32_t* add_idx;
+    const float* add;
+    const float* ln_w;
+    const float* ln_b;
+    float eps;
+    int rows_per_image;
+    // fragment-major weights
+    const void* wqkv_f;
+    const float* bqkv;
+    const void* wproj_f;
+    const float* bproj;
+    const float* gamma;
+    const float* bias;
+    float* x_out;
+    int nwin, S, heads, C;
+    float scale;
+};
+bool attnblk_supported(int C, int heads, int S);
+int launch_attnblk(const AttnBlkCall& c, hipStream_t stream);
+
 struct AttnCall {
     int dtype;
     const void* qkv;  // op16 [rows][ldq], columns [q|k|v][head][dpad]

@@ -135,8 +135,25 @@ def pack_attention(attn, norm, gamma, S: int, dpad: int, op_dtype, keep: _Keep) 
     bias[:, :, S:] = FVIT_MASK_BIAS
     bias[:, S:, :] = 0.0
     bias[:, S:, S:] = FVIT_MASK_BIAS if S < spad else 0.0
+    wqf = bqh = wpf = None
+    if d == 32 and lib.fvit_attn_block_supported(C_, h, S):
+        wqkv32 = _f32(attn.qkv.weight)
+        bqkv32 = _f32(attn.qkv.bias) if attn.qkv.bias is not None else torch.zeros(3 * C_, device=dev)
+        wqf = frag_pack_qkv(wqkv32, h).to(op_dtype)
+        bqh = bqkv32.view(3, h, 32).permute(1, 0, 2).reshape(h, 96).contiguous()
+        wpf = frag_pack_fc2(_f32(attn.proj.weight)).to(op_dtype)   # chunks of 32 input columns = heads
     return FvitAttnWeights(keep.ptr(wq.to(op_dtype), True), keep.ptr(bq), keep.ptr(wp.to(op_dtype), True), keep.ptr(_f32(attn.proj.bias)),
-                           keep.ptr(bias), keep.ptr(_f32(norm.weight)), keep.ptr(_f32(norm.bias)), keep.ptr(_gamma(gamma)))
+                           keep.ptr(bias), keep.ptr(_f32(norm.weight)), keep.ptr(_f32(norm.bias)), keep.ptr(_gamma(gamma)),
+                           keep.ptr(wqf, True), keep.ptr(bqh), keep.ptr(wpf, True))
+
+
+def frag_pack_qkv(wqkv: torch.Tensor, heads: int) -> torch.Tensor:
+    """qkv.weight (3C, C), head_dim 32 -> [heads][6][C/32][64][8] (include/fvit_hip.h: w_qkv_frag): element e of lane 16g + s of
+    fragment (head, ub, kk) = wqkv[(ub>>1)*C + head*32 + (ub&1)*16 + s][kk*32 + 8g + e]."""
+    C3, C_ = wqkv.shape
+    t = wqkv.view(3, heads, 2, 16, C_ // 32, 4, 8)          # sec, head, half, s, kk, g, e
+    t = t.permute(1, 0, 2, 4, 5, 3, 6).contiguous()          # head, sec, half, kk, g, s, e
+    return t.view(heads, 6, C_ // 32, 64, 8)
 
 
 def pack_mlp(mlp, norm, gamma, op_dtype, keep: _Keep) -> FvitMlpWeights:

@@ -85,6 +85,14 @@ typedef struct FvitAttnWeights {
     const float* ln_w;   /* f32  [C] */
     const float* ln_b;   /* f32  [C] */
     const float* gamma;  /* f32  [C] or NULL (layer_scale None => 1) */
+    /* Optional (all NULL => unfused path): MFMA-fragment-order weights for the fused attention block kernel
+     * (csrc/fvit_attnblk.hip; needs C == 256, head_dim == 32).  lane = 16*g + s, e = 0..7:
+     *   w_qkv_frag [h][6 (q0 q1 k0 k1 v0 v1)][C/32 (kk)][64][8]: qkv.weight[(ub>>1)*C + head*32 + (ub&1)*16 + s][kk*32 + 8g + e]
+     *   b_qkv_heads f32 [h][96]: qkv.bias re-ordered per head [q 32 | k 32 | v 32]
+     *   w_proj_frag [h][C/16 (cb)][64][8]: proj.weight[ch(cb, s)][head*32 + (e>>2)*16 + 4g + (e&3)], ch as in w_fc2_frag */
+    const void* w_qkv_frag;
+    const float* b_qkv_heads;
+    const void* w_proj_frag;
 } FvitAttnWeights;
 
 /* LayerNorm -> fc1 -> GELU(erf) -> fc2 -> gamma-residual.  Replaces Mlp.forward (AR:399-408). */
@@ -208,6 +216,19 @@ int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rows
                           const float* ln_b, float eps, int32_t rows, int32_t rows_per_image, int32_t C,
                           fvit_stream_t stream);
 
+/* Fused attention sub-block: x_out[i] = x_in[i] + gamma * proj(softmax(q k^T * scale + bias) v), [q|k|v] = qkv(LayerNorm(x_in)),
+ * x_in[i] = gathered source row + optional add row (exactly the row selection of fvit_gather_layernorm), per window of S rows
+ * (AR:671-696).  One kernel; needs C == 256, heads == 8 (head_dim 32), S <= 16 or 48 < S <= 64 (fvit_attn_block_supported).
+ * bias f32 [heads][spad][spad] with spad = fvit_attention_spad(S); x_out may alias srcA (rows are read before they are written
+ * by the workgroup that owns them). */
+int fvit_attn_block_supported(int32_t C, int32_t heads, int32_t S);
+int fvit_attn_block_fused(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB,
+                          const int32_t* src_idx, const int32_t* add_idx, const float* add, const float* ln_w,
+                          const float* ln_b, float eps, int32_t rows_per_image, const void* w_qkv_frag,
+                          const float* b_qkv_heads, const void* w_proj_frag, const float* b_proj, const float* gamma,
+                          const float* bias, float* x_out, int32_t nwin, int32_t S, int32_t heads, int32_t C, float scale,
+                          fvit_stream_t stream);
+
 /* Fused MLP sub-block: x[m][:] += gamma * fc2(GELU(fc1(LayerNorm(x[m][:])))) in one kernel (AR:697, AR:399-408).
  * x f32 [M][C] in place; w_fc1_frag / w_fc2_frag as in FvitMlpWeights.
  * Supported: C == 256, hidden % 32 == 0, hidden <= 4C (fvit_mlp_fused_supported); otherwise FVIT_EINVAL. */
@@ -251,7 +272,7 @@ int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const void* weight
 int fvit_tune(const char* key, int32_t value);
 
 /* ---- built-in kernel timer (HIP events around every launch, on the launch stream) ---- */
-#define FVIT_PROF_KINDS 10
+#define FVIT_PROF_KINDS 11
 /* kind ids */
 #define FVIT_K_PARTITION 0
 #define FVIT_K_LAYERNORM 1
@@ -263,6 +284,7 @@ int fvit_tune(const char* key, int32_t value);
 #define FVIT_K_OTHER 7
 #define FVIT_K_MLP_FUSED 8
 #define FVIT_K_CONV 9
+#define FVIT_K_ATTN_FUSED 10
 typedef struct FvitProfEntry {
     int64_t launches;
     double ms;     /* summed event-to-event time */

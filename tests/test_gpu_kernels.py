@@ -338,3 +338,70 @@ def test_token_init(fmt, dt, C, res, ws, cw):
     ref = hr.token_initializer(x.float().cpu(), sd, "t.", res, ws, cw)
     assert got.shape == ref.shape
     assert (got.cpu() - ref).abs().max().item() < 2e-4 * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("S,nwin,use_tables,use_gamma", [(53, 9, True, True), (49, 4, False, False), (16, 13, True, True), (64, 3, False, True),
+                                                         (53, 1024, True, True), (16, 256, True, False)])
+def test_attn_block_fused(opname, dt, code, S, nwin, use_tables, use_gamma):
+    """gather + LayerNorm + qkv + attention + proj + gamma-residual in one kernel vs PyTorch fp32 on 16-bit-rounded weights."""
+    lib = _lib.lib()
+    C, heads, d = 256, 8, 32
+    assert lib.fvit_attn_block_supported(C, heads, S) == 1 and lib.fvit_attn_block_supported(512, 16, 49) == 0
+    g = torch.Generator(device="cpu").manual_seed(S * 131 + nwin)
+    rows = nwin * S
+    wins_per_img = 1 if S == 16 else (4 if nwin % 4 == 0 else 1)
+    rpi = wins_per_img * S
+    nimg = nwin // wins_per_img
+    X = (torch.randn(rows, C, generator=g) * 1.3 + 0.2).cuda()
+    R = torch.randn(nimg, 7, C, generator=g).cuda()                       # srcB: 7 extra rows per image
+    src_idx = add_idx = add = None
+    if use_tables:
+        si = torch.arange(rpi)
+        si[1] = -3                                                        # row 1 of every image comes from R[b, 2]
+        si[5 % rpi] = (rpi - 1)                                           # row 5 reads the image's last X row
+        ai = torch.full((rpi,), -1, dtype=torch.int64)
+        ai[2:] = torch.arange(rpi - 2) % 11
+        src_idx, add_idx = si.int().cuda(), ai.int().cuda()
+        add = torch.randn(11, C, generator=g).cuda()
+    lnw = (torch.rand(C, generator=g) + 0.5).cuda()
+    lnb = (torch.randn(C, generator=g) * 0.2).cuda()
+    wqkv = (torch.randn(3 * C, C, generator=g) / C ** 0.5).to(dt).cuda()
+    bqkv = (torch.randn(3 * C, generator=g) * 0.3).cuda()
+    wproj = (torch.randn(C, C, generator=g) / C ** 0.5).to(dt).cuda()
+    bproj = (torch.randn(C, generator=g) * 0.3).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda() if use_gamma else None
+    bias = (torch.randn(heads, S, S, generator=g) * 2).cuda()
+    spad = lib.fvit_attention_spad(S)
+    bp = torch.zeros(heads, spad, spad, device="cuda")
+    bp[:, :S, :S] = bias
+    bp[:, :, S:] = _lib.FVIT_MASK_BIAS
+    wqf = hat_runtime.frag_pack_qkv(wqkv.float(), heads).to(dt).contiguous()
+    bqh = bqkv.view(3, heads, 32).permute(1, 0, 2).reshape(heads, 96).contiguous()
+    wpf = hat_runtime.frag_pack_fc2(wproj.float()).to(dt).contiguous()
+    out = torch.full((rows, C), float("nan"), device="cuda")
+    scale = d ** -0.5
+    rc = lib.fvit_attn_block_fused(code, X.data_ptr(), rpi, R.data_ptr(), 7, src_idx.data_ptr() if use_tables else None,
+                                   add_idx.data_ptr() if use_tables else None, add.data_ptr() if use_tables else None, lnw.data_ptr(),
+                                   lnb.data_ptr(), ctypes.c_float(1e-5), rpi, wqf.data_ptr(), bqh.data_ptr(), wpf.data_ptr(), bproj.data_ptr(),
+                                   gamma.data_ptr() if use_gamma else None, bp.data_ptr(), out.data_ptr(), nwin, S, heads, C,
+                                   ctypes.c_float(scale), _stream())
+    _lib.check(rc, "attn_block_fused")
+    torch.cuda.synchronize()
+    # reference
+    xin = X.view(nimg, rpi, C).clone()
+    if use_tables:
+        sil, ail = src_idx.long(), add_idx.long()
+        xin = torch.where((sil >= 0)[None, :, None], X.view(nimg, rpi, C)[:, sil.clamp(min=0)], R[:, (-sil - 1).clamp(min=0)])
+        xin = xin + torch.where((ail >= 0)[:, None], add[ail.clamp(min=0)], torch.zeros_like(add[:1]))[None]
+    xin = xin.reshape(nwin, S, C)
+    xn = F.layer_norm(xin, (C,), lnw, lnb, 1e-5).to(dt).float()
+    qkv = (xn @ wqkv.float().t() + bqkv).view(nwin, S, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0].to(dt).float(), qkv[1].to(dt).float(), qkv[2].to(dt).float()
+    att = ((q @ k.transpose(-1, -2)) * scale + bias).softmax(-1)
+    o = (att @ v).transpose(1, 2).reshape(nwin, S, C).to(dt).float()
+    y = o @ wproj.float().t() + bproj
+    ref = (xin + (gamma * y if use_gamma else y)).reshape(rows, C)
+    assert torch.isfinite(out).all()
+    tol = (4e-3 if dt == torch.float16 else 3e-2) * ref.abs().max().item()
+    assert (out - ref).abs().max().item() < tol
