@@ -57,6 +57,8 @@ class DeployPlan:
         self.sig = None
         self.t = None
         self.zeros = None
+        self.streams = 1      # > 1: run the batch as that many shards on separate HIP streams
+        self.side = None
         self.use_hip_conv = True  # fused implicit-GEMM conv kernel where the shape allows; False = MIOpen + glue passes
 
     # ---- folding -------------------------------------------------------------------------
@@ -184,6 +186,30 @@ class DeployPlan:
             with torch.autocast(device_type="cuda", enabled=False):
                 self._build()
             self.sig = sig
+        n = self.streams
+        if n <= 1 or x.shape[0] < 2 * n:
+            hat_runtime.set_workspace_slot(0)
+            return self._forward_one(x)
+        # the batch as n independent shards on n HIP streams (fork / join with events; capturable in a hipGraph): every kernel
+        # of this pipeline runs its HBM-bound prologue / epilogue and its MFMA phase in lockstep across workgroups, so two
+        # half-size pipelines interleave better than one full-size one
+        if self.side is None or len(self.side) != n - 1:
+            self.side = [torch.cuda.Stream(device=x.device) for _ in range(n - 1)]
+        main = torch.cuda.current_stream()
+        parts = x.chunk(n, dim=0)
+        outs = [None] * n
+        for i, s in enumerate(self.side):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                hat_runtime.set_workspace_slot(i + 1)
+                outs[i + 1] = self._forward_one(parts[i + 1])
+        hat_runtime.set_workspace_slot(0)
+        outs[0] = self._forward_one(parts[0])
+        for s in self.side:
+            main.wait_stream(s)
+        return torch.cat(outs, dim=0)
+
+    def _forward_one(self, x):
         t = self.t
         with torch.autocast(device_type="cuda", enabled=False):
             w0, b0, w1, b1 = t["stem"]

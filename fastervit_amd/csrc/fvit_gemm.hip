@@ -51,13 +51,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <typename T, bool IS_W>
+template <typename T, bool IS_W, int ROWS>
 __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int row0, int k0, char* tile,
                                            int wave, int lane) {
-    // 16 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces 4w..4w+3.
+    // ROWS/8 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces PW*w .. PW*w + PW-1.
+    constexpr int PW = ROWS / 8 / 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;
+    for (int i = 0; i < PW; ++i) {
+        const int piece = wave * PW + i;
         const int r = piece * 8 + (lane >> 3);
         const int f = IS_W ? swz_w(r) : swz_x(r);
         const int c = (lane & 7) ^ f;
@@ -71,10 +72,14 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
 // NSTAGE = 3: three-deep ring with a COUNTED s_waitcnt vmcnt (the tile after the current one stays in flight across
 //             the raw s_barrier), one workgroup per CU -- for small grids (<= ~1.5 workgroups per CU), where a K step is
 //             otherwise one full LDS-DMA round trip (~1.3 us) because nothing else on the CU hides it.
-template <typename T, int EPI, int NSTAGE>
+// MI: 16-row fragments per wave along M (4: 128-row tile; 2: 64-row tile, 48 KiB LDS, three workgroups per CU -- for
+//     small grids, where twice the workgroups at higher occupancy hide the per-K-step DMA latency better)
+template <typename T, int EPI, int NSTAGE, int MI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     typedef typename Op16<T>::v8 v8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * NSTAGE * TILE_BYTES];  // X ring, then W ring
+    constexpr int BMT = 32 * MI;                       // rows of the workgroup tile (2 waves along M)
+    constexpr int XT_BYTES = BMT * BK * 2;             // activation tile bytes (W tile stays TILE_BYTES = 128 rows)
+    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * (XT_BYTES + TILE_BYTES)];  // X ring, then W ring
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -86,36 +91,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int q = nblk >> 3, rr = nblk & 7, xcd = b & 7, idx = b >> 3;
     const int v = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BMT, n0 = tn * BN;
 
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ W = (const T*)p.W;
 
-    f4 acc[4][4];  // [ni][mi]
+    f4 acc[4][MI];  // [ni][mi]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
     char* const xring = smem;
-    char* const wring = smem + NSTAGE * TILE_BYTES;
+    char* const wring = smem + NSTAGE * XT_BYTES;
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st) {
         if (st < nk) {
-            stage_tile<T, false>(A, p.lda, m0, st * BK, xring + st * TILE_BYTES, wave, lane);
-            stage_tile<T, true>(W, p.ldw, n0, st * BK, wring + st * TILE_BYTES, wave, lane);
+            stage_tile<T, false, BMT>(A, p.lda, m0, st * BK, xring + st * XT_BYTES, wave, lane);
+            stage_tile<T, true, 128>(W, p.ldw, n0, st * BK, wring + st * TILE_BYTES, wave, lane);
         }
     }
 
     // per-lane fragment addressing (bytes inside a tile)
     const int g = lane >> 4, s = lane & 15;
-    int xrow[4], wrow[4];
+    int xrow[MI], wrow[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        xrow[i] = wm * 64 + i * 16 + s;                          // activation row (B operand column)
-        wrow[i] = wn * 64 + (s >> 2) * 16 + i * 4 + (s & 3);      // weight row for A-row slot s of fragment i
-    }
+    for (int i = 0; i < MI; ++i) xrow[i] = wm * (16 * MI) + i * 16 + s;        // activation row (B operand column)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wrow[i] = wn * 64 + (s >> 2) * 16 + i * 4 + (s & 3);  // weight row for A-row slot s of fragment i
 
     int cur = 0;  // ring slot of tile kt
     for (int kt = 0; kt < nk; ++kt) {
@@ -134,25 +138,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             int slot = cur + NSTAGE - 1;
             if (slot >= NSTAGE) slot -= NSTAGE;
             if (nxt < nk) {
-                stage_tile<T, false>(A, p.lda, m0, nxt * BK, xring + slot * TILE_BYTES, wave, lane);
-                stage_tile<T, true>(W, p.ldw, n0, nxt * BK, wring + slot * TILE_BYTES, wave, lane);
+                stage_tile<T, false, BMT>(A, p.lda, m0, nxt * BK, xring + slot * XT_BYTES, wave, lane);
+                stage_tile<T, true, 128>(W, p.ldw, n0, nxt * BK, wring + slot * TILE_BYTES, wave, lane);
             }
         }
-        const char* xt = xring + cur * TILE_BYTES;
+        const char* xt = xring + cur * XT_BYTES;
         const char* wt = wring + cur * TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int c = kk * 4 + g;
-            v8 xf[4], wf[4];
+            v8 xf[MI], wf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xf[i] = *(const v8*)(xt + xrow[i] * 128 + ((c ^ swz_x(xrow[i])) << 4));
-                wf[i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
-            }
+            for (int i = 0; i < MI; ++i) xf[i] = *(const v8*)(xt + xrow[i] * 128 + ((c ^ swz_x(xrow[i])) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[ni], xf[mi], acc[ni][mi]);
+                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[ni], xf[mi], acc[ni][mi]);
         }
         if (++cur == NSTAGE) cur = 0;
     }
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         }
         float* X = (float*)p.out;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 64 + mi * 16 + s;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * (16 * MI) + mi * 16 + s;
             if (m < p.M) {
                 float* px = X + (size_t)m * p.ldo + nb;
 #pragma unroll
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     } else {
         T* O = (T*)p.out;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 64 + mi * 16 + s;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * (16 * MI) + mi * 16 + s;
             if (m < p.M) {
                 v8 o0, o1;
 #pragma unroll
@@ -220,8 +223,12 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.A = c.A; p.W = c.W; p.bias = c.bias; p.gamma = c.gamma; p.out = c.out;
     p.lda = c.lda; p.ldw = c.ldw; p.ldo = c.ldo;
     p.M = c.M; p.N = c.N; p.K = c.K;
-    p.tiles_m = (c.M + BM - 1) / BM;
     p.tiles_n = (c.N + BN - 1) / BN;
+    // small grids (<= 2 workgroups per CU with 128-row tiles) switch to 64-row tiles: twice the workgroups, 3 per CU
+    const int grid128 = ((c.M + 127) / 128) * p.tiles_n;
+    // measured r01: no gain (gamma-residual GEMMs 0.653 vs 0.585 ms per step with 64-row tiles) => opt-in only
+    const bool small = grid128 <= tune_get("gemm_bm64_max_grid", 0);
+    p.tiles_m = small ? (c.M + 63) / 64 : (c.M + 127) / 128;
     const int grid = p.tiles_m * p.tiles_n;
     const double flops = 2.0 * c.M * (double)c.N * c.K;
     double bytes = 2.0 * c.M * (double)c.K + 2.0 * c.N * (double)c.K;  // operands once
@@ -234,21 +241,17 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
         kind = c.epilogue == 1 ? FVIT_K_GEMM_GELU : FVIT_K_GEMM_BIAS;
     }
     ProfScope prof(kind, flops, bytes, stream);
-    // measured r01: no gain over the 2-stage kernel at 64..392 workgroups (0.868 vs 0.820 ms per step) => opt-in only
-    const bool deep = grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
-    if (deep) {
-        switch (c.epilogue) {
-            case 0: hipLaunchKernelGGL((gemm_kernel<T, 0, 3>), dim3(grid), dim3(256), 0, stream, p); break;
-            case 1: hipLaunchKernelGGL((gemm_kernel<T, 1, 3>), dim3(grid), dim3(256), 0, stream, p); break;
-            default: hipLaunchKernelGGL((gemm_kernel<T, 2, 3>), dim3(grid), dim3(256), 0, stream, p); break;
-        }
+    // measured r01: a 3-stage ring with counted vmcnt gave no gain over 2 stages at 64..392 workgroups => opt-in only
+    const bool deep = !small && grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
+#define FVIT_GEMM(E, NS, MI_) hipLaunchKernelGGL((gemm_kernel<T, E, NS, MI_>), dim3(grid), dim3(256), 0, stream, p)
+    if (small) {
+        switch (c.epilogue) { case 0: FVIT_GEMM(0, 2, 2); break; case 1: FVIT_GEMM(1, 2, 2); break; default: FVIT_GEMM(2, 2, 2); break; }
+    } else if (deep) {
+        switch (c.epilogue) { case 0: FVIT_GEMM(0, 3, 4); break; case 1: FVIT_GEMM(1, 3, 4); break; default: FVIT_GEMM(2, 3, 4); break; }
     } else {
-        switch (c.epilogue) {
-            case 0: hipLaunchKernelGGL((gemm_kernel<T, 0, 2>), dim3(grid), dim3(256), 0, stream, p); break;
-            case 1: hipLaunchKernelGGL((gemm_kernel<T, 1, 2>), dim3(grid), dim3(256), 0, stream, p); break;
-            default: hipLaunchKernelGGL((gemm_kernel<T, 2, 2>), dim3(grid), dim3(256), 0, stream, p); break;
-        }
+        switch (c.epilogue) { case 0: FVIT_GEMM(0, 2, 4); break; case 1: FVIT_GEMM(1, 2, 4); break; default: FVIT_GEMM(2, 2, 4); break; }
     }
+#undef FVIT_GEMM
     return check_launch("gemm_kernel");
 }
 

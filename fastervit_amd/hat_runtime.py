@@ -292,8 +292,15 @@ def _prepare(layer, x_dev, Hp: int, Wp: int):
     return st, tb, ctables, desc_common
 
 
+_WS_SLOT = [0]   # workspace slot of the current caller: concurrent forwards on different streams must not share scratch
+
+
+def set_workspace_slot(slot: int) -> None:
+    _WS_SLOT[0] = int(slot)
+
+
 def _workspace(st: StageState, desc_common: dict, B: int, H: int, W: int, device):
-    key = (B, desc_common["Hp"], desc_common["Wp"], H, W, desc_common["operand_dtype"])
+    key = (B, desc_common["Hp"], desc_common["Wp"], H, W, desc_common["operand_dtype"], _WS_SLOT[0])
     hit = st.workspaces.get(key)
     if hit is not None:
         return hit

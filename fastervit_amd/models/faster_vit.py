@@ -421,7 +421,7 @@ class FasterViT(nn.Module):
             lvl.hat_operand_dtype = name
         return self
 
-    def switch_to_deploy(self, dtype=torch.float16):
+    def switch_to_deploy(self, dtype=torch.float16, streams=1):
         """Opt-in inference plan for the conv side (fastervit_amd/conv_runtime.py): BatchNorm folded into the conv
         weights, 16-bit channels_last activations, fused bias/activation/residual/LayerNorm2d HIP passes.
         ``forward`` then returns fp32 logits for GPU inputs; ``switch_to_deploy(None)`` goes back to module mode."""
@@ -429,7 +429,9 @@ class FasterViT(nn.Module):
             self.__dict__.pop("_deploy_plan", None)
             return self
         from ..conv_runtime import DeployPlan
-        self.__dict__["_deploy_plan"] = DeployPlan(self, dtype)
+        plan = DeployPlan(self, dtype)
+        plan.streams = int(streams)   # > 1: the batch runs as that many shards on separate HIP streams (see DeployPlan.forward)
+        self.__dict__["_deploy_plan"] = plan
         return self
 
     def forward_features(self, x):

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_kernels.py -q -m gpu -x -k "attn_block" > gpurun_out/ab_probe.log 2>&1
-tail -2 gpurun_out/ab_probe.log
-python scripts/bench_attnblk.py 53 1024 >> gpurun_out/ab_probe.log 2>&1
-grep "round 1" gpurun_out/ab_probe.log
+for s in 1 2 3 4; do
+  timeout 600 python bench.py --streams $s --no-cpu-baseline --prof-steps 1 > gpurun_out/bench_streams$s.json 2> gpurun_out/bench_streams$s.err
+  echo "streams=$s rc=$?"; python -c "import json; d=json.load(open('gpurun_out/bench_streams$s.json')); print(d['value'], d['ms_per_step'], d['config']['launch'])"
+done

@@ -206,3 +206,34 @@ def test_deploy_mode_vs_reference(name, tol):
     with torch.no_grad():
         logits3 = model(case_input(name).cuda()).float().cpu()
     assert rel_err(logits3 - 1.0, g["logits"]) < 5e-3
+
+
+@pytest.mark.parametrize("streams", [2, 3])
+def test_deploy_mode_stream_shards(streams):
+    """Deploy mode with the batch run as shards on several HIP streams: same logits as the single-stream plan
+    (images are independent), inside and outside a hipGraph."""
+    g = load_golden("fvit0_224")
+    model, _ = build_product_model("fvit0_224", "cuda")
+    x = case_input("fvit0_224").cuda()
+    model.switch_to_deploy(torch.float16)
+    with torch.no_grad():
+        ref = model(x).float()
+    model.switch_to_deploy(torch.float16, streams=streams)
+    with torch.no_grad():
+        y = model(x).float()
+        y2 = model(x).float()
+    assert max_abs(y.cpu(), ref.cpu()) < 2e-4 and torch.equal(y, y2)
+    assert max_abs(y.cpu(), g["logits"]) < 4e-3
+    # capturable: fork / join of the side streams inside one graph
+    static_x = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        model(static_x)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), torch.no_grad():
+        static_y = model(static_x)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert max_abs(static_y.float().cpu(), y.cpu()) < 2e-4
