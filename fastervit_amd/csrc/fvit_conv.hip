@@ -285,8 +285,200 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Halo-tiled 3x3 convolution for Cin = Cout = 64, stride 1 (ConvBlock convs of level 0, FV:502-512).
+//
+// The implicit GEMM above re-reads every input pixel nine times from L2 (once per tap) and the whole 72-KiB
+// weight matrix once per 128-pixel tile: ~220 KiB of L2->LDS traffic per 9.4 MFLOP tile, which is what bounds it.
+// Here a workgroup owns an 8 x 16 pixel output tile, brings its 10 x 18 pixel halo into LDS ONCE (23 KiB, LDS-DMA,
+// double-buffered across a persistent tile loop) and keeps its weights STATIONARY IN REGISTERS: wave (ch, ph) owns
+// output channels 32ch .. 32ch+31 (36 A fragments = 144 VGPRs, loaded once per workgroup) and pixel rows
+// 4ph .. 4ph+3.  A 16-pixel MFMA column group is one row of 16 consecutive pixels, so the B fragment of tap
+// (ky, kx) is the same LDS image read at a shifted address: row (r + ky), column (s + kx).  With chunk position
+// c ^ (hx & 6) (hx = halo column) every ds_read_b128 service group touches each bank once for any shift.
+// Per tile and wave: 72 ds_read_b128 for 144 MFMAs; L2->LDS traffic drops ~9x, HBM traffic is the map read + write.
+// ------------------------------------------------------------------------------------------------------------
+struct HaloParams {
+    const void* in;
+    const void* w;       // [64][9*64]
+    const float* bias;   // [64] or null
+    const void* res;     // [M][64] or null
+    void* out;           // [M][64]
+    const void* zeros;
+    int B, H, W, act;
+    int tiles_x, tiles_y, tiles;
+};
+
+constexpr int HALO_TH = 8, HALO_TW = 16, HALO_PW = HALO_TW + 2, HALO_PH = HALO_TH + 2;
+constexpr int HALO_PIECES = (HALO_PH * HALO_PW + 7) / 8;       // 1-KiB pieces of 8 halo pixels
+constexpr int HALO_BYTES = HALO_PIECES * 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_halo_kernel(HaloParams p) {
+    typedef typename Op16<T>::v8 v8;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * HALO_BYTES];
+    __shared__ __attribute__((aligned(16))) float sbias[64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ch = wave & 1, ph = wave >> 1;
+    if (tid < 64) sbias[tid] = p.bias ? p.bias[tid] : 0.f;   // visible after the first barrier of the tile loop
+    const int g = lane >> 4, s = lane & 15;
+
+    // XCD-aware persistent schedule: XCD x owns a contiguous range of tiles (neighbouring tiles share halo pixels in
+    // that XCD's L2); its workgroups stride through the range together.
+    const int nblk = gridDim.x;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int per_xcd = (nblk + 7 - xcd) >> 3;                  // workgroups that landed on this XCD
+    const int tq = p.tiles >> 3, tr = p.tiles & 7;
+    const int t_begin = xcd * tq + min(xcd, tr);
+    const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
+
+    const T* __restrict__ In = (const T*)p.in;
+    const T* __restrict__ W = (const T*)p.w;
+    const T* __restrict__ Z = (const T*)p.zeros;
+
+    // ---- stationary weights: wf[tap][kk][ni], A-row slot s of fragment ni -> channel 32ch + (s>>2)*8 + ni*4 + (s&3) ----
+    v8 wf[9][2][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                wf[tap][kk][ni] = *(const v8*)(W + (size_t)(ch * 32 + (s >> 2) * 8 + ni * 4 + (s & 3)) * 576 + tap * 64 + kk * 32 + g * 8);
+
+    const int nb = ch * 32 + g * 8;   // lane's 8 consecutive output channels
+
+    // B-fragment read offsets inside a halo row, per horizontal tap
+    int xoff[3];   // K half 1 is the same address with bit 6 flipped (chunk position c ^ 4)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) xoff[kx] = (s + kx) * 128 + ((g ^ ((s + kx) & 6)) << 4);
+
+    auto stage = [&](int tile, char* buf) {
+        const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
+        const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
+        const int y0 = ty * HALO_TH - 1, x0 = tx * HALO_TW - 1;
+        const T* img = In + (size_t)b * p.H * p.W * 64;
+        // the halo coordinates are tile independent, but keeping 6 x (hy, hx, chunk) live across the MFMA loop costs
+        // more registers than the weights leave: recompute them per tile (a handful of VALU ops per 1-KiB piece)
+        int lane8 = lane >> 3;
+        asm volatile("" : "+v"(lane8));
+#pragma unroll
+        for (int i = 0; i < (HALO_PIECES + 3) / 4; ++i) {
+            const int piece = wave + 4 * i;
+            if (piece < HALO_PIECES) {
+                const int hp = piece * 8 + lane8;
+                const int hy = hp / HALO_PW, hx = hp - hy * HALO_PW;
+                const int y = y0 + hy, x = x0 + hx;
+                const bool ok = hy < HALO_PH && y >= 0 && y < p.H && x >= 0 && x < p.W;
+                const int c = (lane & 7) ^ (hx & 6);
+                const T* src = ok ? img + ((size_t)y * p.W + x) * 64 + c * 8 : Z + c * 8;
+                glds16(src, buf + piece * 1024);
+            }
+        }
+    };
+
+    T* __restrict__ O = (T*)p.out;
+    const T* __restrict__ R = (const T*)p.res;
+
+    int tile = t_begin + idx;
+    if (tile < t_end) stage(tile, smem);
+    for (int it = 0; tile < t_end; tile += per_xcd, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = it & 1;
+        if (tile + per_xcd < t_end) stage(tile + per_xcd, smem + (cur ^ 1) * HALO_BYTES);
+        const char* hb = smem + cur * HALO_BYTES + ph * 4 * (HALO_PW * 128);
+
+        f4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        // 18 groups (tap, K half) of 4 B-fragment reads + 8 MFMAs, software pipelined by hand one group ahead; the
+        // scheduling barriers keep the compiler from hoisting more reads than that (it otherwise runs out of registers
+        // next to the 144 weight VGPRs and spills the read offsets, whose reload would queue behind the LDS-DMA)
+        v8 xf[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) xf[0][mi] = *(const v8*)(hb + mi * (HALO_PW * 128) + xoff[0]);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            const int tap = q >> 1, kk = q & 1;
+            if (q + 1 < 18) {
+                const int tap1 = (q + 1) >> 1, kk1 = (q + 1) & 1, ky1 = tap1 / 3, kx1 = tap1 - ky1 * 3;
+                const int o = xoff[kx1] ^ (kk1 << 6);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) xf[(q + 1) & 1][mi] = *(const v8*)(hb + (mi + ky1) * (HALO_PW * 128) + o);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[tap][kk][ni], xf[q & 1][mi], acc[ni][mi]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue: lane holds out[b][y][x][nb .. nb+7] for the 4 rows y = 8ty + 4ph + mi, column x = 16tx + s ----
+        const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
+        const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
+        const int x = tx * HALO_TW + s;
+        float bias[8];
+        {
+            const f4 t0 = *(const f4*)(sbias + nb), t1 = *(const f4*)(sbias + nb + 4);
+            bias[0] = t0[0]; bias[1] = t0[1]; bias[2] = t0[2]; bias[3] = t0[3];
+            bias[4] = t1[0]; bias[5] = t1[1]; bias[6] = t1[2]; bias[7] = t1[3];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int y = ty * HALO_TH + ph * 4 + mi;
+            if (y < p.H && x < p.W) {
+                const size_t m = ((size_t)b * p.H + y) * p.W + x;
+                v8 rv;
+                if (R) rv = *(const v8*)(R + m * 64 + nb);
+                v8 ov;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const f4 a = acc[ni][mi];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float yv = a[r] + bias[ni * 4 + r];
+                        if (p.act == 1) yv = fmaxf(yv, 0.f);
+                        else if (p.act == 2) yv = gelu_fast(yv);
+                        if (R) yv += (float)rv[ni * 4 + r];
+                        ov[ni * 4 + r] = (T)yv;
+                    }
+                }
+                *(v8*)(O + m * 64 + nb) = ov;
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_halo_t(const ConvParams& c, hipStream_t stream) {
+    HaloParams p;
+    p.in = c.in; p.w = c.w; p.bias = c.bias; p.res = c.res; p.out = c.out; p.zeros = c.zeros;
+    p.B = c.B; p.H = c.Hi; p.W = c.Wi; p.act = c.act;
+    p.tiles_x = (c.Wi + HALO_TW - 1) / HALO_TW;
+    p.tiles_y = (c.Hi + HALO_TH - 1) / HALO_TH;
+    p.tiles = c.B * p.tiles_x * p.tiles_y;   // <= M, which the caller checked against int32
+    int maxgrid = tune_get("conv_halo_grid", 512);   // 2 workgroups per CU (230 VGPRs, 46 KiB LDS each)
+    if (maxgrid < 8) maxgrid = 8;                    // every XCD's tile range needs at least one workgroup
+    const int grid = p.tiles < maxgrid ? p.tiles : maxgrid;
+    const double flops = 2.0 * c.M * 64.0 * 576.0;
+    const double bytes = 2.0 * ((double)c.M * 64 * (c.res ? 3.0 : 2.0) + 576.0 * 64);
+    ProfScope prof(FVIT_K_CONV, flops, bytes, stream);
+    hipLaunchKernelGGL((conv3x3_c64_halo_kernel<T>), dim3(grid), dim3(256), 0, stream, p);
+    return check_launch("conv3x3_c64_halo_kernel");
+}
+
 template <typename T>
 int launch_t(ConvParams& p, hipStream_t stream) {
+    if (p.Cin == 64 && p.Cout == 64 && p.stride == 1 && tune_get("conv_halo", 1)) {
+        return launch_halo_t<T>(p, stream);
+    }
     const double flops = 2.0 * p.M * (double)p.Cout * 9.0 * p.Cin;
     const double bytes = 2.0 * ((double)p.B * p.Hi * p.Wi * p.Cin + (double)p.M * p.Cout * (p.res ? 2.0 : 1.0) + 9.0 * p.Cin * p.Cout);
     ProfScope prof(FVIT_K_CONV, flops, bytes, stream);

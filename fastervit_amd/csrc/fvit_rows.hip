@@ -309,29 +309,27 @@ __global__ __launch_bounds__(256) void token_init_kernel(TokParams p) {
 #pragma unroll
     for (int j = 0; j < 9; ++j) wv[j] = p.w[c * 9 + j];
     const int64_t base = b * p.in.stride_b + c * p.in.stride_c;
-    // sum over the pooling window of the 3x3 depthwise responses == weighted sum over the (kh+2) x (kw+2) input patch
+    // sum over the pooling window of the 3x3 depthwise responses == weighted sum over the (kh+2) x (kw+2) input patch:
+    // input (dy, dx) feeds conv outputs (dy - ky, dx - kx) relative to the window, valid for ky in [max(0, dy-kh+1), min(2, dy)]
+    // and the same for kx -- the effective weight is separable into a valid-ky column sum and a valid-kx range sum
     float acc = 0.f;
     const int y0 = oy * p.sh - 1, x0 = ox * p.sw - 1;
     for (int dy = 0; dy < p.kh + 2; ++dy) {
         const int y = y0 + dy;
         if (y < 0 || y >= p.Hp) continue;
+        const int ky_lo = max(0, dy - p.kh + 1), ky_hi = min(2, dy);
+        // static register indexing only (a runtime-indexed register array would go to scratch)
+        const float m0 = (ky_lo <= 0 && ky_hi >= 0) ? 1.f : 0.f, m1 = (ky_lo <= 1 && ky_hi >= 1) ? 1.f : 0.f, m2 = ky_hi >= 2 ? 1.f : 0.f;
+        const float cw0 = m0 * wv[0] + m1 * wv[3] + m2 * wv[6];
+        const float cw1 = m0 * wv[1] + m1 * wv[4] + m2 * wv[7];
+        const float cw2 = m0 * wv[2] + m1 * wv[5] + m2 * wv[8];
+        const int64_t rowoff = base + y * p.in.stride_h;
         for (int dx = 0; dx < p.kw + 2; ++dx) {
             const int x = x0 + dx;
             if (x < 0 || x >= p.Wp) continue;
-            // input (y, x) feeds conv output (y - ky + 1, x - kx + 1); count the taps whose output lies inside the pool window
-            float wsum = 0.f;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int py = dy - ky;  // conv-output row relative to the window start
-                if (py < 0 || py >= p.kh) continue;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int px = dx - kx;
-                    if (px < 0 || px >= p.kw) continue;
-                    wsum += wv[ky * 3 + kx];
-                }
-            }
-            acc += wsum * load_elem(p.in.data, base + y * p.in.stride_h + x * p.in.stride_w, p.in.dtype);
+            const int kx_lo = max(0, dx - p.kw + 1), kx_hi = min(2, dx);
+            const float wsum = (kx_lo <= 0 && kx_hi >= 0 ? cw0 : 0.f) + (kx_lo <= 1 && kx_hi >= 1 ? cw1 : 0.f) + (kx_hi >= 2 ? cw2 : 0.f);
+            acc += wsum * load_elem(p.in.data, rowoff + x * p.in.stride_w, p.in.dtype);
         }
     }
     p.out[i] = acc / (float)(p.kh * p.kw) + p.bias[c];

@@ -259,7 +259,10 @@ def test_mlp_fused(opname, dt, code, M, use_gamma):
 @pytest.mark.parametrize("B,Ci,Co,H,W,stride,act,res", [
     (2, 64, 64, 14, 14, 1, 2, False), (3, 64, 64, 9, 13, 1, 0, True), (2, 64, 64, 16, 16, 2, 1, False),
     (2, 64, 128, 12, 10, 2, 0, False), (2, 128, 128, 7, 9, 1, 2, False), (1, 128, 128, 28, 28, 1, 0, True),
-    (2, 128, 256, 14, 14, 2, 0, False), (1, 256, 512, 14, 14, 2, 0, False), (5, 64, 64, 56, 56, 1, 0, True)])
+    (2, 128, 256, 14, 14, 2, 0, False), (1, 256, 512, 14, 14, 2, 0, False), (5, 64, 64, 56, 56, 1, 0, True),
+    # halo-tiled kernel (Cin = Cout = 64, stride 1): ragged tiles in both directions, single pixel rows/columns, many tiles per workgroup
+    (1, 64, 64, 8, 16, 1, 0, False), (2, 64, 64, 1, 1, 1, 1, True), (1, 64, 64, 3, 40, 1, 2, True), (3, 64, 64, 37, 5, 1, 0, False),
+    (2, 64, 64, 17, 33, 1, 2, True), (40, 64, 64, 56, 56, 1, 1, True)])
 def test_conv3x3_fused(dt, code, B, Ci, Co, H, W, stride, act, res):
     """Implicit-GEMM 3x3 conv + bias + activation (+ residual) on channels_last 16-bit maps vs F.conv2d in fp32."""
     lib = _lib.lib()
@@ -289,6 +292,34 @@ def test_conv3x3_fused(dt, code, B, Ci, Co, H, W, stride, act, res):
                                          stride, act, zeros.data_ptr(), _stream()), "conv3x3 in place")
         torch.cuda.synchronize()
         assert torch.equal(r2, out)
+
+
+@pytest.mark.parametrize("B,H,W,grid", [(3, 56, 56, 512), (2, 24, 50, 8), (9, 9, 17, 16), (1, 40, 40, 1)])
+def test_conv3x3_halo_matches_implicit_gemm_kernel(B, H, W, grid):
+    """The halo-tiled 64->64 kernel and the implicit-GEMM kernel accumulate the same products in fp32: outputs agree to 16-bit rounding,
+    for any persistent grid size (tile ranges per XCD, several tiles per workgroup)."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + H)
+    x = torch.randn(B, H, W, 64, generator=g).half().cuda()
+    r = torch.randn(B, H, W, 64, generator=g).half().cuda()
+    wk = (torch.randn(64, 3, 3, 64, generator=g) / 24).half().cuda()
+    bias = torch.randn(64, generator=g).cuda()
+    zeros = torch.zeros(256, dtype=torch.float16, device="cuda")
+    outs = []
+    try:
+        for halo in (0, 1):
+            _lib.tune("conv_halo", halo)
+            _lib.tune("conv_halo_grid", grid)
+            o = torch.full_like(x, float("nan"))
+            _lib.check(lib.fvit_conv3x3_nhwc(1, x.data_ptr(), wk.data_ptr(), bias.data_ptr(), r.data_ptr(), o.data_ptr(), B, H, W, 64, 64, 1, 2,
+                                             zeros.data_ptr(), _stream()), "conv3x3")
+            torch.cuda.synchronize()
+            outs.append(o.float())
+    finally:
+        _lib.tune("conv_halo", 1)
+        _lib.tune("conv_halo_grid", 512)
+    assert torch.isfinite(outs[1]).all()
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-3 * max(outs[0].abs().max().item(), 1.0)
 
 
 @pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
