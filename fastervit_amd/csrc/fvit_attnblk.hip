@@ -349,10 +349,11 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
     const double bytes = 8.0 * rows * c.C + 8.0 * c.C * c.C;
     ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
     const bool small = c.S <= 16;
-    // 1 (default): 8 waves / 2 windows per workgroup, bias table in LDS, one workgroup per CU;
-    // 0: 4 waves / 1 window, bias from L2, two workgroups per CU -- measured equal (99.9 vs 96.7 us): the sub-block is bound by
-    //    its three fp32 passes over X (gather read, epilogue re-read, write), not by occupancy
-    const int variant = tune_get("ab_variant", 1);
+    // 0 (default): 4 waves / 1 window per workgroup, bias from L2, two workgroups per CU;
+    // 1: 8 waves / 2 windows, bias table in LDS, one workgroup per CU -- equal on whole-batch launches (99.9 vs 96.7 us: the
+    //    sub-block is bound by its three fp32 passes over X), but the smaller workgroups of variant 0 fill the chip better on
+    //    the shard-sized launches of the stream-sharded deploy plan (+2..3 % images/s, r01 sweep r20)
+    const int variant = tune_get("ab_variant", 0);
 #define FVIT_AB(T, NRB, NW, BL) hipLaunchKernelGGL((attnblk_kernel<T, NRB, NW, BL>), dim3((c.nwin + (NW / NRB) - 1) / (NW / NRB)), \
                                                    dim3(64 * NW), 0, stream, p)
     if (c.dtype == FVIT_F16) {

@@ -44,6 +44,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// The activation and the residual switch are runtime arguments but must not be runtime branches inside the per-element
+// epilogue loops (a uniform branch per output value keeps the compiler from interleaving the 32-64 independent
+// bias/GELU/convert chains of a lane): dispatch ONCE per tile to a body specialised on both.
+template <int V> struct IntTag { static constexpr int value = V; };
+template <typename F>
+__device__ __forceinline__ void dispatch_epilogue(int act, bool has_res, F&& body) {
+    if (has_res) {
+        if (act == 0) body(IntTag<0>{}, IntTag<1>{});
+        else if (act == 1) body(IntTag<1>{}, IntTag<1>{});
+        else body(IntTag<2>{}, IntTag<1>{});
+    } else {
+        if (act == 0) body(IntTag<0>{}, IntTag<0>{});
+        else if (act == 1) body(IntTag<1>{}, IntTag<0>{});
+        else body(IntTag<2>{}, IntTag<0>{});
+    }
+}
+
 // per-wave tile: 64 pixels x 16*NI channels; workgroup tile: 64*WM pixels x 16*NI*WN channels (WM*WN = 4 waves)
 template <typename T, int WM, int WN, int NI>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
@@ -171,28 +188,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     }
     T* O = (T*)p.out;
     const T* R = (const T*)p.res;
+    dispatch_epilogue(p.act, R != nullptr, [&](auto act_tag, auto res_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        constexpr bool RES = decltype(res_tag)::value != 0;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + s;
-        if (m < p.M) {
-            vout rv;
-            if (R) rv = *(const vout*)(R + (size_t)m * p.Cout + nb);
-            vout ov;
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + s;
+            if (m < p.M) {
+                vout rv;
+                if (RES) rv = *(const vout*)(R + (size_t)m * p.Cout + nb);
+                vout ov;
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const f4 a = acc[ni][mi];
+                for (int ni = 0; ni < NI; ++ni) {
+                    const f4 a = acc[ni][mi];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float y = a[r] + bias[ni * 4 + r];
-                    if (p.act == 1) y = fmaxf(y, 0.f);
-                    else if (p.act == 2) y = gelu_fast(y);
-                    if (R) y += (float)rv[ni * 4 + r];
-                    ov[ni * 4 + r] = (T)y;
+                    for (int r = 0; r < 4; ++r) {
+                        float y = a[r] + bias[ni * 4 + r];
+                        if (ACT == 1) y = fmaxf(y, 0.f);
+                        else if (ACT == 2) y = gelu_fast(y);
+                        if (RES) y += (float)rv[ni * 4 + r];
+                        ov[ni * 4 + r] = (T)y;
+                    }
                 }
+                *(vout*)(O + (size_t)m * p.Cout + nb) = ov;
             }
-            *(vout*)(O + (size_t)m * p.Cout + nb) = ov;
         }
-    }
+    });
 }
 
 
@@ -308,17 +329,24 @@ struct HaloParams {
     const void* zeros;
     int B, H, W, act;
     int tiles_x, tiles_y, tiles;
+    int buf_bytes;       // LDS bytes per tile buffer: HALO_BYTES (+ HALO_RES_BYTES with a residual)
+    int ablate;          // experiment knob (results are wrong when non-zero): 1 no MFMA loop, 2 no halo/residual DMA, 4 no stores, 8 no epilogue math
 };
 
 constexpr int HALO_TH = 8, HALO_TW = 16, HALO_PW = HALO_TW + 2, HALO_PH = HALO_TH + 2;
 constexpr int HALO_PIECES = (HALO_PH * HALO_PW + 7) / 8;       // 1-KiB pieces of 8 halo pixels
 constexpr int HALO_BYTES = HALO_PIECES * 1024;
+constexpr int HALO_RES_BYTES = HALO_TH * HALO_TW * 128;         // the tile's residual pixels, staged next to the halo
+constexpr int HALO_BUF = HALO_BYTES + HALO_RES_BYTES;
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_halo_kernel(HaloParams p) {
     typedef typename Op16<T>::v8 v8;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * HALO_BYTES];
-    __shared__ __attribute__((aligned(16))) float sbias[64];
+    // dynamic LDS: [64 floats bias | pad to 1 KiB][2 x (halo + residual tile)]; without a residual the second part of each
+    // buffer is neither allocated nor touched (buffer stride p.buf_bytes)
+    extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
+    float* sbias = (float*)smem_dyn;
+    char* smem = smem_dyn + 1024;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -339,6 +367,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_halo_kernel(HaloParams p) 
     const T* __restrict__ In = (const T*)p.in;
     const T* __restrict__ W = (const T*)p.w;
     const T* __restrict__ Z = (const T*)p.zeros;
+    T* O = (T*)p.out;
+    const T* R = (const T*)p.res;   // may alias O (in place): a tile's residual is staged before its output is written
 
     // ---- stationary weights: wf[tap][kk][ni], A-row slot s of fragment ni -> channel 32ch + (s>>2)*8 + ni*4 + (s&3) ----
     v8 wf[9][2][2];
@@ -356,12 +386,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_halo_kernel(HaloParams p) 
     int xoff[3];   // K half 1 is the same address with bit 6 flipped (chunk position c ^ 4)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) xoff[kx] = (s + kx) * 128 + ((g ^ ((s + kx) & 6)) << 4);
+    // residual read offset: pixel (row, s) of the tile at (row*16 + s)*128, chunk c at position c ^ ((s >> 1) & 7)
+    const int roff = HALO_BYTES + (ph * 4 * HALO_TW + s) * 128 + (((ch * 4 + g) ^ ((s >> 1) & 7)) << 4);
 
     auto stage = [&](int tile, char* buf) {
         const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
         const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
         const int y0 = ty * HALO_TH - 1, x0 = tx * HALO_TW - 1;
-        const T* img = In + (size_t)b * p.H * p.W * 64;
+        const size_t ib = (size_t)b * p.H * p.W * 64;
         // the halo coordinates are tile independent, but keeping 6 x (hy, hx, chunk) live across the MFMA loop costs
         // more registers than the weights leave: recompute them per tile (a handful of VALU ops per 1-KiB piece)
         int lane8 = lane >> 3;
@@ -375,14 +407,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_halo_kernel(HaloParams p) 
                 const int y = y0 + hy, x = x0 + hx;
                 const bool ok = hy < HALO_PH && y >= 0 && y < p.H && x >= 0 && x < p.W;
                 const int c = (lane & 7) ^ (hx & 6);
-                const T* src = ok ? img + ((size_t)y * p.W + x) * 64 + c * 8 : Z + c * 8;
+                const T* src = ok ? In + ib + ((size_t)y * p.W + x) * 64 + c * 8 : Z + c * 8;
                 glds16(src, buf + piece * 1024);
+            }
+        }
+        if (R) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int piece = wave * 4 + i;            // 8 pixels of tile row piece >> 1
+                const int col = (piece & 1) * 8 + lane8;
+                const int y = y0 + 1 + (piece >> 1), x = x0 + 1 + col;
+                const bool ok = y < p.H && x < p.W;
+                const int c = (lane & 7) ^ ((col >> 1) & 7);
+                const T* src = ok ? R + ib + ((size_t)y * p.W + x) * 64 + c * 8 : Z + c * 8;
+                glds16(src, buf + HALO_BYTES + piece * 1024);
             }
         }
     };
 
-    T* __restrict__ O = (T*)p.out;
-    const T* __restrict__ R = (const T*)p.res;
+    // Outputs are written one tile late: the 16-bit results of tile i wait in 16 VGPRs while tile i+1 is staged, and are
+    // stored just before tile i+1's MFMA loop -- so the s_waitcnt vmcnt(0) that guards the NEXT halo finds those stores
+    // (and the halo DMA issued with them) long complete instead of exposing the HBM write latency once per tile.
+    v8 pk[4];
+    int ptile = -1;
+    auto flush = [&](int tile) {
+        const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
+        const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
+        const int x = tx * HALO_TW + s;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int y = ty * HALO_TH + ph * 4 + mi;
+            if (y < p.H && x < p.W) *(v8*)(O + (((size_t)b * p.H + y) * p.W + x) * 64 + nb) = pk[mi];
+        }
+    };
 
     int tile = t_begin + idx;
     if (tile < t_end) stage(tile, smem);
@@ -390,8 +447,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_halo_kernel(HaloParams p) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = it & 1;
-        if (tile + per_xcd < t_end) stage(tile + per_xcd, smem + (cur ^ 1) * HALO_BYTES);
-        const char* hb = smem + cur * HALO_BYTES + ph * 4 * (HALO_PW * 128);
+        if (tile + per_xcd < t_end && !(p.ablate & 2)) stage(tile + per_xcd, smem + (cur ^ 1) * p.buf_bytes);
+        if (ptile >= 0 && !(p.ablate & 4)) flush(ptile);
+        const char* tb = smem + cur * p.buf_bytes;
+        const char* hb = tb + ph * 4 * (HALO_PW * 128);
 
         f4 acc[2][4];
 #pragma unroll
@@ -404,6 +463,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_halo_kernel(HaloParams p) 
         v8 xf[2][4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) xf[0][mi] = *(const v8*)(hb + mi * (HALO_PW * 128) + xoff[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.ablate & 1))
 #pragma unroll
         for (int q = 0; q < 18; ++q) {
             const int tap = q >> 1, kk = q & 1;
@@ -420,40 +481,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_halo_kernel(HaloParams p) 
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        // ---- epilogue: lane holds out[b][y][x][nb .. nb+7] for the 4 rows y = 8ty + 4ph + mi, column x = 16tx + s ----
-        const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
-        const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
-        const int x = tx * HALO_TW + s;
+        // ---- epilogue math: lane holds out[b][y][x][nb .. nb+7] for rows y = 8ty + 4ph + mi, column x = 16tx + s ----
         float bias[8];
         {
             const f4 t0 = *(const f4*)(sbias + nb), t1 = *(const f4*)(sbias + nb + 4);
             bias[0] = t0[0]; bias[1] = t0[1]; bias[2] = t0[2]; bias[3] = t0[3];
             bias[4] = t1[0]; bias[5] = t1[1]; bias[6] = t1[2]; bias[7] = t1[3];
         }
+        if (!(p.ablate & 8))
+            dispatch_epilogue(p.act, R != nullptr, [&](auto act_tag, auto res_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
+                constexpr bool RES = decltype(res_tag)::value != 0;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int y = ty * HALO_TH + ph * 4 + mi;
-            if (y < p.H && x < p.W) {
-                const size_t m = ((size_t)b * p.H + y) * p.W + x;
-                v8 rv;
-                if (R) rv = *(const v8*)(R + m * 64 + nb);
-                v8 ov;
+                for (int mi = 0; mi < 4; ++mi) {
+                    v8 rv;
+                    if (RES) rv = *(const v8*)(tb + roff + mi * (HALO_TW * 128));
+                    v8 ov;
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const f4 a = acc[ni][mi];
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const f4 a = acc[ni][mi];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float yv = a[r] + bias[ni * 4 + r];
-                        if (p.act == 1) yv = fmaxf(yv, 0.f);
-                        else if (p.act == 2) yv = gelu_fast(yv);
-                        if (R) yv += (float)rv[ni * 4 + r];
-                        ov[ni * 4 + r] = (T)yv;
+                        for (int r = 0; r < 4; ++r) {
+                            float yv = a[r] + bias[ni * 4 + r];
+                            if (ACT == 1) yv = fmaxf(yv, 0.f);
+                            else if (ACT == 2) yv = gelu_fast(yv);
+                            if (RES) yv += (float)rv[ni * 4 + r];
+                            ov[ni * 4 + r] = (T)yv;
+                        }
                     }
+                    pk[mi] = ov;
                 }
-                *(v8*)(O + m * 64 + nb) = ov;
-            }
-        }
+            });
+        ptile = tile;
     }
+    if (ptile >= 0) flush(ptile);
 }
 
 template <typename T>
@@ -464,13 +525,26 @@ int launch_halo_t(const ConvParams& c, hipStream_t stream) {
     p.tiles_x = (c.Wi + HALO_TW - 1) / HALO_TW;
     p.tiles_y = (c.Hi + HALO_TH - 1) / HALO_TH;
     p.tiles = c.B * p.tiles_x * p.tiles_y;   // <= M, which the caller checked against int32
+    p.ablate = tune_get("conv_halo_ablate", 0);
     int maxgrid = tune_get("conv_halo_grid", 512);   // 2 workgroups per CU (230 VGPRs, 46 KiB LDS each)
     if (maxgrid < 8) maxgrid = 8;                    // every XCD's tile range needs at least one workgroup
     const int grid = p.tiles < maxgrid ? p.tiles : maxgrid;
     const double flops = 2.0 * c.M * 64.0 * 576.0;
     const double bytes = 2.0 * ((double)c.M * 64 * (c.res ? 3.0 : 2.0) + 576.0 * 64);
     ProfScope prof(FVIT_K_CONV, flops, bytes, stream);
-    hipLaunchKernelGGL((conv3x3_c64_halo_kernel<T>), dim3(grid), dim3(256), 0, stream, p);
+    p.buf_bytes = c.res ? HALO_BUF : HALO_BYTES;
+    const size_t lds = 1024 + 2 * (size_t)p.buf_bytes;
+    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process and kernel)
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv3x3_c64_halo_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 + 2 * HALO_BUF);
+        attr_set = true;
+    }
+    if (tune_get("conv_halo_debug", 0)) {
+        int nb = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv3x3_c64_halo_kernel<T>, 256, lds);
+        fprintf(stderr, "[fvit] conv3x3_c64_halo: grid %d, tiles %d, dynamic LDS %zu B, resident workgroups/CU %d\n", grid, p.tiles, lds, nb);
+    }
+    hipLaunchKernelGGL((conv3x3_c64_halo_kernel<T>), dim3(grid), dim3(256), lds, stream, p);
     return check_launch("conv3x3_c64_halo_kernel");
 }
 

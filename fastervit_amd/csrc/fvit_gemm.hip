@@ -226,8 +226,9 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.tiles_n = (c.N + BN - 1) / BN;
     // small grids (<= 2 workgroups per CU with 128-row tiles) switch to 64-row tiles: twice the workgroups, 3 per CU
     const int grid128 = ((c.M + 127) / 128) * p.tiles_n;
-    // measured r01: no gain (gamma-residual GEMMs 0.653 vs 0.585 ms per step with 64-row tiles) => opt-in only
-    const bool small = grid128 <= tune_get("gemm_bm64_max_grid", 0);
+    // measured r01: no gain on whole-batch launches (gamma-residual GEMMs 0.653 vs 0.585 ms per step with 64-row tiles), but
+    // +2 % images/s on the shard-sized launches of the stream-sharded deploy plan (132-396 workgroups with 128-row tiles)
+    const bool small = grid128 <= tune_get("gemm_bm64_max_grid", 400);
     p.tiles_m = small ? (c.M + 63) / 64 : (c.M + 127) / 128;
     const int grid = p.tiles_m * p.tiles_n;
     const double flops = 2.0 * c.M * (double)c.N * c.K;

@@ -41,6 +41,7 @@ def run(name, res, act, n=24):
     if name.startswith("halo"):
         _lib.tune("conv_halo", 1)
         _lib.tune("conv_halo_grid", int(name.split(":")[1]) if ":" in name else 512)
+        _lib.tune("conv_halo_ablate", int(name.split("a")[2]) if name.count("a") > 1 else 0)   # e.g. haloa3 = ablate bits 1|2
     else:
         _lib.tune("conv_halo", 0)
     for i in range(3):
@@ -71,6 +72,8 @@ torch.cuda.synchronize()
 ref = outs[0].clone()
 _lib.tune("conv_halo", 1)
 _lib.tune("conv_halo_grid", 512)
+_lib.tune("conv_halo_ablate", 0)
+_lib.tune("conv_halo_debug", 1)
 conv(0, True, 2)
 torch.cuda.synchronize()
 print("max |halo - gemm| =", (outs[0].float() - ref.float()).abs().max().item(), " max |ref| =", ref.float().abs().max().item())
