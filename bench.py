@@ -167,6 +167,22 @@ def main():
                      "algorithmic_gflop_per_launch": round(e["flops"] / e["launches"] / 1e9, 3),
                      "algorithmic_mbyte_per_launch": round(e["bytes"] / e["launches"] / 1e6, 3)}
 
+    def pmc_traffic(kind, shard_sized):
+        """HBM bytes per launch of the kernel family `kind` from the committed rocprofv3 PMC passes (profiles/, collected with
+        scripts/gpu_prof.sh + scripts/pmc_traffic_summary.py on the same command in eager mode): bench.py cannot sample PMCs on
+        itself.  Picks the (kernel, grid) row with the largest summed time, i.e. the launch shape that dominates the family."""
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic_by_kernel_v9.json")
+        prefix = {"mlp_fused": "mlp_fused_kernel", "attn_block_fused": "attnblk_kernel", "gemm_bias": f"gemm_kernel<{args.operand},0",
+                  "gemm_gelu": f"gemm_kernel<{args.operand},1", "gemm_residual": f"gemm_kernel<{args.operand},2"}.get(kind)
+        if not shard_sized or prefix is None or not os.path.exists(path) or args.model != "faster_vit_0_224" or args.batch != 256:
+            return None, None
+        rows = [r for r in json.load(open(path))["kernels"] if r["kernel"].startswith(prefix)]
+        if not rows:
+            return None, None
+        r = max(rows, key=lambda r: r["total_us"])
+        return int(r["hbm_traffic_mb"] * 1e6), (f"profiles/r01_pmc_hbm_traffic_by_kernel_v9.json: {r['kernel']} x {r['workgroups']} workgroups, "
+                                                f"read {r['hbm_read_mb']} MB (2 x FETCH_SIZE) + write {r['hbm_write_mb']} MB per launch")
+
     def kernel_table(pr):
         return {k: {"launches_per_step": v["launches"] // args.prof_steps, "ms_per_step": round(v["ms"] / args.prof_steps, 4),
                     "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
@@ -177,6 +193,7 @@ def main():
     prof = profile_pass()
     hat_ms = sum(e["ms"] for k, e in prof.items() if k not in ("other", "conv3x3")) / args.prof_steps
     dom, roofline = roofline_of(prof)
+    roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, deploy and args.streams == 3)
     kernels = kernel_table(prof)
     # ---- the same kernels with the GPU to themselves: one stream, whole-batch launches (kernel quality, not job throughput) ----
     roofline_isolated = None

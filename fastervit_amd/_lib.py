@@ -13,17 +13,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libfvit_hip.so")
 
-FVIT_ABI_VERSION = 1
+FVIT_ABI_VERSION = 2
 FVIT_F32, FVIT_F16, FVIT_BF16 = 0, 1, 2
 FVIT_TILE_N, FVIT_TILE_K = 128, 64
 FVIT_MASK_BIAS = -30000.0
+FVIT_MAX_DENSE_SEQ = 208   # longer window sequences use the online-softmax attention kernel with the compact bias table
 FVIT_PROF_KINDS = 11
 
 # every symbol include/fvit_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = (
-    "fvit_abi_version", "fvit_last_error", "fvit_attention_spad", "fvit_stage_workspace_bytes",
+    "fvit_abi_version", "fvit_last_error", "fvit_attention_spad", "fvit_attention_dense", "fvit_stage_workspace_bytes",
     "fvit_workspace_init", "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_token_init", "fvit_window_partition",
-    "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_window_attention",
+    "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_window_attention", "fvit_window_attention_long",
     "fvit_gather_layernorm", "fvit_attn_block_supported", "fvit_attn_block_fused", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl", "fvit_conv3x3_nhwc", "fvit_stem_conv3x3s2",
     "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_kind_name",
 )
@@ -37,7 +38,8 @@ class FvitStageDesc(C.Structure):
 
 class FvitAttnWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w_qkv", "b_qkv", "w_proj", "b_proj", "bias", "ln_w", "ln_b", "gamma",
-                                                  "w_qkv_frag", "b_qkv_heads", "w_proj_frag")]
+                                                  "w_qkv_frag", "b_qkv_heads", "w_proj_frag", "rel_table")] + \
+               [("rel_w", C.c_int32), ("rel_ng", C.c_int32)]
 
 
 class FvitMlpWeights(C.Structure):
@@ -106,6 +108,10 @@ def _declare(lib):
     lib.fvit_gemm_residual.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fvit_window_attention.restype = C.c_int
     lib.fvit_window_attention.argtypes = [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, vp]
+    lib.fvit_attention_dense.restype = C.c_int
+    lib.fvit_attention_dense.argtypes = [i32, i32]
+    lib.fvit_window_attention_long.restype = C.c_int
+    lib.fvit_window_attention_long.argtypes = [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]
     lib.fvit_gather_layernorm.restype = C.c_int
     lib.fvit_gather_layernorm.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, f32, i32, i32, i32, vp]
     lib.fvit_attn_block_supported.restype = C.c_int

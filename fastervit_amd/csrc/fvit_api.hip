@@ -101,7 +101,7 @@ struct StageLayout {
 
 static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
     if (d.batch <= 0 || d.C <= 0 || d.heads <= 0 || d.C % d.heads || d.ws <= 0 || d.Hp % d.ws || d.Wp % d.ws ||
-        (d.dpad != 32 && d.dpad != 64) || d.dpad < d.C / d.heads || d.hidden <= 0 || (d.C % 16) || (d.hidden % 16) ||
+        (d.dpad != 32 && d.dpad != 64 && d.dpad != 96) || d.dpad < d.C / d.heads || d.hidden <= 0 || (d.C % 16) || (d.hidden % 16) ||
         (d.operand_dtype != FVIT_F16 && d.operand_dtype != FVIT_BF16) || (d.hier && d.cw <= 0)) {
         set_error("stage descriptor rejected: batch=%d C=%d heads=%d dpad=%d ws=%d Hp=%d Wp=%d hidden=%d hier=%d cw=%d dtype=%d",
                   d.batch, d.C, d.heads, d.dpad, d.ws, d.Hp, d.Wp, d.hidden, d.hier, d.cw, d.operand_dtype);
@@ -161,7 +161,7 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
     GemmCall g1 = {dt, xn, L.ldn, w.w_qkv, L.ldn, w.b_qkv, nullptr, qkv, L.ldqkv, (int)rows, L.ldqkv, L.ldn, 0};
     FVIT_TRY(launch_gemm(g1, st));
     const float scale = 1.0f / sqrtf((float)(d.C / d.heads));
-    AttnCall at = {dt, qkv, L.ldqkv, ao, L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale};
+    AttnCall at = {dt, qkv, L.ldqkv, ao, L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale, w.rel_table, w.rel_w, w.rel_ng};
     FVIT_TRY(launch_attention(at, st));
     GemmCall g2 = {dt, ao, L.ldao, w.w_proj, L.ldao, w.b_proj, w.gamma, x, d.C, (int)rows, d.C, L.ldao, 2};
     FVIT_TRY(launch_gemm(g2, st));
@@ -260,6 +260,8 @@ extern "C" {
 
 int fvit_abi_version(void) { return FVIT_ABI_VERSION; }
 const char* fvit_last_error(void) { return g_err; }
+
+int fvit_attention_dense(int32_t S, int32_t dpad) { return attention_dense(S, dpad) ? 1 : 0; }
 
 int fvit_attention_spad(int32_t S) {
     int sb = (S + 15) / 16;
@@ -381,8 +383,19 @@ int fvit_gemm_residual(int32_t operand_dtype, const void* A, int32_t lda, const 
 
 int fvit_window_attention(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, const float* bias,
                           int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale, fvit_stream_t stream) {
-    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, bias, nwin, S, heads, dpad, scale};
+    if (!attention_dense(S, dpad)) {
+        set_error("window_attention: S=%d at dpad=%d is outside the dense-bias kernel (fvit_attention_dense); use fvit_window_attention_long", S, dpad);
+        return FVIT_EINVAL;
+    }
+    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, bias, nwin, S, heads, dpad, scale, nullptr, 0, 0};
     return launch_attention(a, (hipStream_t)stream);
+}
+
+int fvit_window_attention_long(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, const float* rel_table,
+                               int32_t rel_w, int32_t rel_ng, int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale,
+                               fvit_stream_t stream) {
+    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, nullptr, nwin, S, heads, dpad, scale, rel_table, rel_w, rel_ng};
+    return launch_attention_long(a, (hipStream_t)stream);
 }
 
 int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB,

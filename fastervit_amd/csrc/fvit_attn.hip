@@ -207,8 +207,8 @@ int launch_sb(const AttnParams& p, int sb, hipStream_t stream) {
         case 6: launch_inst<T, 6, DP>(p, stream); break;
         case 7: launch_inst<T, 7, DP>(p, stream); break;
         case 8: launch_inst<T, 8, DP>(p, stream); break;
-        case 10: launch_inst<T, 10, DP>(p, stream); break;
-        case 13: launch_inst<T, 13, DP>(p, stream); break;
+        case 10: if constexpr (DP <= 64) { launch_inst<T, 10, DP>(p, stream); break; }
+        case 13: if constexpr (DP <= 64) { launch_inst<T, 13, DP>(p, stream); break; }
         default:
             set_error("attention: padded sequence of %d tokens has no kernel instance (supported: 16..128, 160, 208)",
                       sb * 16);
@@ -219,9 +219,16 @@ int launch_sb(const AttnParams& p, int sb, hipStream_t stream) {
 
 }  // namespace
 
+bool attention_dense(int S, int dpad) {
+    // the in-register kernel keeps all K fragments (SB x DP/32 x 4 VGPRs) and a V^T image (4 waves x DP x ~S x 2 B of LDS):
+    // with the 96-wide head padding (head_dim 65..96: FasterViT-5/6) that fits up to 128 tokens
+    return S >= 1 && S <= FVIT_MAX_DENSE_SEQ && (dpad <= 64 || S <= 128);
+}
+
 int launch_attention(const AttnCall& c, hipStream_t stream) {
-    if (c.S <= 0 || c.nwin <= 0 || (c.dpad != 32 && c.dpad != 64) || (c.ldq % 8) || (c.ldo % 8)) {
-        set_error("attention: unsupported geometry S=%d nwin=%d dpad=%d ldq=%d ldo=%d", c.S, c.nwin, c.dpad, c.ldq, c.ldo);
+    if (!attention_dense(c.S, c.dpad)) return launch_attention_long(c, stream);
+    if (c.S <= 0 || c.nwin <= 0 || (c.dpad != 32 && c.dpad != 64 && c.dpad != 96) || (c.ldq % 8) || (c.ldo % 8) || !c.bias) {
+        set_error("attention: unsupported geometry S=%d nwin=%d dpad=%d ldq=%d ldo=%d bias=%p", c.S, c.nwin, c.dpad, c.ldq, c.ldo, (const void*)c.bias);
         return FVIT_EINVAL;
     }
     int sb = (c.S + 15) / 16;
@@ -233,8 +240,10 @@ int launch_attention(const AttnCall& c, hipStream_t stream) {
     const double flops = 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * c.dpad;
     const double bytes = 2.0 * c.nwin * (double)c.S * c.heads * c.dpad * 4.0;  // q,k,v read + o write (16-bit)
     ProfScope prof(FVIT_K_ATTENTION, flops, bytes, stream);
-    if (c.dtype == FVIT_F16) return c.dpad == 32 ? launch_sb<_Float16, 32>(p, sb, stream) : launch_sb<_Float16, 64>(p, sb, stream);
-    if (c.dtype == FVIT_BF16) return c.dpad == 32 ? launch_sb<__bf16, 32>(p, sb, stream) : launch_sb<__bf16, 64>(p, sb, stream);
+#define FVIT_ATTN_DP(T) (c.dpad == 32 ? launch_sb<T, 32>(p, sb, stream) : c.dpad == 64 ? launch_sb<T, 64>(p, sb, stream) : launch_sb<T, 96>(p, sb, stream))
+    if (c.dtype == FVIT_F16) return FVIT_ATTN_DP(_Float16);
+    if (c.dtype == FVIT_BF16) return FVIT_ATTN_DP(__bf16);
+#undef FVIT_ATTN_DP
     set_error("attention: operand dtype %d not supported", c.dtype);
     return FVIT_EINVAL;
 }

@@ -149,11 +149,16 @@ struct AttnCall {
     int ldq;
     void* out;        // op16 [rows][ldo], columns [head][dpad]
     int ldo;
-    const float* bias;  // f32 [heads][Spad][Spad]
+    const float* bias;  // f32 [heads][Spad][Spad] (S <= FVIT_MAX_DENSE_SEQ)
     int nwin, S, heads, dpad;
     float scale;
+    // S > FVIT_MAX_DENSE_SEQ: compact bias table f32 [heads][(2*rel_w-1)^2] (or null), n_g = rel_ng leading tokens without bias
+    const float* rel_table;
+    int rel_w, rel_ng;
 };
-int launch_attention(const AttnCall& c, hipStream_t stream);
+bool attention_dense(int S, int dpad);                               // in-register kernel + dense bias table, else the long kernel
+int launch_attention(const AttnCall& c, hipStream_t stream);        // dispatches on attention_dense(S, dpad)
+int launch_attention_long(const AttnCall& c, hipStream_t stream);   // fvit_attnlong.hip
 
 struct LnCall {
     int dtype;

@@ -129,12 +129,22 @@ def pack_attention(attn, norm, gamma, S: int, dpad: int, op_dtype, keep: _Keep) 
     ldao = _rup(h * dpad, FVIT_TILE_K)
     wp = torch.zeros(_rup(C_, FVIT_TILE_N), ldao, device=dev, dtype=torch.float32)
     wp[:C_, :h * dpad].view(C_, h, dpad)[:, :, :d] = _f32(attn.proj.weight).view(C_, h, d)
-    spad = lib.fvit_attention_spad(S)
-    bias = torch.zeros(h, spad, spad, device=dev, dtype=torch.float32)
-    bias[:, :S, :S] = attn.pos_emb_funct.table(S)
-    bias[:, :, S:] = FVIT_MASK_BIAS
-    bias[:, S:, :] = 0.0
-    bias[:, S:, S:] = FVIT_MASK_BIAS if S < spad else 0.0
+    bias = rel = None
+    rel_w = rel_ng = 0
+    if lib.fvit_attention_dense(S, dpad):
+        spad = lib.fvit_attention_spad(S)
+        bias = torch.zeros(h, spad, spad, device=dev, dtype=torch.float32)
+        bias[:, :S, :S] = attn.pos_emb_funct.table(S)
+        bias[:, :, S:] = FVIT_MASK_BIAS
+        bias[:, S:, :] = 0.0
+        bias[:, S:, S:] = FVIT_MASK_BIAS if S < spad else 0.0
+    else:
+        # long windows (21k 384/512/768 fine-tunes, large carrier grids): the dense table would be heads*S*S floats per block;
+        # the kernel evaluates relative_position_index arithmetically on the un-gathered (heads, (2w-1)^2) table instead
+        rel, rel_w = attn.pos_emb_funct.rel_table()
+        rel_ng = S - rel_w * rel_w
+        if rel_ng < 0:
+            raise RuntimeError(f"bias window {rel_w}x{rel_w} larger than the sequence ({S} tokens)")
     wqf = bqh = wpf = None
     if d == 32 and lib.fvit_attn_block_supported(C_, h, S):
         wqkv32 = _f32(attn.qkv.weight)
@@ -144,7 +154,7 @@ def pack_attention(attn, norm, gamma, S: int, dpad: int, op_dtype, keep: _Keep) 
         wpf = frag_pack_fc2(_f32(attn.proj.weight)).to(op_dtype)   # chunks of 32 input columns = heads
     return FvitAttnWeights(keep.ptr(wq.to(op_dtype), True), keep.ptr(bq), keep.ptr(wp.to(op_dtype), True), keep.ptr(_f32(attn.proj.bias)),
                            keep.ptr(bias), keep.ptr(_f32(norm.weight)), keep.ptr(_f32(norm.bias)), keep.ptr(_gamma(gamma)),
-                           keep.ptr(wqf, True), keep.ptr(bqh), keep.ptr(wpf, True))
+                           keep.ptr(wqf, True), keep.ptr(bqh), keep.ptr(wpf, True), keep.ptr(rel), rel_w, rel_ng)
 
 
 def frag_pack_qkv(wqkv: torch.Tensor, heads: int) -> torch.Tensor:
@@ -264,9 +274,9 @@ def _prepare(layer, x_dev, Hp: int, Wp: int):
     Cdim = blk0.attn.qkv.in_features
     heads = blk0.attn.num_heads
     d = Cdim // heads
-    if d > 64:
-        raise NotImplementedError(f"head_dim {d} > 64 has no attention kernel instance")
-    dpad = 32 if d <= 32 else 64
+    if d > 96:
+        raise NotImplementedError(f"head_dim {d} > 96 has no attention kernel instance")
+    dpad = 32 if d <= 32 else (64 if d <= 64 else 96)   # 96: head_dim 80 of FasterViT-5 / -6
     tkey = (Hp, Wp)
     if tkey not in st.tables:
         tb = build_tables(sr0, sr1, ws, cw, hier)

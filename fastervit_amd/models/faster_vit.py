@@ -226,6 +226,19 @@ class PosEmbMLPSwinv2D(nn.Module):
         pad = S - n
         return F.pad(b, (pad, 0, pad, 0)).contiguous()
 
+    @torch.no_grad()
+    def rel_table(self):
+        """((heads, (2*w0-1)*(2*w1-1)) fp32, w0): 16*sigmoid(cpb_mlp(relative_coords_table)) BEFORE the relative_position_index
+        gather (FV:276-280), head-major -- what the long-window attention kernel indexes arithmetically (square windows only)."""
+        w0, w1 = self.window_size
+        if w0 != w1:
+            raise NotImplementedError("long-window attention expects square windows (the reference only builds those)")
+        m0 = self.cpb_mlp[0].weight
+        with torch.autocast(device_type=m0.device.type, enabled=False):
+            h = torch.relu(F.linear(self.relative_coords_table.float(), m0.float(), self.cpb_mlp[0].bias.float()))
+            t = F.linear(h, self.cpb_mlp[2].weight.float()).float().view(-1, self.num_heads)
+        return (16 * torch.sigmoid(t)).t().contiguous(), int(w0)
+
 
 class Mlp(nn.Module):
     """FV:370-407 parameter holder (fc1 -> GELU -> fc2); executed by the fused GEMM kernels."""

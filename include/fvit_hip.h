@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FVIT_ABI_VERSION 1
+#define FVIT_ABI_VERSION 2
 
 /* error codes */
 #define FVIT_OK 0
@@ -47,6 +47,9 @@ extern "C" {
 #define FVIT_TILE_N 128 /* weight rows are zero-padded to a multiple of this */
 #define FVIT_TILE_K 64  /* K (columns of weights and activations) is zero-padded to a multiple */
 #define FVIT_MASK_BIAS (-30000.0f) /* additive score bias on padded key columns */
+#define FVIT_MAX_DENSE_SEQ 208     /* window sequences up to this length use the dense folded bias table and the in-register
+                                      attention kernel; longer ones (the 21k 384/512/768 fine-tunes: 576..2304 tokens) use the
+                                      online-softmax kernel with the compact relative table (FvitAttnWeights.rel_table) */
 
 typedef void* fvit_stream_t; /* hipStream_t */
 
@@ -58,7 +61,7 @@ typedef struct FvitStageDesc {
     int32_t batch;          /* images B */
     int32_t C;              /* channels */
     int32_t heads;          /* attention heads h (head_dim d = C / h) */
-    int32_t dpad;           /* head_dim padded to 32 or 64 (packed q/k/v/proj layout) */
+    int32_t dpad;           /* head_dim padded to 32, 64 or 96 (packed q/k/v/proj layout) */
     int32_t ws;             /* window side */
     int32_t H, W;           /* feature-map size before padding */
     int32_t Hp, Wp;         /* padded to a multiple of ws (AR:851-857) */
@@ -93,6 +96,13 @@ typedef struct FvitAttnWeights {
     const void* w_qkv_frag;
     const float* b_qkv_heads;
     const void* w_proj_frag;
+    /* Sequences longer than FVIT_MAX_DENSE_SEQ (then `bias` may be NULL): the un-gathered bias table
+     *   rel_table f32 [h][(2*rel_w-1)^2] = 16*sigmoid(cpb_mlp(relative_coords_table)) transposed to head-major (FV:276-280);
+     *   bias(q, k) = rel_table[h][(yq-yk+rel_w-1)*(2*rel_w-1) + (xq-xk+rel_w-1)] for tokens q, k >= rel_ng (token rel_ng + y*rel_w + x),
+     *   0 for the rel_ng = S - rel_w^2 leading tokens (carrier tokens / zero padding, FV:282-299). */
+    const float* rel_table;
+    int32_t rel_w;
+    int32_t rel_ng;
 } FvitAttnWeights;
 
 /* LayerNorm -> fc1 -> GELU(erf) -> fc2 -> gamma-residual.  Replaces Mlp.forward (AR:399-408). */
@@ -151,6 +161,9 @@ const char* fvit_last_error(void);
 /* Padded sequence length (multiple of 16) the attention kernel uses for S tokens; the folded bias
  * tables must be laid out [heads][spad][spad] with this value (FvitStageDesc.spad / .gpad). */
 int fvit_attention_spad(int32_t S);
+/* 1 if a (window sequence, padded head dim) pair runs on the in-register kernel with the dense bias table
+ * (S <= FVIT_MAX_DENSE_SEQ, and S <= 128 for dpad 96), 0 if it needs FvitAttnWeights.rel_table and the online-softmax kernel. */
+int fvit_attention_dense(int32_t S, int32_t dpad);
 
 /* Bytes of workspace fvit_hat_stage_forward needs for this geometry.  The workspace must be
  * zero-filled once (fvit_workspace_init or any memset) before its first use with a given
@@ -206,6 +219,11 @@ int fvit_gemm_residual(int32_t operand_dtype, const void* A, int32_t lda, const 
 int fvit_window_attention(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo,
                           const float* bias, int32_t nwin, int32_t S, int32_t heads, int32_t dpad,
                           float scale, fvit_stream_t stream);
+/* Same contract for windows of more than FVIT_MAX_DENSE_SEQ tokens (any S >= 1 is accepted): online softmax over key tiles,
+ * bias from the compact table rel_table f32 [heads][(2*rel_w-1)^2] (NULL = no bias) with rel_ng + rel_w^2 == S, see FvitAttnWeights. */
+int fvit_window_attention_long(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo,
+                               const float* rel_table, int32_t rel_w, int32_t rel_ng, int32_t nwin, int32_t S,
+                               int32_t heads, int32_t dpad, float scale, fvit_stream_t stream);
 /* Row gather + optional add + LayerNorm: for row i (image b = i / rows_per_image, p = i % rows_per_image)
  *   v = (src_idx ? (src_idx[p] >= 0 ? srcA[b*rowsA + src_idx[p]] : srcB[b*rowsB - src_idx[p] - 1]) : srcA[i])
  *       + (add_idx && add_idx[p] >= 0 ? add[add_idx[p]] : 0)

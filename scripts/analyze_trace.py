@@ -7,8 +7,12 @@ time during which it was the only kernel running.
 """
 import csv
 import re
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import demangle  # noqa: E402
 
 path = sys.argv[1]
 win = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 40e6
@@ -25,10 +29,11 @@ wall = t_end - t0
 
 
 def short(n):
+    n = demangle(n)
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"^void ", "", n)
-    m = re.match(r"(?:fvit::)?(\w+)(<[^(]*>)?", n)
-    return (m.group(1) + (m.group(2) or "")) if m else n[:60]
+    n = n.replace("fvit::", "")
+    return n.split("(")[0][:70]
 
 
 ev = []

@@ -5,8 +5,12 @@ usage: python scripts/summarize_rocprof_db.py <bench_results.db> <out-prefix>
 """
 import csv
 import sqlite3
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import demangle  # noqa: E402
 
 db = sqlite3.connect(sys.argv[1])
 out = sys.argv[2]
@@ -19,11 +23,11 @@ by_name = defaultdict(list)
 by_shape = defaultdict(list)
 for r in rows:
     d = r[ix["end"]] - r[ix["start"]]
-    n = r[ix[name_c]]
+    n = demangle(r[ix[name_c]])
     by_name[n].append(d)
     wg = r[ix["workgroup_x"]] if "workgroup_x" in ix else r[ix["workgroup_size_x"]]
     gx = r[ix["grid_x"]] if "grid_x" in ix else r[ix["grid_size_x"]]
-    if "fvit" in n or "token_init" in n or "map_rows" in n or "ct_rows" in n:
+    if "fvit" in r[ix[name_c]] or "_kernel" in n:
         by_shape[(n, gx // max(wg, 1), wg, r[ix["vgpr_count"]] if "vgpr_count" in ix else 0,
                   r[ix["lds_size"]] if "lds_size" in ix else (r[ix["lds_block_size"]] if "lds_block_size" in ix else 0))].append(d)
 tot = sum(sum(v) for v in by_name.values())

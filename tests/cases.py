@@ -27,6 +27,11 @@ CASES = {
                                  hw=(576, 960), family="init", per_block=False,
                                  arch=_arch([3, 3, 12, 5], [4, 8, 16, 32], [7, 7, 12, 6], 196, [576, 960], prop=True,
                                             any_res=True)),
+    # ---- ImageNet-21k fine-tune geometries with ONE long window per image in stage 2 (576 / 2304 tokens): logits only ----
+    "fvit4_21k_384": dict(entry="faster_vit_4_21k_384", kwargs={}, batch=1, hw=(384, 384), family="init", per_block=False,
+                          arch=_arch([3, 3, 12, 5], [4, 8, 16, 32], [7, 7, 24, 12], 196, 384, hat=[False] * 4, prop=True)),
+    "fvit4_21k_768": dict(entry="faster_vit_4_21k_768", kwargs={}, batch=1, hw=(768, 768), family="init", per_block=False,
+                          arch=_arch([3, 3, 12, 5], [4, 8, 16, 32], [7, 7, 48, 24], 196, 768, hat=[False] * 4, prop=True)),
     # ---- small configs with per-block goldens ("stress" weights so every sub-path matters) ----
     # square hierarchical stage, layer scale + propagation, head_dim 24 (padded to 32)
     "tiny_hier": dict(entry="faster_vit_4_224",
@@ -50,6 +55,23 @@ CASES = {
                      kwargs=dict(depths=[1, 1, 2, 1], num_heads=[1, 1, 2, 4], dim=16, in_dim=16), batch=1, hw=(224, 224),
                      family="stress", per_block=True,
                      arch=_arch([1, 1, 2, 1], [1, 1, 2, 4], [7, 7, 14, 7], 16, 224, hat=[False] * 4, prop=True)),
+    # head_dim 80 (padded to 96) in both transformer stages, as in FasterViT-5 / -6; hierarchical, layer scale, propagation
+    "tiny_d80": dict(entry="faster_vit_5_224",
+                     kwargs=dict(depths=[1, 1, 2, 1], num_heads=[1, 1, 1, 2], dim=20, in_dim=16), batch=2, hw=(224, 224),
+                     family="stress", per_block=True,
+                     arch=_arch([1, 1, 2, 1], [1, 1, 1, 2], [7, 7, 7, 7], 20, 224, prop=True)),
+    # ---- long windows (> 208 tokens): the online-softmax attention kernel with the compact relative-bias table ----
+    # one 24x24 window (576 tokens) in stage 2, 12x12 (144, dense path) in stage 3: the geometry of faster_vit_4_21k_384
+    "tiny_21k_384": dict(entry="faster_vit_4_21k_384",
+                         kwargs=dict(depths=[1, 1, 2, 1], num_heads=[1, 1, 2, 4], dim=16, in_dim=16), batch=1, hw=(384, 384),
+                         family="stress", per_block=True,
+                         arch=_arch([1, 1, 2, 1], [1, 1, 2, 4], [7, 7, 24, 12], 16, 384, hat=[False] * 4, prop=True)),
+    # hierarchical any-res stage with 16x16 windows: S = 256 + 4 carrier tokens (n_g = 4 bias-free rows/columns), 2 windows
+    "tiny_anyres_w16": dict(entry="faster_vit_4_any_res",
+                            kwargs=dict(depths=[1, 1, 2, 1], num_heads=[1, 1, 2, 4], dim=16, in_dim=16, resolution=[256, 512],
+                                        window_size=[7, 7, 16, 8], ct_size=2), batch=1, hw=(256, 512), family="stress",
+                            per_block=True,
+                            arch=_arch([1, 1, 2, 1], [1, 1, 2, 4], [7, 7, 16, 8], 16, [256, 512], prop=True, any_res=True)),
 }
 
 SEED = 1234

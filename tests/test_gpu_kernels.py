@@ -83,7 +83,9 @@ def test_gemm_residual(opname, dt, code, M, N, K, use_gamma):
 @pytest.mark.parametrize("opname,dt,code", OPS)
 @pytest.mark.parametrize("S,dpad,d,heads,nwin", [(53, 32, 32, 8, 7), (49, 32, 32, 16, 5), (16, 32, 32, 8, 6), (53, 64, 49, 16, 3),
                                                   (148, 64, 49, 4, 3), (36, 64, 49, 3, 5), (60, 64, 49, 4, 2),
-                                                  (196, 32, 16, 2, 2), (13, 32, 24, 4, 9), (32, 32, 32, 2, 4)])
+                                                  (196, 32, 16, 2, 2), (13, 32, 24, 4, 9), (32, 32, 32, 2, 4),
+                                                  # head_dim 80 (FasterViT-5 / -6) -> padded to 96
+                                                  (53, 96, 80, 4, 3), (49, 96, 80, 2, 5), (16, 96, 80, 2, 6), (128, 96, 72, 2, 2)])
 def test_window_attention(opname, dt, code, S, dpad, d, heads, nwin):
     lib = _lib.lib()
     g = torch.Generator(device="cpu").manual_seed(S * 7 + d)
@@ -112,6 +114,70 @@ def test_window_attention(opname, dt, code, S, dpad, d, heads, nwin):
     assert torch.isfinite(got).all()
     assert (got[..., :d] - ref).abs().max().item() < (4e-3 if dt == torch.float16 else 2.5e-2) * max(ref.abs().max().item(), 1.0)
     assert got[..., d:].abs().max().item() == 0.0 if d < dpad else True
+
+
+def _rel_bias_dense(rel, w, ng, S):
+    """(heads, S, S) bias from the compact table the way the reference gathers it (FV:243-258, 276-299): token ng + y*w + x."""
+    tw = 2 * w - 1
+    pos = torch.arange(w * w)
+    y, x = pos // w, pos % w
+    idx = (y[:, None] - y[None, :] + w - 1) * tw + (x[:, None] - x[None, :] + w - 1)     # [query][key]
+    dense = torch.zeros(rel.shape[0], S, S)
+    dense[:, ng:, ng:] = rel[:, idx.view(-1)].view(-1, w * w, w * w)
+    return dense
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("S,w,dpad,d,heads,nwin", [(256, 16, 32, 32, 4, 3), (260, 16, 64, 49, 3, 2), (580, 24, 64, 49, 2, 1), (209, 14, 32, 32, 2, 5),
+                                                    (1024, 32, 64, 49, 2, 1), (233, 15, 32, 24, 3, 2), (53, 7, 32, 32, 8, 4),
+                                                    (260, 16, 96, 80, 2, 2), (148, 12, 96, 80, 2, 3)])
+def test_window_attention_long(opname, dt, code, S, w, dpad, d, heads, nwin):
+    """Online-softmax attention for long windows: bias looked up arithmetically from the compact (heads, (2w-1)^2) table, n_g = S - w^2
+    leading tokens without bias; vs PyTorch fp32 with the densely gathered bias.  Any S is accepted (the 53-token case cross-checks the
+    short-window kernel's domain)."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(S * 11 + d)
+    ng = S - w * w
+    rows = nwin * S
+    q, k, v = (torch.randn(nwin, heads, S, d, generator=g).to(dt) for _ in range(3))
+    rel = torch.randn(heads, (2 * w - 1) ** 2, generator=g) * 2
+    ldq = 3 * heads * dpad
+    ldo = _rup(heads * dpad, 64)
+    qkv = torch.zeros(_rup(rows, 128), ldq, dtype=dt)
+    for si, t in enumerate((q, k, v)):
+        qkv[:rows].view(nwin, S, 3, heads, dpad)[:, :, si, :, :d] = t.permute(0, 2, 1, 3)
+    qkv, relc = qkv.cuda(), rel.cuda()
+    out = torch.zeros(_rup(rows, 128), ldo, dtype=dt, device="cuda")
+    scale = d ** -0.5
+    rc = lib.fvit_window_attention_long(code, qkv.data_ptr(), ldq, out.data_ptr(), ldo, relc.data_ptr(), w, ng, nwin, S, heads, dpad,
+                                        ctypes.c_float(scale), _stream())
+    _lib.check(rc, "attention_long")
+    torch.cuda.synchronize()
+    att = (q.float() @ k.float().transpose(-1, -2)) * scale + _rel_bias_dense(rel, w, ng, S)
+    ref = att.softmax(-1) @ v.float()
+    got = out[:rows, :heads * dpad].float().cpu().view(nwin, S, heads, dpad).permute(0, 2, 1, 3)
+    assert torch.isfinite(got).all()
+    assert (got[..., :d] - ref).abs().max().item() < (4e-3 if dt == torch.float16 else 2.5e-2) * max(ref.abs().max().item(), 1.0)
+    if d < dpad:
+        assert got[..., d:].abs().max().item() == 0.0
+    # no bias table at all
+    rc = lib.fvit_window_attention_long(code, qkv.data_ptr(), ldq, out.data_ptr(), ldo, None, 0, 0, nwin, S, heads, dpad,
+                                        ctypes.c_float(scale), _stream())
+    _lib.check(rc, "attention_long (no bias)")
+    torch.cuda.synchronize()
+    ref0 = ((q.float() @ k.float().transpose(-1, -2)) * scale).softmax(-1) @ v.float()
+    got0 = out[:rows, :heads * dpad].float().cpu().view(nwin, S, heads, dpad).permute(0, 2, 1, 3)
+    assert (got0[..., :d] - ref0).abs().max().item() < (4e-3 if dt == torch.float16 else 2.5e-2) * max(ref0.abs().max().item(), 1.0)
+
+
+def test_window_attention_long_rejects_bad_geometry():
+    lib = _lib.lib()
+    t = torch.zeros(1024, 192, dtype=torch.float16, device="cuda")
+    rel = torch.zeros(2, 31 * 31, device="cuda")
+    rc = lib.fvit_window_attention_long(1, t.data_ptr(), 192, t.data_ptr(), 64, rel.data_ptr(), 16, 3, 1, 256, 2, 32, ctypes.c_float(1.0), _stream())
+    assert rc != 0 and b"n_g + w^2" in lib.fvit_last_error()
+    rc = lib.fvit_window_attention(1, t.data_ptr(), 192, t.data_ptr(), 64, rel.data_ptr(), 1, 256, 2, 32, ctypes.c_float(1.0), _stream())
+    assert rc != 0 and b"fvit_window_attention_long" in lib.fvit_last_error()
 
 
 @pytest.mark.parametrize("C", [256, 784, 1568, 64, 2560])

@@ -146,6 +146,54 @@ def test_fvit4_224_logits_vs_reference():
     assert err < 1e-3 * max(np.abs(g["logits"]).max(), 1.0)
 
 
+@pytest.mark.parametrize("name", ["fvit4_21k_384", "fvit4_21k_768"])
+def test_fvit4_21k_long_window_logits_vs_reference(name):
+    """faster_vit_4_21k_{384,768}: stage 2 is ONE window of 576 / 2304 tokens per image (stage 3: 144 / 576) -> the online-softmax
+    attention kernel with the compact relative-bias table; logits vs the reference CPU forward on the same weights."""
+    g = load_golden(name)
+    model, _ = build_product_model(name, "cuda")
+    with torch.no_grad():
+        logits = model(case_input(name).cuda()).float().cpu()
+    assert _native_loaded()
+    err = max_abs(logits, g["logits"])
+    print(f"{CASES[name]['entry']} logits max-abs err {err:.3e} (|logits| max {np.abs(g['logits']).max():.3f})")
+    assert err < 1e-3 * max(np.abs(g["logits"]).max(), 1.0)
+
+
+@pytest.mark.parametrize("entry,kwargs,hw", [
+    ("faster_vit_1_224", {}, (224, 224)), ("faster_vit_2_224", {}, (224, 224)), ("faster_vit_3_224", {}, (224, 224)),
+    ("faster_vit_5_224", {}, (224, 224)), ("faster_vit_6_224", {}, (224, 224)),        # head_dim 80 -> 96-wide head padding
+    ("faster_vit_4_21k_224", {}, (224, 224)), ("faster_vit_4_21k_512", {}, (512, 512)),  # stage 2: 1024 tokens, stage 3: 256
+    ("faster_vit_0_any_res", dict(resolution=[200, 312]), (200, 312)),
+    ("faster_vit_4_21k_384_any_res", dict(resolution=[384, 384]), (384, 384))])
+def test_remaining_entrypoints_run_on_the_hip_path(entry, kwargs, hw):
+    """Every variant family of the reference's registry runs through the HIP HAT path (random-init weights, batch 1): finite logits,
+    repeatable, and equal to the CPU oracle on the same weights for the variants small enough to run it here in seconds."""
+    import fastervit_amd
+    torch.manual_seed(0)
+    model = fastervit_amd.create_model(entry, **kwargs).eval()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    x = torch.randn(1, 3, *hw, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        model(x.cuda())  # MIOpen's first call of a conv configuration may pick a different algorithm than the later ones
+        a = model(x.cuda()).float().cpu()
+        b = model(x.cuda()).float().cpu()
+    assert _native_loaded()
+    assert a.shape == (1, 1000) and torch.isfinite(a).all()
+    assert max_abs(a, b) <= 1e-4 * max(a.abs().max().item(), 1.0)
+    if entry in ("faster_vit_1_224", "faster_vit_2_224", "faster_vit_0_any_res"):
+        from fastervit_amd.models.faster_vit import _ARCH
+        v = entry.split("_")[2]
+        arch = dict(depths=_ARCH[v]["depths"], num_heads=_ARCH[v]["num_heads"], window_size=_ARCH[v]["window_size"], ct_size=2,
+                    dim=_ARCH[v]["dim"], resolution=kwargs.get("resolution", 224), hat=_ARCH[v]["hat"], do_propagation=_ARCH[v]["ls"],
+                    layer_norm_last=False, any_res=entry.endswith("any_res"))
+        ref = model_forward(sd, x, arch)
+        err = max_abs(a, ref)
+        print(f"{entry} logits max-abs err vs CPU oracle {err:.3e} (|logits| max {ref.abs().max().item():.3f})")
+        assert err < 2e-3 * max(ref.abs().max().item(), 1.0)
+
+
 def test_fvit4_anyres_576x960_logits_vs_reference():
     """faster_vit_4_any_res 576x960, ws [7,7,12,6], ct 2: non-square carrier grid (G = 60, S = 148)."""
     g = load_golden("fvit4_anyres_576x960")
@@ -186,7 +234,8 @@ def test_oracle_on_gpu_box_matches_goldens():
     assert max_abs(logits, g["logits"]) < 2e-4 * np.abs(g["logits"]).max()
 
 
-@pytest.mark.parametrize("name,tol", [("fvit0_224", 4e-3), ("tiny_hier", None), ("tiny_anyres", None), ("tiny_w14", None)])
+@pytest.mark.parametrize("name,tol", [("fvit0_224", 4e-3), ("tiny_hier", None), ("tiny_anyres", None), ("tiny_w14", None),
+                                      ("tiny_21k_384", None), ("tiny_anyres_w16", None)])
 def test_deploy_mode_vs_reference(name, tol):
     """switch_to_deploy(): BN folded into the convs, fp16 channels_last conv side, fused glue kernels."""
     g = load_golden(name)

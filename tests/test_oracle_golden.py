@@ -15,7 +15,7 @@ from tests.util import GOLDEN_DIR, build_product_model, case_input, load_golden,
 
 TINY = [n for n, c in CASES.items() if c["per_block"]]
 FULL_FAST = ["fvit0_224", "fvit0_224_stress"]
-FULL_SLOW = ["fvit4_224", "fvit4_anyres_576x960"]
+FULL_SLOW = ["fvit4_224", "fvit4_anyres_576x960", "fvit4_21k_384"]
 
 
 def _digest(sd):
