@@ -257,7 +257,9 @@ def test_errors_are_reported_not_swallowed():
     with pytest.raises(RuntimeError, match="gemm"):
         _lib.check(rc, "gemm")
     rc = lib.fvit_window_attention(1, None, 96, None, 64, None, 1, 300, 1, 32, ctypes.c_float(1.0), _stream())
-    assert rc == -1 and b"no kernel instance" in lib.fvit_last_error()
+    assert rc == -1 and b"fvit_window_attention_long" in lib.fvit_last_error()
+    rc = lib.fvit_window_attention(1, None, 96, None, 64, None, 1, 64, 1, 48, ctypes.c_float(1.0), _stream())   # dpad must be 32 / 64 / 96
+    assert rc == -1 and b"unsupported geometry" in lib.fvit_last_error()
 
 
 @pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
