@@ -212,7 +212,7 @@ def main():
     # ---- CPU baseline: the oracle (port of the reference fp32 CPU path) on a bounded sample ----
     cpu = None
     parity = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0's host cores are shared with the other ranks otherwise)
         from oracle.model_reference import model_forward
         from tests.cases import CASES
         arch = dict(CASES["fvit0_224"]["arch"]) if args.model == "faster_vit_0_224" else None
