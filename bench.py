@@ -188,16 +188,21 @@ def main():
                     "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
                 for k, v in pr.items() if v["launches"]}
 
-    # ---- roofline of the dominant HAT kernel: live HIP-event timing of every launch (eager pass, same stream-shard
-    # configuration as the timed region: launches are shard-sized and overlap with the other shards' kernels) ----
+    # ---- roofline of the dominant HAT kernel: live HIP-event timing of every launch in an eager pass with the SAME launches as
+    # the timed region (shard-sized), the shards issued one after the other on one stream: an event pair then brackets one
+    # kernel alone on the GPU -- the regime rocprofv3 --kernel-trace measures too (it serialises dispatches), so the two agree ----
+    plan = model.__dict__.get("_deploy_plan")
+    if plan is not None:
+        plan.serialize_shards = True
     prof = profile_pass()
+    if plan is not None:
+        plan.serialize_shards = False
     hat_ms = sum(e["ms"] for k, e in prof.items() if k not in ("other", "conv3x3")) / args.prof_steps
     dom, roofline = roofline_of(prof)
     roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, deploy and args.streams == 3)
     kernels = kernel_table(prof)
     # ---- the same kernels with the GPU to themselves: one stream, whole-batch launches (kernel quality, not job throughput) ----
     roofline_isolated = None
-    plan = model.__dict__.get("_deploy_plan")
     if plan is not None and getattr(plan, "streams", 1) > 1:
         shards = plan.streams
         plan.streams = 1

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
 class FvitStageDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "batch", "C", "heads", "dpad", "ws", "H", "W", "Hp", "Wp", "cw", "hier", "square", "hidden",
-        "depth", "do_propagation", "operand_dtype", "spad", "gpad")]
+        "depth", "do_propagation", "operand_dtype", "spad", "gpad")] + [("qk_scale", C.c_float)]
 
 
 class FvitAttnWeights(C.Structure):

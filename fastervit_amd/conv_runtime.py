@@ -193,11 +193,19 @@ class DeployPlan:
         # the batch as n independent shards on n HIP streams (fork / join with events; capturable in a hipGraph): every kernel
         # of this pipeline runs its HBM-bound prologue / epilogue and its MFMA phase in lockstep across workgroups, so two
         # half-size pipelines interleave better than one full-size one
+        parts = x.chunk(n, dim=0)
+        outs = [None] * n
+        if getattr(self, "serialize_shards", False):
+            # measurement aid (bench.py's HIP-event pass): the same shard-sized launches, one after the other on the caller's
+            # stream, so that a kernel's event-pair duration is its own and not shared with the other shards' kernels
+            for i in range(n):
+                hat_runtime.set_workspace_slot(i)
+                outs[i] = self._forward_one(parts[i])
+            hat_runtime.set_workspace_slot(0)
+            return torch.cat(outs, dim=0)
         if self.side is None or len(self.side) != n - 1:
             self.side = [torch.cuda.Stream(device=x.device) for _ in range(n - 1)]
         main = torch.cuda.current_stream()
-        parts = x.chunk(n, dim=0)
-        outs = [None] * n
         for i, s in enumerate(self.side):
             s.wait_stream(main)
             with torch.cuda.stream(s):

@@ -160,7 +160,7 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
     }
     GemmCall g1 = {dt, xn, L.ldn, w.w_qkv, L.ldn, w.b_qkv, nullptr, qkv, L.ldqkv, (int)rows, L.ldqkv, L.ldn, 0};
     FVIT_TRY(launch_gemm(g1, st));
-    const float scale = 1.0f / sqrtf((float)(d.C / d.heads));
+    const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
     AttnCall at = {dt, qkv, L.ldqkv, ao, L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale, w.rel_table, w.rel_w, w.rel_ng};
     FVIT_TRY(launch_attention(at, st));
     GemmCall g2 = {dt, ao, L.ldao, w.w_proj, L.ldao, w.b_proj, w.gamma, x, d.C, (int)rows, d.C, L.ldao, 2};
@@ -210,7 +210,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         void* RQKV = ws + L.off_RQKV;
         void* RAO = ws + L.off_RAO;
         void* RH = ws + L.off_RH;
-        const float scale = 1.0f / sqrtf((float)(d.C / d.heads));
+        const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
         if (fused_attn_ok(d, w.hat_attn, L.G, L.Mc)) {
             // ct_dewindow gather (+ hat_pos_embed), LN, qkv, attention over the G carrier tokens, proj, gamma1-residual -> R
             AttnBlkCall ab = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), w.hat_attn.ln_w, w.hat_attn.ln_b,
@@ -228,7 +228,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
     }
     if (fused_attn_ok(d, w.attn, L.S, L.Mx)) {
         // cat(ct_window(ct), x + pos_embed) gather, LN(norm1), qkv, window attention, proj, gamma3-residual -> X, one kernel
-        const float scale = 1.0f / sqrtf((float)(d.C / d.heads));
+        const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
         AttnBlkCall ab = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, w.attn.ln_w, w.attn.ln_b, 1e-5f, rpi,
                           w.attn.w_qkv_frag, w.attn.b_qkv_heads, w.attn.w_proj_frag, w.attn.b_proj, w.attn.gamma, w.attn.bias, X,
                           d.batch * L.nW, L.S, d.heads, d.C, scale};

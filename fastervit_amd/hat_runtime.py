@@ -298,7 +298,8 @@ def _prepare(layer, x_dev, Hp: int, Wp: int):
     desc_common = dict(C=Cdim, heads=heads, dpad=dpad, ws=ws, Hp=Hp, Wp=Wp, cw=cw if hier else 0, hier=int(hier),
                        square=int(hier and hasattr(blk0, "hat_pos_embed")), hidden=blk0.mlp.fc1.out_features,
                        depth=len(layer.blocks), do_propagation=int(bool(blk0.do_propagation)), operand_dtype=op_code,
-                       spad=lib.fvit_attention_spad(tb["S"]), gpad=lib.fvit_attention_spad(tb["G"]) if hier else 0)
+                       spad=lib.fvit_attention_spad(tb["S"]), gpad=lib.fvit_attention_spad(tb["G"]) if hier else 0,
+                       qk_scale=float(blk0.attn.scale))
     return st, tb, ctables, desc_common
 
 

@@ -260,11 +260,9 @@ class WindowAttention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., resolution=0,
                  seq_length=0):
         super().__init__()
-        if qk_scale is not None:
-            raise NotImplementedError("qk_scale override is not supported by the HIP attention kernel")
         self.num_heads = num_heads
         self.head_dim = dim // num_heads
-        self.scale = self.head_dim ** -0.5
+        self.scale = qk_scale or self.head_dim ** -0.5   # FV:538; reaches the kernels through FvitStageDesc.qk_scale
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)

@@ -74,6 +74,7 @@ typedef struct FvitStageDesc {
     int32_t operand_dtype;  /* FVIT_F16 or FVIT_BF16: MFMA operand type of packed weights */
     int32_t spad;           /* window sequence (ws^2 + cw^2) padded to a multiple of 16 */
     int32_t gpad;           /* carrier sequence G = cw^2 * nW padded to a multiple of 16 (hier) */
+    float qk_scale;         /* score scale of attn and hat_attn; <= 0 selects head_dim^-0.5 (FV:538 `qk_scale or head_dim ** -0.5`) */
 } FvitStageDesc;
 
 /* One attention sub-block: LayerNorm -> qkv -> softmax(q k^T * scale + bias) v -> proj -> gamma-residual.

@@ -126,15 +126,15 @@ def attn_bias(sd: SD, prefix: str, res: int, heads: int, S: int, dtype) -> Tenso
 # --------------------------------------------------------------------------------------------
 # a-8, a-9, a-10
 # --------------------------------------------------------------------------------------------
-def window_attention(x: Tensor, sd: SD, prefix: str, heads: int, res: int) -> Tensor:
-    """WindowAttention.forward (AR:558-569 / FV:557-568).  x: (Bw, S, C)."""
+def window_attention(x: Tensor, sd: SD, prefix: str, heads: int, res: int, qk_scale: Optional[float] = None) -> Tensor:
+    """WindowAttention.forward (AR:558-569 / FV:557-568).  x: (Bw, S, C).  scale = qk_scale or head_dim ** -0.5 (FV:538)."""
     dtype = x.dtype
     Bw, S, C = x.shape
     d = C // heads
     qkv = F.linear(x, sd[prefix + "qkv.weight"].to(dtype), sd[prefix + "qkv.bias"].to(dtype))
     qkv = qkv.reshape(Bw, -1, 3, heads, d).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    attn = (q @ k.transpose(-2, -1)) * (d ** -0.5)
+    attn = (q @ k.transpose(-2, -1)) * (qk_scale or d ** -0.5)
     attn = attn + attn_bias(sd, prefix + "pos_emb_funct.", res, heads, S, dtype).unsqueeze(0)
     attn = attn.softmax(dim=-1)
     out = (attn @ v).transpose(1, 2).reshape(Bw, -1, C)
@@ -163,7 +163,7 @@ def _gamma(sd: SD, key: str, dtype):
 # a-11: HAT.forward
 # --------------------------------------------------------------------------------------------
 def hat_block(x: Tensor, ct: Optional[Tensor], sd: SD, prefix: str, *, heads: int, ws: int, cw: int,
-              sr: Tuple[int, int], last: bool, do_propagation: bool) -> Tuple[Tensor, Optional[Tensor]]:
+              sr: Tuple[int, int], last: bool, do_propagation: bool, qk_scale: Optional[float] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """HAT.forward (AR:668-707 / FV:662-701).  x: (B*nW, ws^2, C); ct: (B, G, C) or None."""
     dtype = x.dtype
     Bw, T, C = x.shape
@@ -178,14 +178,14 @@ def hat_block(x: Tensor, ct: Optional[Tensor], sd: SD, prefix: str, *, heads: in
         g1 = _gamma(sd, prefix + "gamma1", dtype)
         g2 = _gamma(sd, prefix + "gamma2", dtype)
         res_ct = int((cw * cw * sr[0] * sr[1]) ** 0.5)
-        ct = ct + g1 * window_attention(layer_norm(ct, sd, prefix + "hat_norm1."), sd, prefix + "hat_attn.", heads, res_ct)
+        ct = ct + g1 * window_attention(layer_norm(ct, sd, prefix + "hat_norm1."), sd, prefix + "hat_attn.", heads, res_ct, qk_scale)
         ct = ct + g2 * mlp(layer_norm(ct, sd, prefix + "hat_norm2."), sd, prefix + "hat_mlp.")
         ct = ct_window(ct, cw * sr[0], cw * sr[1], cw)
         ct = ct.reshape(Bw, -1, C)
         x = torch.cat((ct, x), dim=1)
     g3 = _gamma(sd, prefix + "gamma3", dtype)
     g4 = _gamma(sd, prefix + "gamma4", dtype)
-    x = x + g3 * window_attention(layer_norm(x, sd, prefix + "norm1."), sd, prefix + "attn.", heads, ws)
+    x = x + g3 * window_attention(layer_norm(x, sd, prefix + "norm1."), sd, prefix + "attn.", heads, ws, qk_scale)
     x = x + g4 * mlp(layer_norm(x, sd, prefix + "norm2."), sd, prefix + "mlp.")
     if do_sr_hat:
         ctr, x = x.split([x.shape[1] - ws * ws, ws * ws], dim=1)
@@ -224,7 +224,7 @@ def padded_resolution(res: Sequence[int], ws: int) -> Tuple[int, int]:
 
 def hat_stage(x: Tensor, sd: SD, prefix: str, *, depth: int, heads: int, ws: int, cw: int,
               input_resolution: Sequence[int], only_local: bool, do_propagation: bool,
-              any_res: bool = True, capture: Optional[list] = None) -> Tensor:
+              any_res: bool = True, capture: Optional[list] = None, qk_scale: Optional[float] = None) -> Tensor:
     """Transformer branch of FasterViTLayer.forward WITHOUT the Downsample (AR:848-869 / FV:832-841).
 
     ``any_res`` False applies the base-file rule for the tokenizer (FV:821: needs
@@ -247,7 +247,7 @@ def hat_stage(x: Tensor, sd: SD, prefix: str, *, depth: int, heads: int, ws: int
     x = window_partition(x, ws)
     for i in range(depth):
         x, ct = hat_block(x, ct, sd, f"{prefix}blocks.{i}.", heads=heads, ws=ws, cw=cw, sr=sr,
-                          last=(i == depth - 1), do_propagation=do_propagation)
+                          last=(i == depth - 1), do_propagation=do_propagation, qk_scale=qk_scale)
         if capture is not None:
             capture.append((x.clone(), None if ct is None else ct.clone()))
     x = window_reverse(x, ws, Hp, Wp, B)

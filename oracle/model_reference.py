@@ -84,7 +84,7 @@ def model_forward(sd: SD, x: Tensor, arch: dict, dtype=torch.float32,
                 cw=arch["ct_size"],
                 input_resolution=[int(2 ** (-2 - i) * res[0]), int(2 ** (-2 - i) * res[1])],
                 only_local=not arch["hat"][i], do_propagation=arch.get("do_propagation", False),
-                any_res=arch.get("any_res", False), capture=cap)
+                any_res=arch.get("any_res", False), capture=cap, qk_scale=arch.get("qk_scale"))
             if capture is not None:
                 capture[f"blocks{i}"] = cap
         if capture is not None:

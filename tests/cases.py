@@ -8,9 +8,9 @@ Hyper-parameters of the named variants follow the reference entrypoints (FV:975-
 _H = [False, False, True, False]
 
 
-def _arch(depths, heads, ws, dim, res, hat=_H, prop=False, any_res=False, ct=2):
+def _arch(depths, heads, ws, dim, res, hat=_H, prop=False, any_res=False, ct=2, qk_scale=None):
     return dict(depths=depths, num_heads=heads, window_size=ws, ct_size=ct, dim=dim, resolution=res, hat=hat,
-                do_propagation=prop, layer_norm_last=False, any_res=any_res)
+                do_propagation=prop, layer_norm_last=False, any_res=any_res, qk_scale=qk_scale)
 
 
 CASES = {
@@ -60,6 +60,11 @@ CASES = {
                      kwargs=dict(depths=[1, 1, 2, 1], num_heads=[1, 1, 1, 2], dim=20, in_dim=16), batch=2, hw=(224, 224),
                      family="stress", per_block=True,
                      arch=_arch([1, 1, 2, 1], [1, 1, 1, 2], [7, 7, 7, 7], 20, 224, prop=True)),
+    # qk_scale override (pass-through kwarg of every entrypoint, FV:538), head_dim 32
+    "tiny_qk": dict(entry="faster_vit_0_224",
+                    kwargs=dict(depths=[1, 1, 2, 1], num_heads=[1, 1, 2, 4], dim=16, in_dim=16, qk_scale=0.31), batch=2, hw=(224, 224),
+                    family="stress", per_block=True,
+                    arch=_arch([1, 1, 2, 1], [1, 1, 2, 4], [7, 7, 7, 7], 16, 224, qk_scale=0.31)),
     # ---- long windows (> 208 tokens): the online-softmax attention kernel with the compact relative-bias table ----
     # one 24x24 window (576 tokens) in stage 2, 12x12 (144, dense path) in stage 3: the geometry of faster_vit_4_21k_384
     "tiny_21k_384": dict(entry="faster_vit_4_21k_384",

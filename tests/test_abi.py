@@ -32,7 +32,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_abi_version_and_struct_sizes(lib):
     assert lib.fvit_abi_version() == _lib.FVIT_ABI_VERSION
-    assert ctypes.sizeof(_lib.FvitStageDesc) == 18 * 4
+    assert ctypes.sizeof(_lib.FvitStageDesc) == 19 * 4
     assert ctypes.sizeof(_lib.FvitAttnWeights) == 12 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.FvitMlpWeights) == 9 * 8
     assert ctypes.sizeof(_lib.FvitBlockWeights) == 2 * 104 + 2 * 72 + 16 + 8
