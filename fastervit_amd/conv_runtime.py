@@ -180,12 +180,20 @@ class DeployPlan:
 
     # ---- forward -------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, x):
+    def _refresh(self):
         sig = self._signature()
         if sig != self.sig:
             with torch.autocast(device_type="cuda", enabled=False):
                 self._build()
             self.sig = sig
+
+    def forward_single(self, x):
+        """One shard on the caller's stream and current workspace slot (no sharding)."""
+        self._refresh()
+        return self._forward_one(x)
+
+    def forward(self, x):
+        self._refresh()
         n = self.streams
         if n <= 1 or x.shape[0] < 2 * n:
             hat_runtime.set_workspace_slot(0)
@@ -216,6 +224,10 @@ class DeployPlan:
         for s in self.side:
             main.wait_stream(s)
         return torch.cat(outs, dim=0)
+
+    def shard_runner(self, x, n=None):
+        """Free-running stream shards for throughput serving: see ``ShardRunner``."""
+        return ShardRunner(self, x, n or max(self.streams, 1))
 
     def _forward_one(self, x):
         t = self.t
@@ -248,3 +260,55 @@ class DeployPlan:
                 x = self._ln2d(x, *ln)
             feat = x.float().mean(dim=(2, 3))
             return F.linear(feat, hw, hb)
+
+
+class ShardRunner:
+    """Throughput driver for steady-state inference: the batch is split into n shards, each shard's whole forward is captured in its
+    OWN hipGraph on its OWN stream, and ``launch()`` enqueues one replay per stream without any fork / join between steps.
+
+    ``DeployPlan.forward`` (fork / join inside one graph) starts all shards of a step together and ends the step when the slowest
+    is done, so the shards walk through the network in lockstep: three stems, then three level-0 conv stacks, ..., then three
+    carrier-token branches (22 workgroups each) at the same time.  Independent per-stream graphs let consecutive steps of different
+    shards overlap: the streams drift apart and an underfilled phase of one shard (carrier branch, stage 3) runs beside a
+    chip-filling phase of another (convs).  Images are independent, so there is no data hazard; ``wait()`` joins all streams.
+    Results of the LAST launch are in ``outputs()`` (static buffers, as with any graph replay)."""
+
+    def __init__(self, plan, x, n):
+        self.plan = plan
+        self.n = n = max(1, min(int(n), x.shape[0]))
+        self.streams = [torch.cuda.Stream(device=x.device) for _ in range(n)]
+        self.inputs = [p.clone() for p in x.chunk(n, dim=0)]
+        self.graphs, self.outs = [], []
+        torch.cuda.synchronize()
+        for i, (st, xi) in enumerate(zip(self.streams, self.inputs)):
+            with torch.cuda.stream(st), torch.no_grad():
+                hat_runtime.set_workspace_slot(i)
+                for _ in range(2):           # warm-up on this stream: packs weights, sizes this slot's workspaces
+                    plan.forward_single(xi)
+            st.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g, stream=st):
+                hat_runtime.set_workspace_slot(i)
+                y = plan.forward_single(xi)
+            self.graphs.append(g)
+            self.outs.append(y)
+        hat_runtime.set_workspace_slot(0)
+        torch.cuda.synchronize()
+
+    def set_input(self, x):
+        for dst, src in zip(self.inputs, x.chunk(self.n, dim=0)):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+
+    def launch(self):
+        for st, g in zip(self.streams, self.graphs):
+            with torch.cuda.stream(st):
+                g.replay()
+
+    def wait(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def outputs(self):
+        self.wait()
+        return torch.cat(self.outs, dim=0)
