@@ -49,8 +49,8 @@ def parse():
     ap.add_argument("--shard-launch", choices=["free", "forkjoin"], default="forkjoin",
                     help="deploy mode with --streams > 1: 'free' = one hipGraph per shard on its own stream, replayed back to back with no "
                          "join between steps (streams drift apart, consecutive steps overlap); 'forkjoin' = one graph per step that "
-                         "forks the shards and joins them (model.forward semantics; measured faster: 62.9k vs 44.9k / 62.5k / 60.0k img/s for free-running 3 / 2 / 4 streams, '
-                         'profiles/r01_shard_launch_sweep.log)")
+                         "forks the shards and joins them (model.forward semantics; measured faster: 62.9k vs 44.9k / 62.5k / 60.0k img/s for free-running "
+                         "3 / 2 / 4 streams, profiles/r01_shard_launch_sweep.log)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--prof-steps", type=int, default=3)
