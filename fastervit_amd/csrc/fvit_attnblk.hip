@@ -135,16 +135,20 @@ __global__ __launch_bounds__(64 * NW, 2) void attnblk_kernel(AttnBlkParams p) {
             if (ai >= 0) addp = p.add + (size_t)ai * C;
         }
     }
+    // GEMM k slot kk*32 + 8g + e carries input channel kch(kk, g, e) = (kk>>1)*64 + g*16 + (kk&1)*8 + e (w_qkv_frag is packed in
+    // that order): the 64 values a lane gathers are then exactly the 64 output channels it owns in the proj accumulator, and
+    // the residual epilogue uses them from registers instead of gathering the row a second time
     v8 xf[KK];
+    f4 v[KK][2];
     {
-        f4 v[KK][2];
         float sum = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                f4 t = *(const f4*)(src + kk * 32 + g * 8 + h2 * 4);
-                if (addp) t += *(const f4*)(addp + kk * 32 + g * 8 + h2 * 4);
+                const int co = (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 + h2 * 4;
+                f4 t = *(const f4*)(src + co);
+                if (addp) t += *(const f4*)(addp + co);
                 v[kk][h2] = t;
                 sum += (t[0] + t[1]) + (t[2] + t[3]);
             }
@@ -167,8 +171,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attnblk_kernel(AttnBlkParams p) {
             v8 o;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                const f4 w = *(const f4*)(p.ln_w + kk * 32 + g * 8 + h2 * 4);
-                const f4 b = *(const f4*)(p.ln_b + kk * 32 + g * 8 + h2 * 4);
+                const int co = (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 + h2 * 4;
+                const f4 w = *(const f4*)(p.ln_w + co);
+                const f4 b = *(const f4*)(p.ln_b + co);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)((v[kk][h2][r] - mean) * rstd * w[r] + b[r]);
             }
@@ -315,8 +320,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attnblk_kernel(AttnBlkParams p) {
             const int c0 = cg * 64 + g * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f4 xv = *(const f4*)(src + c0 + q * 4);
-                if (addp) xv += *(const f4*)(addp + c0 + q * 4);
+                f4 xv = v[2 * cg + (q >> 1)][q & 1];   // channel c0 + 4q = kch(2cg + (q>>1), g, 4(q&1)): the gathered row, still in registers
                 const f4 bv = *(const f4*)(p.bproj + c0 + q * 4);
                 const f4 gv = p.gamma ? *(const f4*)(p.gamma + c0 + q * 4) : (f4){1.f, 1.f, 1.f, 1.f};
                 const f4 a = oacc[cg * 4 + q];

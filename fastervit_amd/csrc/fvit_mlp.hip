@@ -55,7 +55,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 // one fragment = 64 lanes x 16 bytes = 1 KiB = one global_load_lds instruction = one conflict-free
 // lane-linear ds_read_b128.  The HBM image of a 32-unit chunk IS its LDS image: staging is a linear copy and
 // every fragment address is (buffer base + lane*16 + compile-time immediate) -- one address register.
-template <typename T, int C, int RB, int NW, int MINW>
+// KEEPX: keep the fp32 input rows in registers for the residual epilogue instead of re-reading X (a third of the kernel's HBM
+// traffic).  It works because the k-slot order of GEMM1 is free: k slot (kk, g, e) is mapped to channel
+//     kch(kk, g, e) = (kk>>1)*64 + g*16 + (kk&1)*8 + e
+// (w_fc1_frag is packed in that order), so the 64 input values a lane loads per row are exactly the 64 output channels it owns
+// in GEMM2's accumulator layout (fragment cb, slot 4g + r <-> channel (cb>>2)*64 + 16g + (cb&3)*4 + r).
+template <typename T, int C, int RB, int NW, int MINW, bool KEEPX>
 __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
     constexpr int NBUF = 2;
     typedef typename Op16<T>::v8 v8;
@@ -98,18 +103,19 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
     stage(chunk_of(0), smem);
 
     // ---- LayerNorm of this wave's rows straight into B-operand fragments ----
-    // lane (g, s) holds channels kk*32 + g*8 .. +8 (kk = 0..KK-1) of row rb*16 + s
+    // lane (g, s) holds channels kch(kk, g, 0..7) = (kk>>1)*64 + g*16 + (kk&1)*8 .. +8 (kk = 0..KK-1) of row rb*16 + s
     v8 xf[RB][KK];
+    f4 xk[KEEPX ? RB : 1][KK][2];   // KEEPX: the fp32 rows, alive until the epilogue
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int row = min(row0 + rb * 16 + s, p.M - 1);  // tail rows recompute the last row; never stored
-        const float* xr = p.x + (size_t)row * C + g * 8;
-        f4 v[KK][2];
+        const float* xr = p.x + (size_t)row * C + g * 16;
+        f4 (&v)[KK][2] = xk[KEEPX ? rb : 0];
         float sum = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            v[kk][0] = *(const f4*)(xr + kk * 32);
-            v[kk][1] = *(const f4*)(xr + kk * 32 + 4);
+            v[kk][0] = *(const f4*)(xr + (kk >> 1) * 64 + (kk & 1) * 8);
+            v[kk][1] = *(const f4*)(xr + (kk >> 1) * 64 + (kk & 1) * 8 + 4);
             sum += (v[kk][0][0] + v[kk][0][1]) + (v[kk][0][2] + v[kk][0][3]) + (v[kk][1][0] + v[kk][1][1]) + (v[kk][1][2] + v[kk][1][3]);
         }
         sum += __shfl_xor(sum, 16);
@@ -128,8 +134,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
         const float rstd = rsqrtf(sq / (float)C + p.eps);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            const float* lw = p.ln_w + kk * 32 + g * 8;
-            const float* lb = p.ln_b + kk * 32 + g * 8;
+            const float* lw = p.ln_w + (kk >> 1) * 64 + g * 16 + (kk & 1) * 8;
+            const float* lb = p.ln_b + (kk >> 1) * 64 + g * 16 + (kk & 1) * 8;
             v8 o;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -211,7 +217,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
                 for (int q = 0; q < 4; ++q) {
                     const f4 bv = *(const f4*)(p.b2 + c0 + q * 4);
                     const f4 gv = p.gamma ? *(const f4*)(p.gamma + c0 + q * 4) : (f4){1.f, 1.f, 1.f, 1.f};
-                    f4 xv = *(f4*)(px + q * 4);
+                    f4 xv;
+                    if (KEEPX) xv = xk[KEEPX ? rb : 0][2 * cg + (q >> 1)][q & 1];
+                    else xv = *(f4*)(px + q * 4);
                     const f4 a = acc2[cg * 4 + q][rb];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xv[r] += gv[r] * (a[r] + bv[r]);
@@ -233,13 +241,18 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
     ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
     if (c.C == 256) {
-        // variants for within-process A/B (fvit_tune "mlp_variant"); 0 is the default
-        switch (tune_get("mlp_variant", 0)) {
-            case 1: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p); break;
-            case 2: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 8, 2>), dim3((c.M + 127) / 128), dim3(512), 0, stream, p); break;
-            case 3: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 1>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;
-            case 4: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 8, 2>), dim3((c.M + 255) / 256), dim3(512), 0, stream, p); break;
-            default: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;
+        // variants for within-process A/B (fvit_tune "mlp_variant"); 0 (16 rows per wave, input rows kept in registers) is the default;
+        // 3 = the r01 v1-v10 default (32 rows per wave, X re-read in the epilogue)
+        int variant = tune_get("mlp_variant", -1);
+        // auto: 32 rows per wave (half the weight traffic per row) once 128-row workgroups fill the chip with two per CU, else 16 rows per
+        // wave with the input rows kept in registers (M = 54272: 96-107 vs 117-134 us; M = 18020: 72-74 vs 58-59 us, r01 sweep r27)
+        if (variant < 0) variant = (c.M + 127) / 128 >= 400 ? 3 : 0;
+        switch (variant) {
+            case 2: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 8, 2, true>), dim3((c.M + 127) / 128), dim3(512), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2, false>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;
+            case 4: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, false>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p); break;
+            case 5: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2, true>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;  // spills
+            default: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, true>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p); break;
         }
     } else {
         set_error("mlp_fused: C=%d has no fused instance", c.C);

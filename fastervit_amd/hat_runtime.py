@@ -159,8 +159,9 @@ def pack_attention(attn, norm, gamma, S: int, dpad: int, op_dtype, keep: _Keep) 
 
 def frag_pack_qkv(wqkv: torch.Tensor, heads: int) -> torch.Tensor:
     """qkv.weight (3C, C), head_dim 32 -> [heads][6][C/32][64][8] (include/fvit_hip.h: w_qkv_frag): element e of lane 16g + s of
-    fragment (head, ub, kk) = wqkv[(ub>>1)*C + head*32 + (ub&1)*16 + s][kk*32 + 8g + e]."""
+    fragment (head, ub, kk) = wqkv[(ub>>1)*C + head*32 + (ub&1)*16 + s][kch(kk, g, e)] (kslot_channels)."""
     C3, C_ = wqkv.shape
+    wqkv = wqkv[:, kslot_channels(C_, wqkv.device)]
     t = wqkv.view(3, heads, 2, 16, C_ // 32, 4, 8)          # sec, head, half, s, kk, g, e
     t = t.permute(1, 0, 2, 4, 5, 3, 6).contiguous()          # head, sec, half, kk, g, s, e
     return t.view(heads, 6, C_ // 32, 64, 8)
@@ -184,10 +185,19 @@ def pack_mlp(mlp, norm, gamma, op_dtype, keep: _Keep) -> FvitMlpWeights:
                           keep.ptr(_gamma(gamma)), keep.ptr(w1f, True), keep.ptr(w2f, True))
 
 
+def kslot_channels(C_: int, device=None) -> torch.Tensor:
+    """Input channel of GEMM k slot kk*32 + 8g + e in the fused kernels: kch = (kk>>1)*64 + g*16 + (kk&1)*8 + e.  With this order the
+    64 input values a lane loads per row are the 64 output channels it owns in the epilogue, so the residual needs no re-read of X."""
+    k = torch.arange(C_, device=device)
+    kk, g, e = k >> 5, (k >> 3) & 3, k & 7
+    return (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 + e
+
+
 def frag_pack_fc1(w1: torch.Tensor) -> torch.Tensor:
     """fc1.weight (hidden, C) -> [hidden/32][2][C/32][64][8] in MFMA A-fragment order (include/fvit_hip.h: w_fc1_frag):
-    element e of lane 16g + s of fragment (j, hb, kk) = w1[j*32 + hb*16 + s][kk*32 + 8g + e]."""
+    element e of lane 16g + s of fragment (j, hb, kk) = w1[j*32 + hb*16 + s][kch(kk, g, e)] (kslot_channels)."""
     hid, C_ = w1.shape
+    w1 = w1[:, kslot_channels(C_, w1.device)]
     t = w1.view(hid // 32, 2, 16, C_ // 32, 4, 8)       # j, hb, s, kk, g, e
     return t.permute(0, 1, 3, 4, 2, 5).contiguous()      # j, hb, kk, g, s, e
 

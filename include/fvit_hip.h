@@ -91,7 +91,7 @@ typedef struct FvitAttnWeights {
     const float* gamma;  /* f32  [C] or NULL (layer_scale None => 1) */
     /* Optional (all NULL => unfused path): MFMA-fragment-order weights for the fused attention block kernel
      * (csrc/fvit_attnblk.hip; needs C == 256, head_dim == 32).  lane = 16*g + s, e = 0..7:
-     *   w_qkv_frag [h][6 (q0 q1 k0 k1 v0 v1)][C/32 (kk)][64][8]: qkv.weight[(ub>>1)*C + head*32 + (ub&1)*16 + s][kk*32 + 8g + e]
+     *   w_qkv_frag [h][6 (q0 q1 k0 k1 v0 v1)][C/32 (kk)][64][8]: qkv.weight[(ub>>1)*C + head*32 + (ub&1)*16 + s][kch(kk, g, e)]  (kch as in w_fc1_frag)
      *   b_qkv_heads f32 [h][96]: qkv.bias re-ordered per head [q 32 | k 32 | v 32]
      *   w_proj_frag [h][C/16 (cb)][64][8]: proj.weight[ch(cb, s)][head*32 + (e>>2)*16 + 4g + (e&3)], ch as in w_fc2_frag */
     const void* w_qkv_frag;
@@ -117,7 +117,8 @@ typedef struct FvitMlpWeights {
     const float* gamma;  /* f32 [C] or NULL */
     /* Optional (both NULL => unfused path): weights pre-packed in MFMA fragment order for the fused MLP kernel
      * (csrc/fvit_mlp.hip).  One fragment = 64 lanes x 8 elements (1 KiB); lane = 16*g + s (g = 0..3, s = 0..15), e = 0..7:
-     *   w_fc1_frag [hidden/32][2 (hb)][C/32 (kk)][64][8]:  fc1.weight[j*32 + hb*16 + s][kk*32 + 8g + e]
+     *   w_fc1_frag [hidden/32][2 (hb)][C/32 (kk)][64][8]:  fc1.weight[j*32 + hb*16 + s][kch(kk, g, e)],
+     *                                                       kch(kk, g, e) = (kk>>1)*64 + g*16 + (kk&1)*8 + e  (input channel of k slot kk*32 + 8g + e)
      *   w_fc2_frag [hidden/32][C/16 (cb)][64][8]:          fc2.weight[ch(cb, s)][j*32 + (e>>2)*16 + 4g + (e&3)]
      *                                                       ch(cb, s) = (cb>>2)*64 + (s>>2)*16 + (cb&3)*4 + (s&3)
      * (the k-slot order of w_fc2_frag is the order in which GELU(fc1) leaves the first MFMA's accumulator) */
