@@ -128,7 +128,7 @@ def _declare(lib):
     lib.fvit_bias_residual_cl.restype = C.c_int
     lib.fvit_bias_residual_cl.argtypes = [i32, vp, vp, vp, C.c_int64, i32, vp]
     lib.fvit_layernorm2d_cl.restype = C.c_int
-    lib.fvit_layernorm2d_cl.argtypes = [i32, vp, vp, vp, vp, f32, C.c_int64, i32, vp]
+    lib.fvit_layernorm2d_cl.argtypes = [i32, vp, vp, vp, vp, f32, C.c_int64, i32, i32, vp]
     lib.fvit_conv3x3_nhwc.restype = C.c_int
     lib.fvit_conv3x3_nhwc.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.fvit_stem_conv3x3s2.restype = C.c_int

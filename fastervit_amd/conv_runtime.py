@@ -60,6 +60,11 @@ class DeployPlan:
         self.streams = 1      # > 1: run the batch as that many shards on separate HIP streams
         self.side = None
         self.use_hip_conv = True  # fused implicit-GEMM conv kernel where the shape allows; False = MIOpen + glue passes
+        # conv-side maps carry their channels padded to a multiple of 64 (zeros), weights / biases / LayerNorm2d parameters are
+        # zero-padded to match: every 3x3 conv then runs on the fused HIP kernel (FasterViT-1/2/4: 80 / 96 / 196 / 392 channels
+        # would otherwise fall back to MIOpen + glue passes; a 196-channel fp16 pixel is not even 16-byte aligned).  Pad channels
+        # stay exactly zero through bias (0), ReLU / GELU (f(0) = 0), residual adds and LayerNorm2d (zero weight / bias there).
+        self.pad_channels = True
 
     # ---- folding -------------------------------------------------------------------------
     def _signature(self):
@@ -71,9 +76,28 @@ class DeployPlan:
             sig.append((p.data_ptr(), p._version))
         return tuple(sig)
 
+    def _cp(self, c):
+        """Channel count of a conv-side map holding c real channels."""
+        return c if (c % 64 == 0 or c <= 3 or not (self.pad_channels and self.use_hip_conv)) else (c + 63) // 64 * 64
+
+    def _padv(self, v, n):
+        """1-D parameter zero-padded to n entries."""
+        if v is None or v.numel() == n:
+            return v
+        out = torch.zeros(n, dtype=v.dtype, device=v.device)
+        out[:v.numel()] = v
+        return out
+
     def _cw(self, w):
         """(MIOpen weight, HIP-kernel weight): the channels_last 16-bit tensor for F.conv2d, and -- when the fused
-        implicit-GEMM kernel supports the shape (3x3, Cin and Cout multiples of 64) -- its [Cout][3][3][Cin] matrix view."""
+        implicit-GEMM kernel supports the shape (3x3, Cin and Cout multiples of 64) -- its [Cout][3][3][Cin] matrix view.
+        Both channel counts are zero-padded to the map layout (``_cp``)."""
+        co0, ci0 = w.shape[:2]
+        cop, cip = self._cp(co0), self._cp(ci0)
+        if (cop, cip) != (co0, ci0):
+            wp = torch.zeros((cop, cip) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+            wp[:co0, :ci0] = w
+            w = wp
         wcl = w.to(self.dtype).contiguous(memory_format=torch.channels_last)
         co, ci, kh, kw = w.shape
         wk = None
@@ -109,7 +133,8 @@ class DeployPlan:
         pe = m.patch_embed.conv_down
         w0, b0 = _fold(pe[0], pe[1])
         w1, b1 = _fold(pe[3], pe[4])
-        t["stem"] = (self._cw(w0), b0.contiguous(), self._cw(w1), b1.contiguous())
+        t["stem"] = (self._cw(w0), self._padv(b0, self._cp(b0.numel())).contiguous(), self._cw(w1),
+                     self._padv(b1, self._cp(b1.numel())).contiguous())
         t["stem_k"] = None
         if self.use_hip_conv and tuple(w0.shape) == (64, 3, 3, 3) and pe[0].stride == (2, 2):
             wk = torch.zeros(64, 32, device=w0.device, dtype=torch.float32)
@@ -123,7 +148,8 @@ class DeployPlan:
                 for blk in lvl.blocks:
                     wa, ba = _fold(blk.conv1, blk.norm1)
                     wb, bb = _fold(blk.conv2, blk.norm2, blk.gamma if blk.layer_scale else None)
-                    blocks.append((self._cw(wa), ba.contiguous(), self._cw(wb), bb.contiguous()))
+                    cpd = self._cp(ba.numel())
+                    blocks.append((self._cw(wa), self._padv(ba, cpd).contiguous(), self._cw(wb), self._padv(bb, cpd).contiguous()))
                 e["blocks"] = blocks
             elif getattr(lvl, "do_gt", False):
                 tk = lvl.global_tokenizer
@@ -131,8 +157,10 @@ class DeployPlan:
                             tk.to_global_feature.pool.kernel_size, tk.to_global_feature.pool.stride, tk.window_size)
             if lvl.downsample is not None:
                 ds = lvl.downsample
-                e["down"] = (ds.norm.weight.float().contiguous(), ds.norm.bias.float().contiguous(), float(ds.norm.eps),
-                             self._cw(ds.reduction[0].weight.float()))
+                cin = ds.norm.weight.numel()
+                e["down"] = (self._padv(ds.norm.weight.float(), self._cp(cin)).contiguous(),
+                             self._padv(ds.norm.bias.float(), self._cp(cin)).contiguous(), float(ds.norm.eps),
+                             self._cw(ds.reduction[0].weight.float()), cin)
             t["levels"].append(e)
         hw, hb = m.head.weight.float(), m.head.bias.float()
         if isinstance(m.norm, torch.nn.BatchNorm2d):
@@ -158,14 +186,17 @@ class DeployPlan:
                                                     _stream()), "fvit_bias_residual_cl")
         return x
 
-    def _ln2d(self, x, w, b, eps):
+    def _ln2d(self, x, w, b, eps, c_valid=None):
+        """LayerNorm2d over the first c_valid (default: all) channels of a channels_last map; pad channels stay zero."""
         B, C, H, W = x.shape
+        cv = C if c_valid is None else c_valid
         if C % 8 or not x.is_contiguous(memory_format=torch.channels_last):
-            y = F.layer_norm(x.permute(0, 2, 3, 1).float(), (C,), w, b, eps).permute(0, 3, 1, 2)
+            y = torch.zeros_like(x, dtype=torch.float32)
+            y[:, :cv] = F.layer_norm(x[:, :cv].permute(0, 2, 3, 1).float(), (cv,), w[:cv], b[:cv], eps).permute(0, 3, 1, 2)
             return y.to(self.dtype).contiguous(memory_format=torch.channels_last)
         out = torch.empty_like(x)
         _lib.check(_lib.lib().fvit_layernorm2d_cl(self.code, x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(), eps,
-                                                  B * H * W, C, _stream()), "fvit_layernorm2d_cl")
+                                                  B * H * W, C, cv, _stream()), "fvit_layernorm2d_cl")
         return out
 
     def _tokenizer(self, tok):
@@ -251,10 +282,22 @@ class DeployPlan:
                         y = self._conv(x, wa, ba, 1, 2)
                         x = self._conv(y, wb, bb, 1, 0, residual=x)
                 else:
-                    x = hat_runtime.stage_forward(lvl, x)  # TokenInitializer runs in fvit_token_init (HIP) in both modes
+                    # the HIP stage reads / writes its maps through strided views: the padded map's first C channels in, and
+                    # -- when a Downsample follows -- the first C channels of a zero-initialised padded map out
+                    creal = lvl.blocks[0].attn.qkv.in_features if len(lvl.blocks) else x.shape[1]
+                    xin = x[:, :creal] if x.shape[1] != creal else x
+                    cpo = self._cp(creal) if "down" in e else creal
+                    if cpo != creal:
+                        xo = torch.empty((x.shape[0], cpo, x.shape[2], x.shape[3]), dtype=self.dtype, device=x.device,
+                                         memory_format=torch.channels_last)
+                        xo[:, creal:] = 0   # only the pad channels need initialising; the stage writes the first creal
+                        hat_runtime.stage_forward(lvl, xin, out=xo[:, :creal])  # TokenInitializer: fvit_token_init in both modes
+                        x = xo
+                    else:
+                        x = hat_runtime.stage_forward(lvl, xin)
                 if "down" in e:
-                    lw, lb, eps, wd = e["down"]
-                    x = self._conv(self._ln2d(x, lw, lb, eps), wd, None, 2, 0)
+                    lw, lb, eps, wd, cin = e["down"]
+                    x = self._conv(self._ln2d(x, lw, lb, eps, cin), wd, None, 2, 0)
             hw, hb, ln = t["head"]
             if ln is not None:
                 x = self._ln2d(x, *ln)

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void bias_kernel(T* __restrict__ x, const T* _
 // 8 per lane and per step (MAXV steps).  LPP = 8 for C = 64 so that narrow maps still use every lane.
 template <typename T, int LPP, int MAXV>
 __global__ __launch_bounds__(256) void ln2d_kernel(const T* __restrict__ in, T* __restrict__ out, const float* __restrict__ w,
-                                                   const float* __restrict__ b, float eps, int64_t npix, int C) {
+                                                   const float* __restrict__ b, float eps, int64_t npix, int C, int Cv) {
     typedef T v8 __attribute__((ext_vector_type(8)));
     constexpr int PPW = 64 / LPP;  // pixels per wave
     const int lane = threadIdx.x & 63;
@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void ln2d_kernel(const T* __restrict__ in, T* 
     }
 #pragma unroll
     for (int o = LPP / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float mean = sum / (float)C;
+    // Cv <= C real channels; the C - Cv trailing pad channels hold zeros (channel-padded deploy maps): they add nothing to
+    // the sum and (0 - mean)^2 each to the squared deviations, which is taken out again below
+    const float mean = sum / (float)Cv;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -90,7 +92,8 @@ __global__ __launch_bounds__(256) void ln2d_kernel(const T* __restrict__ in, T* 
     }
 #pragma unroll
     for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    const float rstd = rsqrtf(sq / (float)C + eps);
+    sq -= (float)(C - Cv) * mean * mean;
+    const float rstd = rsqrtf(fmaxf(sq, 0.f) / (float)Cv + eps);
     if (!ok) return;
     T* dst = out + pix * C;
 #pragma unroll
@@ -122,11 +125,11 @@ int bias_launch(T* x, const T* y, const float* bias, int64_t n, int C, int act, 
 }
 
 template <typename T>
-int ln2d_launch(const T* in, T* out, const float* w, const float* b, float eps, int64_t npix, int C, hipStream_t stream) {
+int ln2d_launch(const T* in, T* out, const float* w, const float* b, float eps, int64_t npix, int C, int Cv, hipStream_t stream) {
     const int c8 = C / 8;
 #define FVIT_LN2D(LPP, MAXV)                                                                                          \
     hipLaunchKernelGGL((ln2d_kernel<T, LPP, MAXV>), dim3((unsigned)((npix + 4 * (64 / LPP) - 1) / (4 * (64 / LPP)))), \
-                       dim3(256), 0, stream, in, out, w, b, eps, npix, C)
+                       dim3(256), 0, stream, in, out, w, b, eps, npix, C, Cv)
     if (c8 <= 8) FVIT_LN2D(8, 1);
     else if (c8 <= 16) FVIT_LN2D(16, 1);
     else if (c8 <= 32) FVIT_LN2D(32, 1);
@@ -176,14 +179,15 @@ int fvit_bias_residual_cl(int32_t dtype, void* x, const void* y, const float* bi
 }
 
 int fvit_layernorm2d_cl(int32_t dtype, const void* in, void* out, const float* weight, const float* bias, float eps,
-                        int64_t n_pixels, int32_t C, fvit_stream_t stream) {
-    if (!in || !out || !weight || !bias || n_pixels <= 0 || C <= 0 || (C % 8)) {
-        set_error("layernorm2d: bad arguments (C=%d must be a multiple of 8)", C);
+                        int64_t n_pixels, int32_t C, int32_t C_valid, fvit_stream_t stream) {
+    if (C_valid <= 0) C_valid = C;
+    if (!in || !out || !weight || !bias || n_pixels <= 0 || C <= 0 || (C % 8) || C_valid > C) {
+        set_error("layernorm2d: bad arguments (C=%d must be a multiple of 8, C_valid=%d <= C)", C, C_valid);
         return FVIT_EINVAL;
     }
     ProfScope prof(FVIT_K_OTHER, 0.0, 4.0 * n_pixels * C, (hipStream_t)stream);
-    if (dtype == FVIT_F16) return ln2d_launch<_Float16>((const _Float16*)in, (_Float16*)out, weight, bias, eps, n_pixels, C, (hipStream_t)stream);
-    if (dtype == FVIT_BF16) return ln2d_launch<__bf16>((const __bf16*)in, (__bf16*)out, weight, bias, eps, n_pixels, C, (hipStream_t)stream);
+    if (dtype == FVIT_F16) return ln2d_launch<_Float16>((const _Float16*)in, (_Float16*)out, weight, bias, eps, n_pixels, C, C_valid, (hipStream_t)stream);
+    if (dtype == FVIT_BF16) return ln2d_launch<__bf16>((const __bf16*)in, (__bf16*)out, weight, bias, eps, n_pixels, C, C_valid, (hipStream_t)stream);
     set_error("layernorm2d: dtype %d not supported (16-bit maps only)", dtype);
     return FVIT_EINVAL;
 }

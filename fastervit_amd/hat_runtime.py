@@ -368,8 +368,9 @@ def _check_mode(layer):
 
 
 @torch.no_grad()
-def stage_forward(layer, x: torch.Tensor, tokenizer=None) -> torch.Tensor:
-    """Transformer branch of FasterViTLayer.forward (AR:848-869) minus the Downsample.
+def stage_forward(layer, x: torch.Tensor, tokenizer=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Transformer branch of FasterViTLayer.forward (AR:848-869) minus the Downsample.  ``x`` and the optional preallocated
+    ``out`` (same shape and dtype) may be arbitrary strided views, e.g. the leading channels of a channel-padded map.
 
     ``tokenizer`` (optional) replaces the layer's TokenInitializer module with an equivalent callable
     returning f32 (B, G, C) carrier tokens (deploy mode passes a 16-bit channels_last version)."""
@@ -394,7 +395,10 @@ def stage_forward(layer, x: torch.Tensor, tokenizer=None) -> torch.Tensor:
             ct = token_init(layer.global_tokenizer, xp)
     st, tb, ctables, dc = _prepare(layer, x.device, Hp, Wp)
     desc, ws_t = _workspace(st, dc, B, H, W, x.device)
-    out = torch.empty_like(x)  # keeps dtype and memory format (NCHW or channels_last)
+    if out is None:
+        out = torch.empty_like(x)  # keeps dtype and memory format (NCHW or channels_last)
+    elif out.shape != x.shape or out.dtype != x.dtype or out.device != x.device:
+        raise RuntimeError(f"stage_forward: out {tuple(out.shape)} {out.dtype} does not match x {tuple(x.shape)} {x.dtype}")
     vin, vout = _map_view(xp), _map_view(out)
     rc = lib.fvit_hat_stage_forward(C.byref(desc), st.blocks_c, C.byref(ctables), C.byref(vin),
                                     ct.data_ptr() if ct is not None else None, C.byref(vout), ws_t.data_ptr(),

@@ -266,9 +266,11 @@ int fvit_bias_act_cl(int32_t dtype, void* x, const float* bias, int64_t n_pixels
 /* x = x + y + bias[c] in place (ConvBlock residual, FV:512, with conv2's bias and norm2/gamma folded). */
 int fvit_bias_residual_cl(int32_t dtype, void* x, const void* y, const float* bias, int64_t n_pixels, int32_t C,
                           fvit_stream_t stream);
-/* Per-pixel LayerNorm over C (timm LayerNorm2d of Downsample, FV:432,438; eps 1e-6), fp32 statistics. */
+/* Per-pixel LayerNorm (timm LayerNorm2d of Downsample, FV:432,438; eps 1e-6), fp32 statistics.  Pixels are C channels apart;
+ * the statistics run over the first C_valid of them (C_valid <= 0: all C).  With C_valid < C the trailing channels must hold zeros
+ * on input (channel-padded deploy maps) and weight / bias must be zero there, so they stay zero on output. */
 int fvit_layernorm2d_cl(int32_t dtype, const void* in, void* out, const float* weight, const float* bias, float eps,
-                        int64_t n_pixels, int32_t C, fvit_stream_t stream);
+                        int64_t n_pixels, int32_t C, int32_t C_valid, fvit_stream_t stream);
 
 /* 3x3 convolution, pad 1, stride 1 or 2, on channels-last 16-bit maps as an implicit GEMM on the MFMA cores with the
  * epilogue fused: out = act(conv(in, weight) + bias) (+ residual).  Replaces (deploy mode, BatchNorm folded into

@@ -285,7 +285,7 @@ def test_glue_kernels(dt, code, C):
         w = (torch.rand(C, generator=g) + 0.5).cuda()
         out = torch.empty_like(x)
         _lib.check(lib.fvit_layernorm2d_cl(code, x.data_ptr(), out.data_ptr(), w.data_ptr(), bias.data_ptr(),
-                                           ctypes.c_float(1e-6), B * H * W, C, _stream()), "ln2d")
+                                           ctypes.c_float(1e-6), B * H * W, C, 0, _stream()), "ln2d")
         ref = F.layer_norm(x.float().permute(0, 2, 3, 1), (C,), w, bias, 1e-6).permute(0, 3, 1, 2)
         assert (out.float() - ref).abs().max().item() < 4 * tol
     torch.cuda.synchronize()
@@ -321,6 +321,28 @@ def test_mlp_fused(opname, dt, code, M, use_gamma):
     tol = (3e-3 if dt == torch.float16 else 2e-2) * ref.abs().max().item()
     assert torch.isfinite(x).all()
     assert (x - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("C,Cv", [(256, 196), (448, 392), (64, 16), (128, 80)])
+def test_layernorm2d_channel_padded(C, Cv):
+    """LayerNorm2d over the first Cv of C channels (zero pad channels in, zero weight/bias there, zeros out) vs F.layer_norm on Cv."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(C + Cv)
+    x = torch.zeros(2, 9, 7, C)
+    x[..., :Cv] = torch.randn(2, 9, 7, Cv, generator=g) * 2 + 0.3
+    x = x.half().cuda()
+    w = torch.zeros(C)
+    b = torch.zeros(C)
+    w[:Cv] = torch.rand(Cv, generator=g) + 0.5
+    b[:Cv] = torch.randn(Cv, generator=g)
+    w, b = w.cuda(), b.cuda()
+    out = torch.full_like(x, float("nan"))
+    _lib.check(lib.fvit_layernorm2d_cl(1, x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(), ctypes.c_float(1e-6), 2 * 9 * 7, C, Cv,
+                                       _stream()), "ln2d padded")
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x[..., :Cv].float(), (Cv,), w[:Cv], b[:Cv], 1e-6)
+    assert (out[..., :Cv].float() - ref).abs().max().item() < 1e-2 * max(ref.abs().max().item(), 1.0)
+    assert out[..., Cv:].abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])

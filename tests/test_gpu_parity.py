@@ -235,7 +235,7 @@ def test_oracle_on_gpu_box_matches_goldens():
 
 
 @pytest.mark.parametrize("name,tol", [("fvit0_224", 4e-3), ("tiny_hier", None), ("tiny_anyres", None), ("tiny_w14", None),
-                                      ("tiny_21k_384", None), ("tiny_anyres_w16", None)])
+                                      ("tiny_21k_384", None), ("tiny_anyres_w16", None), ("tiny_d80", None), ("fvit4_224", None)])
 def test_deploy_mode_vs_reference(name, tol):
     """switch_to_deploy(): BN folded into the convs, fp16 channels_last conv side, fused glue kernels."""
     g = load_golden(name)
