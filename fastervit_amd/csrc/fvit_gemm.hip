@@ -51,11 +51,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <typename T, bool IS_W, int ROWS>
+template <typename T, bool IS_W, int ROWS, int NW>
 __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int row0, int k0, char* tile,
                                            int wave, int lane) {
     // ROWS/8 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces PW*w .. PW*w + PW-1.
-    constexpr int PW = ROWS / 8 / 4;
+    constexpr int PW = ROWS / 8 / NW;
+    static_assert(PW >= 1, "tile too small for this many waves");
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int piece = wave * PW + i;
@@ -74,10 +75,17 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
 //             otherwise one full LDS-DMA round trip (~1.3 us) because nothing else on the CU hides it.
 // MI: 16-row fragments per wave along M (4: 128-row tile; 2: 64-row tile, 48 KiB LDS, three workgroups per CU -- for
 //     small grids, where twice the workgroups at higher occupancy hide the per-K-step DMA latency better)
-template <typename T, int EPI, int NSTAGE, int MI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+// NW: waves per workgroup, NW/2 along M x 2 along N (8 = two waves per SIMD even with one workgroup per CU).
+// Measured r01 (scripts/bench_gemm.py, profiles/r01_gemm_small_grid_variants.log): on the shard-sized stage-3 GEMMs (132-264
+// workgroups, K = 512..2048) the time per K step is 0.58 us WHATEVER the tile height (64 / 128 rows), the ring depth (2 / 3), the
+// LDS read schedule or the waves per workgroup (4 / 8): it is set by the memory system, not by the instruction stream -- a CU
+// sustains ~16 KiB of loads in flight (scripts/probes/dma_probe.hip: 125 GB/s per CU from L2, 30-40 GB/s per CU from HBM / MALL,
+// independent of ring depth), and the A operand of these GEMMs was just written by the previous kernel and comes from the
+// memory side.  NW = 8 and NSTAGE = 3 are therefore opt-in knobs only.
+template <typename T, int EPI, int NSTAGE, int MI, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmParams p) {
     typedef typename Op16<T>::v8 v8;
-    constexpr int BMT = 32 * MI;                       // rows of the workgroup tile (2 waves along M)
+    constexpr int BMT = (NW / 2) * 16 * MI;            // rows of the workgroup tile (NW/2 waves along M)
     constexpr int XT_BYTES = BMT * BK * 2;             // activation tile bytes (W tile stays TILE_BYTES = 128 rows)
     __shared__ __attribute__((aligned(16))) char smem[NSTAGE * (XT_BYTES + TILE_BYTES)];  // X ring, then W ring
 
@@ -108,8 +116,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st) {
         if (st < nk) {
-            stage_tile<T, false, BMT>(A, p.lda, m0, st * BK, xring + st * XT_BYTES, wave, lane);
-            stage_tile<T, true, 128>(W, p.ldw, n0, st * BK, wring + st * TILE_BYTES, wave, lane);
+            stage_tile<T, false, BMT, NW>(A, p.lda, m0, st * BK, xring + st * XT_BYTES, wave, lane);
+            stage_tile<T, true, 128, NW>(W, p.ldw, n0, st * BK, wring + st * TILE_BYTES, wave, lane);
         }
     }
 
@@ -138,25 +146,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             int slot = cur + NSTAGE - 1;
             if (slot >= NSTAGE) slot -= NSTAGE;
             if (nxt < nk) {
-                stage_tile<T, false, BMT>(A, p.lda, m0, nxt * BK, xring + slot * XT_BYTES, wave, lane);
-                stage_tile<T, true, 128>(W, p.ldw, n0, nxt * BK, wring + slot * TILE_BYTES, wave, lane);
+                stage_tile<T, false, BMT, NW>(A, p.lda, m0, nxt * BK, xring + slot * XT_BYTES, wave, lane);
+                stage_tile<T, true, 128, NW>(W, p.ldw, n0, nxt * BK, wring + slot * TILE_BYTES, wave, lane);
             }
         }
         const char* xt = xring + cur * XT_BYTES;
         const char* wt = wring + cur * TILE_BYTES;
+        // all fragment reads of the K step are issued up front (both 32-deep halves): left to itself the compiler reads one
+        // half, drains lgkmcnt, multiplies, reads the next half, drains again -- three exposed LDS round trips per K step, which
+        // is what bounds small grids (one wave per SIMD, nothing else to hide them)
+        v8 xf[2][MI], wf[2][4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int c = kk * 4 + g;
-            v8 xf[MI], wf[4];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) xf[i] = *(const v8*)(xt + xrow[i] * 128 + ((c ^ swz_x(xrow[i])) << 4));
+            for (int i = 0; i < MI; ++i) xf[kk][i] = *(const v8*)(xt + xrow[i] * 128 + ((c ^ swz_x(xrow[i])) << 4));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
+            for (int i = 0; i < 4; ++i) wf[kk][i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[ni], xf[mi], acc[ni][mi]);
-        }
+                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[kk][ni], xf[kk][mi], acc[ni][mi]);
         if (++cur == NSTAGE) cur = 0;
     }
 
@@ -224,11 +238,13 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.lda = c.lda; p.ldw = c.ldw; p.ldo = c.ldo;
     p.M = c.M; p.N = c.N; p.K = c.K;
     p.tiles_n = (c.N + BN - 1) / BN;
-    // small grids (<= 2 workgroups per CU with 128-row tiles) switch to 64-row tiles: twice the workgroups, 3 per CU
     const int grid128 = ((c.M + 127) / 128) * p.tiles_n;
-    // measured r01: no gain on whole-batch launches (gamma-residual GEMMs 0.653 vs 0.585 ms per step with 64-row tiles), but
-    // +2 % images/s on the shard-sized launches of the stream-sharded deploy plan (132-396 workgroups with 128-row tiles)
-    const bool small = grid128 <= tune_get("gemm_bm64_max_grid", 400);
+    // tile / workgroup shape by grid size (fvit_tune knobs for A/B):
+    //   grid128 <= bm64_max : 64-row tiles (twice the workgroups; +2 % images/s on shard-sized launches), else 128-row tiles
+    //   grid128 <= nw8_max  : 8 waves per workgroup (default off: no gain, see gemm_kernel)
+    const int nw8_max = tune_get("gemm_nw8_max_grid", 0), bm64_max = tune_get("gemm_bm64_max_grid", 400);
+    const bool nw8 = grid128 <= nw8_max;
+    const bool small = grid128 <= bm64_max;   // 64-row tiles
     p.tiles_m = small ? (c.M + 63) / 64 : (c.M + 127) / 128;
     const int grid = p.tiles_m * p.tiles_n;
     const double flops = 2.0 * c.M * (double)c.N * c.K;
@@ -243,15 +259,16 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     }
     ProfScope prof(kind, flops, bytes, stream);
     // measured r01: a 3-stage ring with counted vmcnt gave no gain over 2 stages at 64..392 workgroups => opt-in only
-    const bool deep = !small && grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
-#define FVIT_GEMM(E, NS, MI_) hipLaunchKernelGGL((gemm_kernel<T, E, NS, MI_>), dim3(grid), dim3(256), 0, stream, p)
-    if (small) {
-        switch (c.epilogue) { case 0: FVIT_GEMM(0, 2, 2); break; case 1: FVIT_GEMM(1, 2, 2); break; default: FVIT_GEMM(2, 2, 2); break; }
-    } else if (deep) {
-        switch (c.epilogue) { case 0: FVIT_GEMM(0, 3, 4); break; case 1: FVIT_GEMM(1, 3, 4); break; default: FVIT_GEMM(2, 3, 4); break; }
-    } else {
-        switch (c.epilogue) { case 0: FVIT_GEMM(0, 2, 4); break; case 1: FVIT_GEMM(1, 2, 4); break; default: FVIT_GEMM(2, 2, 4); break; }
-    }
+    const bool deep = !small && !nw8 && grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
+#define FVIT_GEMM(E, NS, MI_, NW_) hipLaunchKernelGGL((gemm_kernel<T, E, NS, MI_, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p)
+#define FVIT_GEMM_E(NS, MI_, NW_) \
+    switch (c.epilogue) { case 0: FVIT_GEMM(0, NS, MI_, NW_); break; case 1: FVIT_GEMM(1, NS, MI_, NW_); break; default: FVIT_GEMM(2, NS, MI_, NW_); break; }
+    if (nw8 && small) { FVIT_GEMM_E(2, 1, 8) }        // 64 rows = 4 waves along M x 16 rows
+    else if (nw8) { FVIT_GEMM_E(2, 2, 8) }            // 128 rows = 4 waves x 32 rows
+    else if (small) { FVIT_GEMM_E(2, 2, 4) }          // 64 rows = 2 waves x 32 rows
+    else if (deep) { FVIT_GEMM_E(3, 4, 4) }
+    else { FVIT_GEMM_E(2, 4, 4) }
+#undef FVIT_GEMM_E
 #undef FVIT_GEMM
     return check_launch("gemm_kernel");
 }

@@ -1,0 +1,56 @@
+"""Micro-benchmark of the gamma-residual / bias GEMM kernels at the shard-sized shapes of FasterViT-0 (A/B of the tile and ring variants).
+usage: python scripts/bench_gemm.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fastervit_amd import _lib  # noqa: E402
+
+lib = _lib.lib()
+st = torch.cuda.current_stream().cuda_stream
+dt, code = torch.float16, 1
+SHAPES = [  # name, M, N, K, epilogue (0 bias, 1 gelu, 2 residual)
+    ("s3 fc2 shard", 4165, 512, 2048, 2), ("s3 proj shard", 4165, 512, 512, 2), ("s3 fc1 shard", 4165, 2048, 512, 1),
+    ("s3 qkv shard", 4165, 1536, 512, 0), ("ct fc2 shard", 1360, 256, 1024, 2), ("ct proj shard", 1360, 256, 256, 2),
+    ("s3 fc2 full", 12544, 512, 2048, 2), ("s3 fc1 full", 12544, 2048, 512, 1)]
+VARIANTS = [("8 waves, 64-row (default)", dict(gemm_nw8_max_grid=400, gemm_bm64_max_grid=400)),
+            ("8 waves, 128-row", dict(gemm_nw8_max_grid=400, gemm_bm64_max_grid=0)),
+            ("4 waves, 64-row", dict(gemm_nw8_max_grid=0, gemm_bm64_max_grid=400)),
+            ("4 waves, 128-row", dict(gemm_nw8_max_grid=0, gemm_bm64_max_grid=0))]
+g = torch.Generator(device="cpu").manual_seed(0)
+for name, M, N, K, epi in SHAPES:
+    Mp = (M + 127) // 128 * 128
+    NBUF = 6   # rotate operands so that a launch does not find its own A tile in L2 from the previous launch
+    As = [torch.randn(Mp, K, generator=g).to(dt).cuda() for _ in range(NBUF)]
+    W = (torch.randn((N + 127) // 128 * 128, K, generator=g) / K ** 0.5).to(dt).cuda()
+    bias = torch.zeros(N).cuda()
+    gamma = torch.ones(N).cuda()
+    X = [torch.zeros(Mp, N).cuda() for _ in range(NBUF)]
+    O = [torch.zeros(Mp, N, dtype=dt).cuda() for _ in range(NBUF)]
+
+    def call(i):
+        k = i % NBUF
+        if epi == 2:
+            _lib.check(lib.fvit_gemm_residual(code, As[k].data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), gamma.data_ptr(), X[k].data_ptr(), N,
+                                              M, N, K, st), "gemm_residual")
+        else:
+            _lib.check(lib.fvit_gemm_bias_act(code, As[k].data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), O[k].data_ptr(), N, M, N, K, epi, st),
+                       "gemm_bias_act")
+    line = f"{name:14s} M={M:5d} N={N:4d} K={K:4d}:"
+    for vname, knobs in VARIANTS:
+        for k, v in knobs.items():
+            _lib.tune(k, v)
+        for i in range(3):
+            call(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 30
+        for i in range(n):
+            call(i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        line += f"  {vname}: {us:6.1f} us"
+    print(line, flush=True)
