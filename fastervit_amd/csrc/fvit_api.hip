@@ -181,7 +181,10 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
     const int dt = d.operand_dtype;
     // the fused kernel streams all MLP weights per 128-row workgroup: it wins once the launch fills the chip
     // (>= ~16k rows; 104 vs 137 us at 54k rows) and loses on the latency-bound carrier branch (4k rows: 83 vs 31 us)
-    if (w.w_fc1_frag && w.w_fc2_frag && mlp_fused_supported(d.C, d.hidden) && rows >= tune_get("mlp_fused_min_rows", 16384) &&
+    // C = 512 (stage 3): the fused instance is correct but slower than LN + 2 GEMMs at these row counts (65-196 workgroups, each
+    // streaming 4 MiB of weights: 65.8k vs 71.0k images/s end to end, r01 sweep r31) => opt-in
+    const int64_t fused_min = d.C == 256 ? tune_get("mlp_fused_min_rows", 16384) : tune_get("mlp_fused512_min_rows", 1 << 30);
+    if (w.w_fc1_frag && w.w_fc2_frag && mlp_fused_supported(d.C, d.hidden) && rows >= fused_min &&
         tune_get("mlp_fused", 1)) {
         MlpFusedCall mc = {dt, x, (int)rows, d.C, d.hidden, w.ln_w, w.ln_b, 1e-5f, w.w_fc1_frag, w.b_fc1, w.w_fc2_frag, w.b_fc2, w.gamma};
         return launch_mlp_fused(mc, st);

@@ -254,6 +254,10 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
             case 5: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2, true>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;  // spills
             default: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, true>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p); break;
         }
+    } else if (c.C == 512) {
+        // stage 3 of FasterViT-0: 16 rows per wave, one workgroup (136 KiB of LDS: two 64-KiB weight chunks) per CU; the 128
+        // accumulator VGPRs leave no room to keep the fp32 rows, so the epilogue re-reads X
+        hipLaunchKernelGGL((mlp_fused_kernel<T, 512, 1, 4, 1, false>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p);
     } else {
         set_error("mlp_fused: C=%d has no fused instance", c.C);
         return FVIT_EINVAL;
@@ -263,7 +267,7 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
 
 }  // namespace
 
-bool mlp_fused_supported(int C, int hidden) { return C == 256 && hidden % 32 == 0 && hidden > 0 && hidden <= 4 * C; }
+bool mlp_fused_supported(int C, int hidden) { return (C == 256 || C == 512) && hidden % 32 == 0 && hidden > 0 && hidden <= 4 * C; }
 
 int launch_mlp_fused(const MlpFusedCall& c, hipStream_t stream) {
     if (!mlp_fused_supported(c.C, c.hidden) || c.M <= 0 || !c.x || !c.w1f || !c.w2f) {

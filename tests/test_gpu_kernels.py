@@ -292,11 +292,12 @@ def test_glue_kernels(dt, code, C):
 
 
 @pytest.mark.parametrize("opname,dt,code", OPS)
-@pytest.mark.parametrize("M,use_gamma", [(128, True), (300, False), (54272, True), (4096, True), (17, True)])
-def test_mlp_fused(opname, dt, code, M, use_gamma):
-    """x += gamma * fc2(GELU(fc1(LN(x)))) in one kernel vs PyTorch fp32 on 16-bit-rounded weights."""
+@pytest.mark.parametrize("M,use_gamma,C", [(128, True, 256), (300, False, 256), (54272, True, 256), (4096, True, 256), (17, True, 256),
+                                           (4165, True, 512), (12544, False, 512), (70, True, 512)])
+def test_mlp_fused(opname, dt, code, M, use_gamma, C):
+    """x += gamma * fc2(GELU(fc1(LN(x)))) in one kernel vs PyTorch fp32 on 16-bit-rounded weights (C = 256: stage 2, 512: stage 3)."""
     lib = _lib.lib()
-    C, hid = 256, 1024
+    hid = 4 * C
     assert lib.fvit_mlp_fused_supported(C, hid) == 1 and lib.fvit_mlp_fused_supported(784, 3136) == 0
     g = torch.Generator(device="cpu").manual_seed(M)
     x0 = (torch.randn(M, C, generator=g) * 1.5 + 0.3).cuda()
