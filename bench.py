@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=3,
                     help="deploy mode: run the batch as this many shards on separate HIP streams (fork/join inside the hipGraph); "
                          "r01: 57.2k / 61.4k / 62.6k / 59.4k img/s for 1 / 2 / 3 / 4")
+    ap.add_argument("--shard-sizes", type=str, default="", help="comma list of images per stream shard (default: equal split)")
     ap.add_argument("--shard-launch", choices=["free", "forkjoin"], default="forkjoin",
                     help="deploy mode with --streams > 1: 'free' = one hipGraph per shard on its own stream, replayed back to back with no "
                          "join between steps (streams drift apart, consecutive steps overlap); 'forkjoin' = one graph per step that "
@@ -84,7 +85,12 @@ def main():
     conv_dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": None}[args.conv_dtype]
     deploy = args.mode == "deploy" and conv_dt is not None
     if deploy:
+        if args.shard_sizes:
+            sizes = [int(v) for v in args.shard_sizes.split(",")]
+            args.streams = len(sizes)
         model.switch_to_deploy(conv_dt, streams=args.streams)
+        if args.shard_sizes:
+            model.__dict__["_deploy_plan"].shard_sizes = sizes
 
     def forward(inp):
         with torch.no_grad():

@@ -232,7 +232,8 @@ class DeployPlan:
         # the batch as n independent shards on n HIP streams (fork / join with events; capturable in a hipGraph): every kernel
         # of this pipeline runs its HBM-bound prologue / epilogue and its MFMA phase in lockstep across workgroups, so two
         # half-size pipelines interleave better than one full-size one
-        parts = x.chunk(n, dim=0)
+        sizes = getattr(self, "shard_sizes", None)
+        parts = x.split(list(sizes), dim=0) if sizes and sum(sizes) == x.shape[0] and len(sizes) == n else x.chunk(n, dim=0)
         outs = [None] * n
         if getattr(self, "serialize_shards", False):
             # measurement aid (bench.py's HIP-event pass): the same shard-sized launches, one after the other on the caller's

@@ -34,6 +34,7 @@ struct ConvParams {
     const void* zeros;   // >= 128 bytes of zeros
     int B, Hi, Wi, Cin, Cout, Ho, Wo, stride, act;
     int M, tiles_m, tiles_n;
+    int ablate;   // experiment knob (wrong results when non-zero): 1 no X gather, 2 no W staging, 4 no MFMA, 8 no epilogue
 };
 
 __device__ __forceinline__ int swz_x(int r) { return (r >> 1) & 7; }
@@ -120,11 +121,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
         const int tap = kt / cpt, ci0 = (kt - tap * cpt) * BK;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int toff = (ky * p.Wi + kx) * p.Cin + ci0;
+        if (!(p.ablate & 1))
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const T* src = ((rowmask[i] >> tap) & 1) ? rowbase[i] + toff + rowchunk[i] : Z + rowchunk[i];
             glds16(src, xbuf + (wave * XP + i) * 1024);
         }
+        if (!(p.ablate & 2))
 #pragma unroll
         for (int i = 0; i < WP; ++i) {
             const int piece = wave * WP + i;
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
             for (int i = 0; i < NI; ++i) wf[kk][i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!(p.ablate & 4))
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[kk][ni], xf[kk][mi], acc[ni][mi]);
     }
+    if (p.ablate & 8) return;
 
     // ---- epilogue: lane holds out[m][nb .. nb + 4*NI - 1] for 4 pixels m ----
     constexpr int NC = 4 * NI;  // consecutive channels per lane (16 or 8)
@@ -561,7 +566,13 @@ int launch_t(ConvParams& p, hipStream_t stream) {
     const double bytes = 2.0 * ((double)p.B * p.Hi * p.Wi * p.Cin + (double)p.M * p.Cout * (p.res ? 2.0 : 1.0) + 9.0 * p.Cin * p.Cout);
     ProfScope prof(FVIT_K_CONV, flops, bytes, stream);
     const int variant = tune_get("conv64_variant", 0);
-    if (p.Cout % 128 == 0) {
+    // 128x128 tiles run two workgroups per CU (64 KiB LDS): 512 slots.  A grid just above a multiple of 512 pays a whole extra
+    // round for a handful of tiles (527 tiles at 86 images of 28x28: 2 rounds, 42 us, of which one full round for 15 tiles).
+    // 128x64 tiles (48 KiB, three per CU: 768 slots) do half the MFMA work per workgroup and soften that cliff in isolation
+    // (40.6 vs 44 us at 85-86 images, but 41 vs 30 us at 83), yet end to end they lose (68.1k vs 70.0k images/s: the other stream
+    // shards' kernels fill the idle slots of a partial round anyway) => opt-in knob only.
+    const int narrow = tune_get("conv128_narrow", 0);
+    if (p.Cout % 128 == 0 && !narrow) {
         p.tiles_m = (p.M + 127) / 128;
         p.tiles_n = p.Cout / 128;
         hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
@@ -594,6 +605,7 @@ extern "C" int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weig
     ConvParams p;
     p.in = in; p.w = weight; p.bias = bias; p.res = residual; p.out = out; p.zeros = zeros;
     p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.act = act;
+    p.ablate = tune_get("conv_ablate", 0);
     p.Ho = (Hi + 2 - 3) / stride + 1;
     p.Wo = (Wi + 2 - 3) / stride + 1;
     const int64_t M = (int64_t)B * p.Ho * p.Wo;

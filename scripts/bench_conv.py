@@ -15,7 +15,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 85
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 56
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 56
 variants = sys.argv[4].split(",") if len(sys.argv) > 4 else ["gemm", "halo", "halo:256", "halo:768", "halo:1024"]
-C = 64
+C = int(os.environ.get("CONV_C", "64"))
 dt, code = torch.float16, 1
 g = torch.Generator(device="cpu").manual_seed(0)
 # several input/output buffers so that consecutive launches do not find their map in the 256-MiB infinity cache
@@ -44,6 +44,8 @@ def run(name, res, act, n=24):
         _lib.tune("conv_halo_ablate", int(name.split("a")[2]) if name.count("a") > 1 else 0)   # e.g. haloa3 = ablate bits 1|2
     else:
         _lib.tune("conv_halo", 0)
+        _lib.tune("conv_ablate", int(name[5:]) if name.startswith("gemma") else 0)   # e.g. gemma3 = conv_ablate bits 1|2
+        _lib.tune("conv128_narrow", 1 if name == "gemmn" else (0 if name == "gemmw" else -1))      # 128x64 / 128x128 tiles / auto
     for i in range(3):
         conv(i, res, act)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -59,12 +61,14 @@ def run(name, res, act, n=24):
     return us
 
 
-print(f"conv3x3 64->64 s1, B={B} {H}x{W}, {NBUF} rotating buffers")
+print(f"conv3x3 {C}->{C} s1, B={B} {H}x{W}, {NBUF} rotating buffers")
 for rnd in range(2):
     print("round", rnd + 1)
     for res, act in ((False, 2), (True, 0)):
         for v in variants:
             run(v, res, act)
+if C != 64:
+    sys.exit(0)
 # cross-check the two kernels against each other on the last buffers
 _lib.tune("conv_halo", 0)
 conv(0, True, 2)
