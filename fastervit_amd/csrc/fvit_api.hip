@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,7 +49,10 @@ static std::map<std::string, int>& tune_map() {
     static std::map<std::string, int> m;
     return m;
 }
+static std::mutex g_tune_mu;   // launches may come from several host threads (one per device under nn.DataParallel)
+
 int tune_get(const char* key, int dflt) {
+    std::lock_guard<std::mutex> lock(g_tune_mu);
     auto& m = tune_map();
     auto it = m.find(key);
     if (it != m.end()) return it->second;
@@ -433,6 +437,7 @@ int fvit_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_
 
 int fvit_tune(const char* key, int32_t value) {
     if (!key) return FVIT_EINVAL;
+    std::lock_guard<std::mutex> lock(g_tune_mu);
     tune_map()[key] = value;
     return FVIT_OK;
 }

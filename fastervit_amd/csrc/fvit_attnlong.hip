@@ -243,11 +243,9 @@ int launch_long_t(AttnLongParams& p, hipStream_t stream) {
         set_error("attention(long): %d tokens per window exceed the key-position table in LDS", p.S);
         return FVIT_EINVAL;
     }
-    static size_t attr_bytes = 0;   // opt in to > 64 KiB of dynamic LDS, once per kernel instance and size class
-    if (lds > 64 * 1024 && lds > attr_bytes) {
+    static DeviceOnce once;   // opt in to > 64 KiB of dynamic LDS, once per device and kernel instance
+    if (once.first_on_current_device())
         hipFuncSetAttribute((const void*)attn_long_kernel<T, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_bytes = 150 * 1024;
-    }
     const int64_t grid = (int64_t)p.nwin * p.heads * p.nqt;
     if (grid > 0x7fffffff) {
         set_error("attention(long): grid too large");

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 
 #include "../../include/fvit_hip.h"
@@ -67,6 +68,18 @@ __device__ __forceinline__ float gelu_fast(float x) {
 
 __host__ __device__ constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: remember which devices a kernel instance was opted in on
+// (one static DeviceOnce per kernel instance; one process may drive several GPUs, e.g. nn.DataParallel in the reference's validate.py)
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    bool first_on_current_device() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;   // unknown: just set the attribute again
+        const uint64_t bit = 1ull << dev;
+        return (mask.fetch_or(bit) & bit) == 0;
+    }
+};
 
 // ---- error plumbing (thread-local message, negative return codes) ----
 void set_error(const char* fmt, ...);

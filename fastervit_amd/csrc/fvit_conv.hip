@@ -543,11 +543,9 @@ int launch_halo_t(const ConvParams& c, hipStream_t stream) {
     ProfScope prof(FVIT_K_CONV, flops, bytes, stream);
     p.buf_bytes = c.res ? HALO_BUF : HALO_BYTES;
     const size_t lds = 1024 + 2 * (size_t)p.buf_bytes;
-    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process and kernel)
-    if (!attr_set) {
+    static DeviceOnce once;   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device and kernel instance)
+    if (once.first_on_current_device())
         hipFuncSetAttribute((const void*)conv3x3_c64_halo_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 + 2 * HALO_BUF);
-        attr_set = true;
-    }
     if (tune_get("conv_halo_debug", 0)) {
         int nb = -1;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv3x3_c64_halo_kernel<T>, 256, lds);
