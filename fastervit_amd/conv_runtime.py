@@ -18,6 +18,8 @@ remains the default so that the reference's scripts run unchanged.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -65,6 +67,7 @@ class DeployPlan:
         # would otherwise fall back to MIOpen + glue passes; a 196-channel fp16 pixel is not even 16-byte aligned).  Pad channels
         # stay exactly zero through bias (0), ReLU / GELU (f(0) = 0), residual adds and LayerNorm2d (zero weight / bias there).
         self.pad_channels = True
+        self.fused_stem = os.environ.get("FVIT_NO_FUSED_STEM", "0") != "1"   # both PatchEmbed convs in one kernel when in_dim == dim == 64 (the 112x112x64 map never reaches HBM)
 
     # ---- folding -------------------------------------------------------------------------
     def _signature(self):
@@ -265,18 +268,28 @@ class DeployPlan:
         t = self.t
         with torch.autocast(device_type="cuda", enabled=False):
             w0, b0, w1, b1 = t["stem"]
-            if t["stem_k"] is not None and x.shape[1] == 3 and x.dtype in hat_runtime._DT:
+            wk1 = w1[1]
+            if (self.fused_stem and t["stem_k"] is not None and x.shape[1] == 3 and x.dtype in hat_runtime._DT and wk1 is not None
+                    and tuple(wk1.shape) == (64, 3, 3, 64)):
+                B, _, Hi, Wi = x.shape
+                H1, W1 = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
+                y = torch.empty((B, 64, (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1), dtype=self.dtype, device=x.device,
+                                memory_format=torch.channels_last)
+                view = hat_runtime._map_view(x)
+                _lib.check(_lib.lib().fvit_stem_fused(self.code, view, t["stem_k"].data_ptr(), b0.data_ptr(), wk1.data_ptr(),
+                                                      b1.data_ptr(), y.data_ptr(), B, Hi, Wi, _stream()), "fvit_stem_fused")
+                x = y
+            elif t["stem_k"] is not None and x.shape[1] == 3 and x.dtype in hat_runtime._DT:
                 B, _, Hi, Wi = x.shape   # fused stem kernel reads the caller's image in place (any strides, fp32/16-bit)
                 y = torch.empty((B, 64, (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1), dtype=self.dtype, device=x.device,
                                 memory_format=torch.channels_last)
                 view = hat_runtime._map_view(x)
                 _lib.check(_lib.lib().fvit_stem_conv3x3s2(self.code, view, t["stem_k"].data_ptr(), b0.data_ptr(), y.data_ptr(),
                                                           B, Hi, Wi, _stream()), "fvit_stem_conv3x3s2")
-                x = y
+                x = self._conv(y, w1, b1, 2, 1)
             else:
                 x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
-                x = self._conv(x, w0, b0, 2, 1)
-            x = self._conv(x, w1, b1, 2, 1)
+                x = self._conv(self._conv(x, w0, b0, 2, 1), w1, b1, 2, 1)
             for lvl, e in zip(self.model.levels, t["levels"]):
                 if "blocks" in e:
                     for wa, ba, wb, bb in e["blocks"]:

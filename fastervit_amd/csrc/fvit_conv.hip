@@ -555,6 +555,182 @@ int launch_halo_t(const ConvParams& c, hipStream_t stream) {
     return check_launch("conv3x3_c64_halo_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused two-conv stem of PatchEmbed (FV:458-464) for in_dim = dim = 64 (FasterViT-0):
+//     out = ReLU(conv2_s2(ReLU(conv1_s2(image) + b1)) + b2),  conv1: 3 -> 64, conv2: 64 -> 64, both 3x3 / stride 2 / pad 1.
+// The 112x112x64 map between the two convs is the largest tensor of the network (1.6 MB per image in fp16): written and read
+// back it is 3.2 MB of the ~47 MB per image this pipeline moves through HBM.  Here a workgroup owns an 8x16 tile of the FINAL
+// 56x56 map: phase A computes the 17x33 conv1 pixels that tile needs (stem_conv_kernel's gather + one 32-deep MFMA step per 16
+// pixels, 10 % halo recompute) straight into LDS; phase B is the halo kernel's register-stationary conv over that LDS image.
+// Stride 2 would make a 16-pixel MFMA column group read every other LDS pixel, so phase A stores even and odd conv1 columns
+// in two planes: tap kx = 0 / 1 / 2 of output column j is plane E pixel j / plane O pixel j / plane E pixel j + 1 -- 16 consecutive
+// pixels again, conflict-free with the chunk position c ^ (px & 6) as in conv3x3_c64_halo_kernel.
+// ------------------------------------------------------------------------------------------------------------
+struct StemFusedParams {
+    FvitMapView in;      // (B, 3, Hi, Wi)
+    const void* w1;      // op16 [64][32]: k = ky*9 + kx*3 + c, zero for k >= 27
+    const float* b1;     // [64]
+    const void* w2;      // op16 [64][9*64]
+    const float* b2;     // [64]
+    void* out;           // [B][H2][W2][64]
+    int B, Hi, Wi, H1, W1, H2, W2;
+    int tiles_x, tiles_y, tiles;
+};
+
+constexpr int SF_ROWS = 2 * HALO_TH + 1, SF_COLS = 2 * HALO_TW + 1;         // 17 x 33 conv1 pixels per tile
+constexpr int SF_PLANE = (HALO_TW + 1) * 128;                                // 17 pixels of 128 B
+constexpr int SF_ROWPITCH = 2 * SF_PLANE;                                    // plane E (17 px) then plane O (16 px + 1 unused)
+constexpr int SF_LDS = SF_ROWS * SF_ROWPITCH;                                // 73 984 B
+constexpr int SF_GROUPS = (SF_ROWS * SF_COLS + 15) / 16;                     // 36 groups of 16 conv1 pixels
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
+    typedef typename Op16<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
+    float* sb1 = (float*)smem_dyn;             // [64]
+    float* sb2 = sb1 + 64;                     // [64]
+    char* img = smem_dyn + 1024;               // conv1 tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ch = wave & 1, ph = wave >> 1;
+    const int g = lane >> 4, s = lane & 15;
+    if (tid < 64) { sb1[tid] = p.b1[tid]; sb2[tid] = p.b2[tid]; }
+
+    const int nblk = gridDim.x;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int per_xcd = (nblk + 7 - xcd) >> 3;
+    const int tq = p.tiles >> 3, tr = p.tiles & 7;
+    const int t_begin = xcd * tq + min(xcd, tr);
+    const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
+
+    const T* __restrict__ W1 = (const T*)p.w1;
+    const T* __restrict__ W2 = (const T*)p.w2;
+    T* __restrict__ O = (T*)p.out;
+
+    // ---- conv2 weights, stationary in registers: wf[tap][kk][ni], slot s of fragment ni -> channel 32ch + (s>>2)*8 + ni*4 + (s&3) ----
+    v8 wf[9][2][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                wf[tap][kk][ni] = *(const v8*)(W2 + (size_t)(ch * 32 + (s >> 2) * 8 + ni * 4 + (s & 3)) * 576 + tap * 64 + kk * 32 + g * 8);
+    const int nb = ch * 32 + g * 8;
+
+    // phase-B read offsets inside a conv1 row, per horizontal tap: (plane, pixel shift) = (E, 0), (O, 0), (E, 1)
+    int xoff[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = s + (kx == 2 ? 1 : 0);
+        xoff[kx] = (kx == 1 ? SF_PLANE : 0) + px * 128 + ((g ^ (px & 6)) << 4);
+    }
+
+    for (int tile = t_begin + idx; tile < t_end; tile += per_xcd) {
+        const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
+        const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
+        const int r0 = 2 * ty * HALO_TH - 1, c0 = 2 * tx * HALO_TW - 1;      // conv1 coordinates of local (0, 0)
+        __syncthreads();   // every wave is done reading the previous tile's conv1 image (and sb1 / sb2 are visible)
+
+        // ================= phase A: conv1 + bias + ReLU of the tile's 17 x 33 conv1 pixels -> LDS =================
+        {
+            int lane_s = s, lane_g = g;
+            asm volatile("" : "+v"(lane_s), "+v"(lane_g));   // keep the per-group index math inside the loop (registers!)
+            // first-conv weights: fragment ni, slot s -> channel (s>>2)*16 + ni*4 + (s&3): lane (g, .) owns channels 16g .. 16g+15
+            v8 w1f[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) w1f[ni] = *(const v8*)(W1 + ((lane_s >> 2) * 16 + ni * 4 + (lane_s & 3)) * 32 + lane_g * 8);
+            const int64_t ibase = (int64_t)b * p.in.stride_b;
+            for (int grp = wave; grp < SF_GROUPS; grp += 4) {
+                const int q = grp * 16 + lane_s;
+                const int lr = q / SF_COLS, lc = q - lr * SF_COLS;
+                const int R = r0 + lr, Cc = c0 + lc;
+                const bool v1 = q < SF_ROWS * SF_COLS && R >= 0 && R < p.H1 && Cc >= 0 && Cc < p.W1;
+                const int yi = 2 * R - 1, xi = 2 * Cc - 1;
+                v8 xf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = lane_g * 8 + e;
+                    const int ky = k / 9, r9 = k - ky * 9, kx = r9 / 3, c = r9 - kx * 3;
+                    const int y = yi + ky, x = xi + kx;
+                    const bool inb = v1 && k < 27 && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi;
+                    // always a legal address (the image's first element when masked), then select
+                    const int64_t off = inb ? ibase + c * p.in.stride_c + y * p.in.stride_h + x * p.in.stride_w : ibase;
+                    const float val = stem_load(p.in, off);
+                    xf[e] = (T)(inb ? val : 0.f);
+                }
+                f4 acc[4];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[ni] = Op16<T>::mfma(w1f[ni], xf, (f4){0.f, 0.f, 0.f, 0.f});
+                if (q < SF_ROWS * SF_COLS) {
+                    v8 o0, o1;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const f4 bv = *(const f4*)(sb1 + lane_g * 16 + ni * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float y = v1 ? fmaxf(acc[ni][r] + bv[r], 0.f) : 0.f;   // outside the conv1 map: conv2's zero padding
+                            if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
+                        }
+                    }
+                    const int px = lc >> 1;
+                    char* dst = img + lr * SF_ROWPITCH + (lc & 1) * SF_PLANE + px * 128;
+                    *(v8*)(dst + (((2 * lane_g) ^ (px & 6)) << 4)) = o0;          // channels 16g .. 16g+7   = chunk 2g
+                    *(v8*)(dst + (((2 * lane_g + 1) ^ (px & 6)) << 4)) = o1;      // channels 16g+8 .. 16g+15 = chunk 2g + 1
+                }
+            }
+        }
+        __syncthreads();
+
+        // ================= phase B: conv2 (stride 2) over the LDS image, weights in registers =================
+        const char* hb = img + (2 * ph * 4) * SF_ROWPITCH;
+        f4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+        v8 xf[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) xf[0][mi] = *(const v8*)(hb + (2 * mi) * SF_ROWPITCH + xoff[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            const int tap = q >> 1, kk = q & 1;
+            if (q + 1 < 18) {
+                const int tap1 = (q + 1) >> 1, kk1 = (q + 1) & 1, ky1 = tap1 / 3, kx1 = tap1 - ky1 * 3;
+                const int o = xoff[kx1] ^ (kk1 << 6);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) xf[(q + 1) & 1][mi] = *(const v8*)(hb + (2 * mi + ky1) * SF_ROWPITCH + o);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[tap][kk][ni], xf[q & 1][mi], acc[ni][mi]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue: bias + ReLU, out[b][y][x][nb .. nb+7] for rows y = 8ty + 4ph + mi, column x = 16tx + s ----
+        const f4 t0 = *(const f4*)(sb2 + nb), t1 = *(const f4*)(sb2 + nb + 4);
+        const float bias[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        const int x = tx * HALO_TW + s;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int y = ty * HALO_TH + ph * 4 + mi;
+            if (y < p.H2 && x < p.W2) {
+                v8 ov;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[ni * 4 + r] = (T)fmaxf(acc[ni][mi][r] + bias[ni * 4 + r], 0.f);
+                *(v8*)(O + (((size_t)b * p.H2 + y) * p.W2 + x) * 64 + nb) = ov;
+            }
+        }
+    }
+}
+
 template <typename T>
 int launch_t(ConvParams& p, hipStream_t stream) {
     if (p.Cin == 64 && p.Cout == 64 && p.stride == 1 && tune_get("conv_halo", 1)) {
@@ -646,4 +822,46 @@ extern "C" int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const v
         return FVIT_EINVAL;
     }
     return check_launch("stem_conv_kernel");
+}
+
+extern "C" int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2,
+                               void* out, int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream) {
+    if (!in || !in->data || !w1 || !b1 || !w2 || !b2 || !out || B <= 0 || Hi <= 0 || Wi <= 0) {
+        set_error("stem_fused: null or empty argument");
+        return FVIT_EINVAL;
+    }
+    StemFusedParams p;
+    p.in = *in; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.B = B; p.Hi = Hi; p.Wi = Wi;
+    p.H1 = (Hi - 1) / 2 + 1; p.W1 = (Wi - 1) / 2 + 1;
+    p.H2 = (p.H1 - 1) / 2 + 1; p.W2 = (p.W1 - 1) / 2 + 1;
+    p.tiles_x = (p.W2 + HALO_TW - 1) / HALO_TW;
+    p.tiles_y = (p.H2 + HALO_TH - 1) / HALO_TH;
+    const int64_t tiles = (int64_t)B * p.tiles_x * p.tiles_y;
+    if (tiles > 0x7fffffff || (int64_t)B * p.H2 * p.W2 > 0x7fffffff) {
+        set_error("stem_fused: too many output pixels");
+        return FVIT_EINVAL;
+    }
+    p.tiles = (int)tiles;
+    int maxgrid = tune_get("stem_fused_grid", 512);
+    if (maxgrid < 8) maxgrid = 8;
+    const int grid = p.tiles < maxgrid ? p.tiles : maxgrid;
+    const size_t lds = 1024 + SF_LDS;
+    const double M1 = (double)B * p.H1 * p.W1, M2 = (double)B * p.H2 * p.W2;
+    const double bytes = (double)B * 3 * Hi * Wi * (in->dtype == FVIT_F32 ? 4 : 2) + 2.0 * M2 * 64;
+    ProfScope prof(FVIT_K_CONV, 2.0 * M1 * 64 * 27 + 2.0 * M2 * 64 * 576, bytes, (hipStream_t)stream);
+    if (dtype == FVIT_F16) {
+        static DeviceOnce once;
+        if (once.first_on_current_device())
+            hipFuncSetAttribute((const void*)stem_fused_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((stem_fused_kernel<_Float16>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    } else if (dtype == FVIT_BF16) {
+        static DeviceOnce once;
+        if (once.first_on_current_device())
+            hipFuncSetAttribute((const void*)stem_fused_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((stem_fused_kernel<__bf16>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    } else {
+        set_error("stem_fused: dtype %d not supported (16-bit output only)", dtype);
+        return FVIT_EINVAL;
+    }
+    return check_launch("stem_fused_kernel");
 }

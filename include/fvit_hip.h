@@ -289,6 +289,12 @@ int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weight, const f
 int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const void* weight, const float* bias, void* out,
                         int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream);
 
+/* Both convolutions of PatchEmbed in one kernel for in_dim = dim = 64 (FV:458-464): conv1 as above (w1, b1), then 3x3 stride 2 pad 1
+ * 64 -> 64 (w2 op16 [64][3][3][64], b2) + ReLU; the 112x112x64 intermediate lives in LDS only.  out: op16 [B][H2][W2][64] with
+ * H1 = (Hi-1)/2+1, H2 = (H1-1)/2+1 (same for W). */
+int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2,
+                    void* out, int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream);
+
 /* Performance-experiment knob (never changes results beyond fp32 summation order): e.g. "mlp_fused" 0/1,
  * "mlp_stagger" 0/1, "mlp_rb" 1/2.  Not thread safe; meant for A/B runs inside one process. */
 int fvit_tune(const char* key, int32_t value);

@@ -439,6 +439,48 @@ def test_stem_conv(dt, code, in_dt, fmt, B, H, W):
     assert (out.float() - ref).abs().max().item() < (4e-3 if dt == torch.float16 else 3e-2) * max(ref.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
+@pytest.mark.parametrize("in_dt,fmt,B,H,W", [(torch.float32, "nchw", 2, 224, 224), (torch.float16, "nhwc", 3, 64, 96), (torch.float32, "nchw", 1, 50, 38),
+                                            (torch.float32, "nhwc", 2, 36, 132), (torch.float32, "nchw", 5, 8, 8)])
+def test_stem_fused(dt, code, in_dt, fmt, B, H, W):
+    """Both PatchEmbed convs in one kernel (conv1 3->64 s2 + ReLU kept in LDS, conv2 64->64 s2 + ReLU) vs the two separate kernels
+    (same 16-bit rounding of the intermediate) and vs PyTorch fp32."""
+    import ctypes as C
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(H * 7 + W)
+    x = torch.randn(B, 3, H, W, generator=g).to(in_dt).cuda()
+    if fmt == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    w1 = (torch.randn(64, 3, 3, 3, generator=g) / 27 ** 0.5).cuda()
+    b1 = torch.randn(64, generator=g).cuda()
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) / 576 ** 0.5).to(dt).cuda()
+    b2 = torch.randn(64, generator=g).cuda()
+    wk1 = torch.zeros(64, 32, device="cuda")
+    wk1[:, :27] = w1.permute(0, 2, 3, 1).reshape(64, 27)
+    wk1 = wk1.to(dt).contiguous()
+    wk2 = w2.permute(0, 2, 3, 1).contiguous()
+    H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
+    view = hat_runtime._map_view(x)
+    out = torch.full((B, H2, W2, 64), float("nan"), dtype=dt, device="cuda")
+    _lib.check(lib.fvit_stem_fused(code, C.byref(view), wk1.data_ptr(), b1.data_ptr(), wk2.data_ptr(), b2.data_ptr(), out.data_ptr(), B, H, W,
+                                   _stream()), "stem_fused")
+    # the two-kernel path
+    mid = torch.empty(B, H1, W1, 64, dtype=dt, device="cuda")
+    _lib.check(lib.fvit_stem_conv3x3s2(code, C.byref(view), wk1.data_ptr(), b1.data_ptr(), mid.data_ptr(), B, H, W, _stream()), "stem")
+    two = torch.empty(B, H2, W2, 64, dtype=dt, device="cuda")
+    zeros = torch.zeros(256, dtype=dt, device="cuda")
+    _lib.check(lib.fvit_conv3x3_nhwc(code, mid.data_ptr(), wk2.data_ptr(), b2.data_ptr(), None, two.data_ptr(), B, H1, W1, 64, 64, 2, 1,
+                                     zeros.data_ptr(), _stream()), "conv2")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    scale = max(two.float().abs().max().item(), 1.0)
+    assert (out.float() - two.float()).abs().max().item() <= (2e-3 if dt == torch.float16 else 1.6e-2) * scale
+    ref1 = torch.relu(F.conv2d(x.float().to(dt).float(), wk1[:, :27].float().view(64, 3, 3, 3).permute(0, 3, 1, 2), b1, 2, 1)).to(dt).float()
+    ref = torch.relu(F.conv2d(ref1, w2.float(), b2, 2, 1)).permute(0, 2, 3, 1)
+    assert (out.float() - ref).abs().max().item() < (6e-3 if dt == torch.float16 else 4e-2) * max(ref.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize("fmt,dt", [("nchw", torch.float32), ("nhwc", torch.float16), ("nhwc", torch.bfloat16)])
 @pytest.mark.parametrize("C,res,ws,cw", [(64, (14, 14), 7, 2), (48, (6, 12), 3, 2), (32, (36, 60), 12, 2), (16, (8, 8), 4, 1)])
 def test_token_init(fmt, dt, C, res, ws, cw):
