@@ -583,6 +583,7 @@ constexpr int SF_PLANE = (HALO_TW + 1) * 128;                                // 
 constexpr int SF_ROWPITCH = 2 * SF_PLANE;                                    // plane E (17 px) then plane O (16 px + 1 unused)
 constexpr int SF_LDS = SF_ROWS * SF_ROWPITCH;                                // 73 984 B
 constexpr int SF_GROUPS = (SF_ROWS * SF_COLS + 15) / 16;                     // 36 groups of 16 conv1 pixels
+constexpr int SF_BATCH = 2;                                                  // groups whose gathers are in flight together (3 spills)
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
@@ -643,43 +644,62 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
             v8 w1f[4];
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) w1f[ni] = *(const v8*)(W1 + ((lane_s >> 2) * 16 + ni * 4 + (lane_s & 3)) * 32 + lane_g * 8);
-            const int64_t ibase = (int64_t)b * p.in.stride_b;
-            for (int grp = wave; grp < SF_GROUPS; grp += 4) {
-                const int q = grp * 16 + lane_s;
-                const int lr = q / SF_COLS, lc = q - lr * SF_COLS;
-                const int R = r0 + lr, Cc = c0 + lc;
-                const bool v1 = q < SF_ROWS * SF_COLS && R >= 0 && R < p.H1 && Cc >= 0 && Cc < p.W1;
-                const int yi = 2 * R - 1, xi = 2 * Cc - 1;
-                v8 xf;
+            // per-image base pointer is wave-uniform (SGPRs); per-lane offsets inside one image fit 32 bits
+            const int esz = p.in.dtype == FVIT_F32 ? 4 : 2;
+            const char* ib = (const char*)p.in.data + (int64_t)b * p.in.stride_b * esz;
+            const int sc = (int)p.in.stride_c, sh = (int)p.in.stride_h, sw = (int)p.in.stride_w;
+            // 9 groups per wave, SF_BATCH at a time: the scalar gathers of a batch are in flight together (with ~250 VGPRs there are
+            // only two waves per SIMD to hide their latency; one group at a time costs nine memory round trips per tile)
+            for (int g3 = wave; g3 < SF_GROUPS; g3 += 4 * SF_BATCH) {
+                v8 xfb[SF_BATCH];
+                int qv[SF_BATCH], lrv[SF_BATCH], lcv[SF_BATCH];
+                bool v1v[SF_BATCH];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = lane_g * 8 + e;
-                    const int ky = k / 9, r9 = k - ky * 9, kx = r9 / 3, c = r9 - kx * 3;
-                    const int y = yi + ky, x = xi + kx;
-                    const bool inb = v1 && k < 27 && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi;
-                    // always a legal address (the image's first element when masked), then select
-                    const int64_t off = inb ? ibase + c * p.in.stride_c + y * p.in.stride_h + x * p.in.stride_w : ibase;
-                    const float val = stem_load(p.in, off);
-                    xf[e] = (T)(inb ? val : 0.f);
-                }
-                f4 acc[4];
+                for (int u = 0; u < SF_BATCH; ++u) {
+                    const int q = (g3 + 4 * u) * 16 + lane_s;
+                    const int lr = q / SF_COLS, lc = q - lr * SF_COLS;
+                    const int R = r0 + lr, Cc = c0 + lc;
+                    const bool v1 = q < SF_ROWS * SF_COLS && R >= 0 && R < p.H1 && Cc >= 0 && Cc < p.W1;
+                    const int yi = 2 * R - 1, xi = 2 * Cc - 1;
+                    qv[u] = q; lrv[u] = lr; lcv[u] = lc; v1v[u] = v1;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[ni] = Op16<T>::mfma(w1f[ni], xf, (f4){0.f, 0.f, 0.f, 0.f});
-                if (q < SF_ROWS * SF_COLS) {
-                    v8 o0, o1;
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        const f4 bv = *(const f4*)(sb1 + lane_g * 16 + ni * 4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float y = v1 ? fmaxf(acc[ni][r] + bv[r], 0.f) : 0.f;   // outside the conv1 map: conv2's zero padding
-                            if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
-                        }
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = lane_g * 8 + e;
+                        const int ky = k / 9, r9 = k - ky * 9, kx = r9 / 3, c = r9 - kx * 3;
+                        const int y = yi + ky, x = xi + kx;
+                        const bool inb = v1 && k < 27 && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi;
+                        // always a legal address (the image's first element when masked), then select
+                        const int off = inb ? c * sc + y * sh + x * sw : 0;
+                        float val;
+                        if (p.in.dtype == FVIT_F32) val = ((const float*)ib)[off];
+                        else if (p.in.dtype == FVIT_F16) val = (float)((const _Float16*)ib)[off];
+                        else val = (float)((const __bf16*)ib)[off];
+                        xfb[u][e] = (T)(inb ? val : 0.f);
                     }
-                    const int px = lc >> 1;
-                    char* dst = img + lr * SF_ROWPITCH + (lc & 1) * SF_PLANE + px * 128;
-                    *(v8*)(dst + (((2 * lane_g) ^ (px & 6)) << 4)) = o0;          // channels 16g .. 16g+7   = chunk 2g
-                    *(v8*)(dst + (((2 * lane_g + 1) ^ (px & 6)) << 4)) = o1;      // channels 16g+8 .. 16g+15 = chunk 2g + 1
+                }
+#pragma unroll
+                for (int u = 0; u < SF_BATCH; ++u) {
+                    const int q = qv[u], lr = lrv[u], lc = lcv[u];
+                    const bool v1 = v1v[u];
+                    f4 acc[4];
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[ni] = Op16<T>::mfma(w1f[ni], xfb[u], (f4){0.f, 0.f, 0.f, 0.f});
+                    if (q < SF_ROWS * SF_COLS) {
+                        v8 o0, o1;
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const f4 bv = *(const f4*)(sb1 + lane_g * 16 + ni * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float y = v1 ? fmaxf(acc[ni][r] + bv[r], 0.f) : 0.f;   // outside the conv1 map: conv2's zero padding
+                                if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
+                            }
+                        }
+                        const int px = lc >> 1;
+                        char* dst = img + lr * SF_ROWPITCH + (lc & 1) * SF_PLANE + px * 128;
+                        *(v8*)(dst + (((2 * lane_g) ^ (px & 6)) << 4)) = o0;          // channels 16g .. 16g+7   = chunk 2g
+                        *(v8*)(dst + (((2 * lane_g + 1) ^ (px & 6)) << 4)) = o1;      // channels 16g+8 .. 16g+15 = chunk 2g + 1
+                    }
                 }
             }
         }
