@@ -286,3 +286,49 @@ def test_deploy_mode_stream_shards(streams):
     graph.replay()
     torch.cuda.synchronize()
     assert max_abs(static_y.float().cpu(), y.cpu()) < 2e-4
+
+
+def test_deploy_plan_options_agree():
+    """The deploy plan's switches change the kernels, not the result: fused two-conv stem vs stem + stride-2 conv (bit-identical),
+    channel-padded maps vs the MIOpen fallback for 24-channel maps, unequal shard sizes, the free-running ShardRunner, and
+    stage_forward writing into a strided view of a padded map."""
+    from fastervit_amd import hat_runtime
+    from fastervit_amd.conv_runtime import ShardRunner
+    model, _ = build_product_model("fvit0_224", "cuda")
+    x = case_input("fvit0_224").cuda()
+    model.switch_to_deploy(torch.float16)
+    plan = model.__dict__["_deploy_plan"]
+    with torch.no_grad():
+        ref = model(x).float()
+        plan.fused_stem = False
+        two = model(x).float()
+        plan.fused_stem = True
+        assert torch.equal(ref, two)
+        plan.streams, plan.shard_sizes = 3, [3, 1, 4]
+        uneven = model(x).float()
+        plan.streams, plan.shard_sizes = 1, None
+        assert max_abs(uneven.cpu(), ref.cpu()) < 2e-4
+        runner = ShardRunner(plan, x, 2)
+        runner.launch()
+        runner.launch()
+        assert max_abs(runner.outputs().float().cpu(), ref.cpu()) < 2e-4
+    # 24 / 48-channel conv side: padded to 64 (HIP conv kernels) vs unpadded (MIOpen + glue kernels)
+    g = load_golden("tiny_hier")
+    small, _ = build_product_model("tiny_hier", "cuda")
+    xs = case_input("tiny_hier").cuda()
+    small.switch_to_deploy(torch.float16)
+    with torch.no_grad():
+        a = small(xs).float().cpu()
+        small.switch_to_deploy(torch.float16)
+        small.__dict__["_deploy_plan"].pad_channels = False
+        b = small(xs).float().cpu()
+    assert rel_err(a, g["logits"]) < 1e-2 and rel_err(b, g["logits"]) < 1e-2 and rel_err(a, b) < 5e-3
+    # stage_forward with strided input / output views (first C channels of wider maps)
+    lvl = small.levels[2]
+    C = lvl.blocks[0].attn.qkv.in_features
+    xin = torch.randn(2, C + 40, 14, 14, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    out = torch.zeros(2, C + 24, 14, 14, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        dense = hat_runtime.stage_forward(lvl, xin[:, :C].contiguous(memory_format=torch.channels_last))
+        hat_runtime.stage_forward(lvl, xin[:, :C], out=out[:, :C])
+    assert torch.equal(out[:, :C], dense) and out[:, C:].abs().max().item() == 0.0
