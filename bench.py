@@ -188,7 +188,7 @@ def main():
         """HBM bytes per launch of the kernel family `kind` from the committed rocprofv3 PMC passes (profiles/, collected with
         scripts/gpu_prof.sh + scripts/pmc_traffic_summary.py on the same command in eager mode): bench.py cannot sample PMCs on
         itself.  Picks the (kernel, grid) row with the largest summed time, i.e. the launch shape that dominates the family."""
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic_by_kernel_v9.json")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic_by_kernel_v13.json")
         prefix = {"mlp_fused": "mlp_fused_kernel", "attn_block_fused": "attnblk_kernel", "gemm_bias": f"gemm_kernel<{args.operand},0",
                   "gemm_gelu": f"gemm_kernel<{args.operand},1", "gemm_residual": f"gemm_kernel<{args.operand},2"}.get(kind)
         if not shard_sized or prefix is None or not os.path.exists(path) or args.model != "faster_vit_0_224" or args.batch != 256:
@@ -197,7 +197,7 @@ def main():
         if not rows:
             return None, None
         r = max(rows, key=lambda r: r["total_us"])
-        return int(r["hbm_traffic_mb"] * 1e6), (f"profiles/r01_pmc_hbm_traffic_by_kernel_v9.json: {r['kernel']} x {r['workgroups']} workgroups, "
+        return int(r["hbm_traffic_mb"] * 1e6), (f"profiles/r01_pmc_hbm_traffic_by_kernel_v13.json: {r['kernel']} x {r['workgroups']} workgroups, "
                                                 f"read {r['hbm_read_mb']} MB (2 x FETCH_SIZE) + write {r['hbm_write_mb']} MB per launch")
 
     def kernel_table(pr):
