@@ -174,9 +174,11 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
 
 // the fused attention block wins once the launch fills the chip (92 vs 117 us at 54k rows); on the carrier branch (4k rows,
 // 32 workgroups) it is latency-bound and loses (38 vs 30 us)
+// C = 512 / 16 heads (stage 3): the fused instance is correct but loses end to end (66.0k vs 71.9k images/s, r01 sweep r41): one
+// workgroup per 49-token window streams 2 MiB of weights for 49 rows => opt-in (attn_fused512_min_rows)
 static bool fused_attn_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S, int64_t rows) {
     return w.w_qkv_frag && w.b_qkv_heads && w.w_proj_frag && d.dpad == 32 && d.C / d.heads == 32 && attnblk_supported(d.C, d.heads, S) &&
-           rows >= tune_get("attn_fused_min_rows", 16384) && tune_get("attn_fused", 1);
+           rows >= (d.C == 256 ? tune_get("attn_fused_min_rows", 16384) : tune_get("attn_fused512_min_rows", 1 << 30)) && tune_get("attn_fused", 1);
 }
 
 // LN -> fc1 + GELU -> fc2 + gamma-residual

@@ -1,4 +1,4 @@
-// fvit_attnblk.hip -- fused attention sub-block of HAT for head_dim 32, C = 256 (gfx950):
+// fvit_attnblk.hip -- fused attention sub-block of HAT for head_dim 32, C = 256 / 8 heads or C = 512 / 16 heads (gfx950):
 //
 //   x_out = x_in + gamma * proj( softmax( q k^T * scale + bias ) v ),   [q|k|v] = qkv( LayerNorm(x_in) )
 //   x_in  = gathered source row (+ position embedding row)              (AR:671-696 / FV:665-690)
@@ -60,11 +60,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 
 // NRB: row blocks (of 16 tokens) per window: 4 (S <= 64) or 1 (S <= 16); NW: waves per workgroup (8 or 4);
 // BIAS_LDS: stage the head's bias table in LDS (else read it from L2 with ordinary loads issued ahead of the DMA)
-template <typename T, int NRB, int NW, bool BIAS_LDS>
-__global__ __launch_bounds__(64 * NW, 2) void attnblk_kernel(AttnBlkParams p) {
+// CC: channels (256: stage 2 of FasterViT-0, 8 heads; 512: stage 3, 16 heads -- one 142-KiB workgroup per CU, one wave per SIMD,
+//     so the 128 + 128 + 64 VGPRs of input rows, proj accumulator and LayerNorm fragments fit without spilling)
+template <typename T, int CC, int NRB, int NW, bool BIAS_LDS>
+__global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(AttnBlkParams p) {
     typedef typename Op16<T>::v8 v8;
     typedef typename Op16<T>::v4 v4;
-    constexpr int C = 256, KK = C / 32, CB = C / 16;
+    constexpr int C = CC, KK = C / 32, CB = C / 16;
     constexpr int SP = NRB * 16;              // padded window length
     constexpr int WPW = NW / NRB;             // windows per workgroup
     constexpr int NKB32 = (NRB + 1) / 2;      // 32-key groups per window
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attnblk_kernel(AttnBlkParams p) {
     constexpr int VX_BYTES = WPW * 2 * NKB32 * 1024;
     constexpr int OFF_PROJ = QKV_BYTES, OFF_BIAS = OFF_PROJ + PROJ_BYTES, OFF_KX = OFF_BIAS + ((BIAS_BYTES + 1023) / 1024) * 1024;
     constexpr int OFF_VX = OFF_KX + KX_BYTES, OFF_BQ = OFF_VX + VX_BYTES;
-    constexpr int MAX_HEADS = 8;
+    constexpr int MAX_HEADS = CC / 32;
     __shared__ __attribute__((aligned(16))) char smem[OFF_BQ + MAX_HEADS * 96 * 4];
 
     const int tid = threadIdx.x;
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attnblk_kernel(AttnBlkParams p) {
     // GEMM k slot kk*32 + 8g + e carries input channel kch(kk, g, e) = (kk>>1)*64 + g*16 + (kk&1)*8 + e (w_qkv_frag is packed in
     // that order): the 64 values a lane gathers are then exactly the 64 output channels it owns in the proj accumulator, and
     // the residual epilogue uses them from registers instead of gathering the row a second time
+    constexpr bool KEEPX = CC == 256;   // C = 512: 128 more VGPRs next to the 128 of the proj accumulator would spill: re-gather instead
     v8 xf[KK];
     f4 v[KK][2];
     {
@@ -320,7 +323,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attnblk_kernel(AttnBlkParams p) {
             const int c0 = cg * 64 + g * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f4 xv = v[2 * cg + (q >> 1)][q & 1];   // channel c0 + 4q = kch(2cg + (q>>1), g, 4(q&1)): the gathered row, still in registers
+                f4 xv;
+                if (KEEPX) {
+                    xv = v[2 * cg + (q >> 1)][q & 1];   // channel c0 + 4q = kch(2cg + (q>>1), g, 4(q&1)): the gathered row, still in registers
+                } else {
+                    xv = *(const f4*)(src + c0 + q * 4);
+                    if (addp) xv += *(const f4*)(addp + c0 + q * 4);
+                }
                 const f4 bv = *(const f4*)(p.bproj + c0 + q * 4);
                 const f4 gv = p.gamma ? *(const f4*)(p.gamma + c0 + q * 4) : (f4){1.f, 1.f, 1.f, 1.f};
                 const f4 a = oacc[cg * 4 + q];
@@ -335,7 +344,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attnblk_kernel(AttnBlkParams p) {
 }  // namespace
 
 // S <= 16 uses the 16-token instance (bias tables padded to 16), 48 < S <= 64 the 64-token one (padded to 64)
-bool attnblk_supported(int C, int heads, int S) { return C == 256 && heads == 8 && ((S >= 1 && S <= 16) || (S > 48 && S <= 64)); }
+bool attnblk_supported(int C, int heads, int S) {
+    if (C == 256 && heads == 8) return (S >= 1 && S <= 16) || (S > 48 && S <= 64);
+    return C == 512 && heads == 16 && S > 48 && S <= 64;   // stage 3 of FasterViT-0: 7x7 windows, no carrier tokens
+}
 
 int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
     if (!attnblk_supported(c.C, c.heads, c.S) || c.nwin <= 0 || !c.wqkv_f || !c.wproj_f || !c.x_out) {
@@ -358,8 +370,10 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
     //    sub-block is bound by its three fp32 passes over X), but the smaller workgroups of variant 0 fill the chip better on
     //    the shard-sized launches of the stream-sharded deploy plan (+2..3 % images/s, r01 sweep r20)
     const int variant = tune_get("ab_variant", 0);
-#define FVIT_AB(T, NRB, NW, BL) hipLaunchKernelGGL((attnblk_kernel<T, NRB, NW, BL>), dim3((c.nwin + (NW / NRB) - 1) / (NW / NRB)), \
-                                                   dim3(64 * NW), 0, stream, p)
+#define FVIT_AB(T, NRB, NW, BL) do { \
+        if (c.C == 256) hipLaunchKernelGGL((attnblk_kernel<T, 256, NRB, NW, BL>), dim3((c.nwin + (NW / NRB) - 1) / (NW / NRB)), dim3(64 * NW), 0, stream, p); \
+        else hipLaunchKernelGGL((attnblk_kernel<T, 512, 4, 4, false>), dim3(c.nwin), dim3(256), 0, stream, p); \
+    } while (0)
     if (c.dtype == FVIT_F16) {
         if (small) FVIT_AB(_Float16, 1, 8, true);
         else if (variant == 1) FVIT_AB(_Float16, 4, 8, true);

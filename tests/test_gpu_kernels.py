@@ -505,13 +505,16 @@ def test_token_init(fmt, dt, C, res, ws, cw):
 
 
 @pytest.mark.parametrize("opname,dt,code", OPS)
-@pytest.mark.parametrize("S,nwin,use_tables,use_gamma", [(53, 9, True, True), (49, 4, False, False), (16, 13, True, True), (64, 3, False, True),
-                                                         (53, 1024, True, True), (16, 256, True, False)])
-def test_attn_block_fused(opname, dt, code, S, nwin, use_tables, use_gamma):
-    """gather + LayerNorm + qkv + attention + proj + gamma-residual in one kernel vs PyTorch fp32 on 16-bit-rounded weights."""
+@pytest.mark.parametrize("S,nwin,use_tables,use_gamma,C", [(53, 9, True, True, 256), (49, 4, False, False, 256), (16, 13, True, True, 256),
+                                                           (64, 3, False, True, 256), (53, 1024, True, True, 256), (16, 256, True, False, 256),
+                                                           (49, 85, False, True, 512), (49, 3, False, False, 512), (53, 8, True, True, 512)])
+def test_attn_block_fused(opname, dt, code, S, nwin, use_tables, use_gamma, C):
+    """gather + LayerNorm + qkv + attention + proj + gamma-residual in one kernel vs PyTorch fp32 on 16-bit-rounded weights
+    (C = 256 / 8 heads: stage 2 of FasterViT-0 and its carrier branch; C = 512 / 16 heads: stage 3)."""
     lib = _lib.lib()
-    C, heads, d = 256, 8, 32
-    assert lib.fvit_attn_block_supported(C, heads, S) == 1 and lib.fvit_attn_block_supported(512, 16, 49) == 0
+    heads, d = C // 32, 32
+    assert lib.fvit_attn_block_supported(C, heads, S) == 1 and lib.fvit_attn_block_supported(512, 16, 16) == 0 and \
+        lib.fvit_attn_block_supported(784, 16, 53) == 0
     g = torch.Generator(device="cpu").manual_seed(S * 131 + nwin)
     rows = nwin * S
     wins_per_img = 1 if S == 16 else (4 if nwin % 4 == 0 else 1)
