@@ -295,8 +295,13 @@ int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const void* weight
 int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2,
                     void* out, int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream);
 
-/* Performance-experiment knob (never changes results beyond fp32 summation order): e.g. "mlp_fused" 0/1,
- * "mlp_stagger" 0/1, "mlp_rb" 1/2.  Not thread safe; meant for A/B runs inside one process. */
+/* Performance-experiment knobs for A/B runs inside one process; the same keys can be preset through the environment as
+ * FVIT_TUNE_<key>=<int> (read once per key).  Kernel-selection knobs never change results beyond fp32 summation order:
+ *   "mlp_fused", "attn_fused" 0/1; "mlp_fused_min_rows", "attn_fused_min_rows", "mlp_fused512_min_rows", "attn_fused512_min_rows";
+ *   "mlp_variant" (-1 auto), "ab_variant", "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
+ *   "conv_halo_grid", "conv64_variant", "conv128_narrow", "stem_fused_grid".
+ * The "*_ablate" keys ("mlp_ablate", "ab_ablate", "conv_ablate", "conv_halo_ablate") switch off parts of a kernel for timing and
+ * DO produce wrong results.  Guarded by a mutex; launches read the values at launch time. */
 int fvit_tune(const char* key, int32_t value);
 
 /* ---- built-in kernel timer (HIP events around every launch, on the launch stream) ---- */
