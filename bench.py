@@ -92,6 +92,9 @@ def main():
         if args.shard_sizes:
             model.__dict__["_deploy_plan"].shard_sizes = sizes
 
+    if not deploy:
+        model.auto_deploy = False   # --mode module measures the plain nn.Module path (MIOpen convs), not the automatic deploy plan
+
     def forward(inp):
         with torch.no_grad():
             if deploy or conv_dt is None:

@@ -91,11 +91,23 @@ def test_fvit0_224_channels_last_and_autocast():
     model, _ = build_product_model("fvit0_224", "cuda")
     model = model.to(memory_format=torch.channels_last)
     x = case_input("fvit0_224").cuda().contiguous(memory_format=torch.channels_last)
+    assert model.auto_deploy
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        logits = model(x).float().cpu()
-    err = max_abs(logits, g["logits"])
-    print(f"faster_vit_0_224 autocast-fp16 + channels_last logits max-abs err {err:.3e}")
-    assert err < 4e-3
+        out = model(x)
+        assert out.dtype == torch.float16 and "_auto_plans" in model.__dict__   # validate.py --amp: the automatic deploy plan
+        logits = out.float().cpu()
+        model.auto_deploy = False
+        plain = model(x).float().cpu()                                           # plain nn.Module path (MIOpen convs under autocast)
+    err, err_plain = max_abs(logits, g["logits"]), max_abs(plain, g["logits"])
+    print(f"faster_vit_0_224 autocast-fp16 + channels_last logits max-abs err {err:.3e} (auto deploy plan), {err_plain:.3e} (module path)")
+    assert err < 4e-3 and err_plain < 4e-3
+    # outside autocast, with grad enabled, or in train mode nothing is switched automatically
+    model.auto_deploy = True
+    assert model._autocast_plan(x) is None
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert model._autocast_plan(x) is None                                  # grad enabled
+        with torch.no_grad():
+            assert model._autocast_plan(x) is not None
 
 
 def test_fvit0_224_stage_maps_vs_reference():
