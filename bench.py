@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--input-size", default="", help="HxW override (secondary configs, e.g. 576x960)")
     ap.add_argument("--operand", default="f16", choices=["f16", "bf16"], help="MFMA operand type of the HAT kernels")
     ap.add_argument("--conv-dtype", default="f16", choices=["f16", "bf16", "f32"], help="dtype of the PyTorch-ROCm conv side")
-    ap.add_argument("--mode", default="deploy", choices=["deploy", "module"],
+    ap.add_argument("--mode", default="deploy", choices=["deploy", "module", "auto"],
                     help="deploy: BN folded into convs + fused glue kernels (switch_to_deploy); module: nn.Module forward under autocast")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--streams", type=int, default=3,
@@ -93,7 +93,9 @@ def main():
             model.__dict__["_deploy_plan"].shard_sizes = sizes
 
     if not deploy:
-        model.auto_deploy = False   # --mode module measures the plain nn.Module path (MIOpen convs), not the automatic deploy plan
+        # --mode module measures the plain nn.Module path (MIOpen convs); --mode auto the same call under autocast with the
+        # automatic deploy plan (what validate.py --amp gets)
+        model.auto_deploy = args.mode == "auto"
 
     def forward(inp):
         with torch.no_grad():
@@ -282,7 +284,8 @@ def main():
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent shards, no data-path collective)",
                    "hat_operands": args.operand, "conv_side": (f"deploy plan: BN folded, {args.conv_dtype} channels_last, fused HIP conv3x3 (halo-tiled / implicit-GEMM) + stem + LayerNorm2d "
                                                "kernels (MIOpen only for channel counts the kernels do not cover; none in this model)"
-                                 if deploy else f"PyTorch-ROCm nn.Module forward, channels_last, autocast {args.conv_dtype}"),
+                                 if deploy else (f"model(x) under autocast {args.conv_dtype}: automatic deploy plan (single stream)" if args.mode == "auto"
+                                                 else f"PyTorch-ROCm nn.Module forward, channels_last, autocast {args.conv_dtype}")),
                    "launch": (f"{args.streams} free-running stream shards, one hipGraph replay per shard and step, no join between steps" if runner is not None
                               else ("hipGraph replay" if graph is not None else "eager") + (f", {args.streams} stream shards (fork/join)" if deploy and args.streams > 1 else ""))},
         "roofline": roofline, "roofline_isolated": roofline_isolated, "cpu_baseline": cpu, "parity": parity,
