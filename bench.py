@@ -284,7 +284,7 @@ def main():
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent shards, no data-path collective)",
                    "hat_operands": args.operand, "conv_side": (f"deploy plan: BN folded, {args.conv_dtype} channels_last, fused HIP conv3x3 (halo-tiled / implicit-GEMM) + stem + LayerNorm2d "
                                                "kernels (MIOpen only for channel counts the kernels do not cover; none in this model)"
-                                 if deploy else (f"model(x) under autocast {args.conv_dtype}: automatic deploy plan (single stream)" if args.mode == "auto"
+                                 if deploy else (f"model(x) under autocast {args.conv_dtype}: automatic deploy plan ({model.auto_deploy_streams} stream shards)" if args.mode == "auto"
                                                  else f"PyTorch-ROCm nn.Module forward, channels_last, autocast {args.conv_dtype}")),
                    "launch": (f"{args.streams} free-running stream shards, one hipGraph replay per shard and step, no join between steps" if runner is not None
                               else ("hipGraph replay" if graph is not None else "eager") + (f", {args.streams} stream shards (fork/join)" if deploy and args.streams > 1 else ""))},

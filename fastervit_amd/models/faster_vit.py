@@ -460,6 +460,7 @@ class FasterViT(nn.Module):
     #: from the module path).  That is the configuration of the reference's ``validate.py --amp``: 2x faster with no call-site
     #: change.  Set ``model.auto_deploy = False`` (or FVIT_AUTO_DEPLOY=0) for the plain nn.Module path.
     auto_deploy = os.environ.get("FVIT_AUTO_DEPLOY", "1") != "0"
+    auto_deploy_streams = 3   # stream shards of the automatic plan (batches of fewer than 2 x this many images run unsharded)
 
     def _autocast_plan(self, x):
         if (not self.auto_deploy or self.training or not x.is_cuda or torch.is_grad_enabled() or not torch.is_autocast_enabled()
@@ -472,6 +473,7 @@ class FasterViT(nn.Module):
         if dt not in plans:
             from ..conv_runtime import DeployPlan
             plans[dt] = DeployPlan(self, dt)
+            plans[dt].streams = int(self.auto_deploy_streams)
         return plans[dt], dt
 
     def forward(self, x):
