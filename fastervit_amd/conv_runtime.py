@@ -1,20 +1,26 @@
 """Deploy-mode plan for the conv side of FasterViT.
 
-The convolutions stay PyTorch-ROCm / MIOpen (north_star), but everything around them that is
-input-independent or elementwise is removed from the per-forward path:
+In module mode the convolutions are plain PyTorch-ROCm / MIOpen modules (north_star's drop-in default).  The deploy plan
+runs the conv side through this library's own kernels instead and removes everything input-independent from the
+per-forward path:
 
   * BatchNorm (eval) is folded into the preceding conv's weights and bias at load:
         PatchEmbed  conv(no bias)+BN(eps 1e-4)          (FV:458-463)
         ConvBlock   conv1+BN1, conv2+BN2 (+gamma)        (FV:490-512)
         final BN + AdaptiveAvgPool2d(1) + head           (FV:925-927, 953-960) -> one fp32 Linear on the pooled map
-    exact in real arithmetic; weights are kept as 16-bit channels_last tensors, so there is no autocast
-    and no per-forward cast of parameters.
-  * conv bias + activation, conv bias + residual and timm's LayerNorm2d run as single HBM passes in
-    hand-written HIP kernels (csrc/fvit_glue.hip) instead of MIOpen BN / OpTensor + several ATen kernels.
-  * The transformer stages are the same `fvit_hat_stage_forward` calls as in module mode.
+    exact in real arithmetic; weights are kept as 16-bit channels_last tensors ([Cout][3][3][Cin] matrices), so there is
+    no autocast and no per-forward cast of parameters.
+  * every 3x3 convolution (+ folded bias + ReLU / GELU + residual) is ONE hand-written HIP kernel (csrc/fvit_conv.hip:
+    implicit-GEMM, halo-tiled 64-channel conv, fused two-conv stem); channel counts that are not a multiple of 64 are
+    zero-padded to one (``pad_channels``).  MIOpen (``F.conv2d``) + the glue passes of csrc/fvit_glue.hip remain only as the
+    fallback for shapes those kernels do not cover (``pad_channels = False`` or ``use_hip_conv = False``).
+  * timm's LayerNorm2d (Downsample) is one HBM pass (``ln2d_kernel``).
+  * The transformer stages are the same ``fvit_hat_stage_forward`` calls as in module mode.
 
-Enabled by `FasterViT.switch_to_deploy()`; module mode (plain nn.Module forward, any dtype / autocast)
-remains the default so that the reference's scripts run unchanged.
+Enabled by ``FasterViT.switch_to_deploy()`` (explicit) or automatically for eval-mode forwards under ``torch.autocast`` with grad
+disabled (``FasterViT.auto_deploy``); module mode (plain nn.Module forward, any dtype) remains the default so that the
+reference's scripts run unchanged.  Logits of the 16-bit plan differ from the fp32 reference by the conv side's 16-bit rounding:
+measured 6.5e-4 .. 9.5e-4 max-abs on FasterViT-0 (asserted < 1e-3 in tests/test_gpu_parity.py).
 """
 from __future__ import annotations
 
@@ -28,8 +34,8 @@ from . import _lib, hat_runtime
 _CODE = {torch.float16: _lib.FVIT_F16, torch.bfloat16: _lib.FVIT_BF16}
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _bn_scale_shift(bn):
@@ -61,6 +67,7 @@ class DeployPlan:
         self.zeros = None
         self.streams = 1      # > 1: run the batch as that many shards on separate HIP streams
         self.side = None
+        self.dev = None       # device of the current forward (raw-pointer launches go to torch's current stream on THIS device)
         self.use_hip_conv = True  # fused implicit-GEMM conv kernel where the shape allows; False = MIOpen + glue passes
         # conv-side maps carry their channels padded to a multiple of 64 (zeros), weights / biases / LayerNorm2d parameters are
         # zero-padded to match: every 3x3 conv then runs on the fused HIP kernel (FasterViT-1/2/4: 80 / 96 / 196 / 392 channels
@@ -121,7 +128,7 @@ class DeployPlan:
                 self.zeros = torch.zeros(256, dtype=self.dtype, device=x.device)
             rc = _lib.lib().fvit_conv3x3_nhwc(self.code, x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
                                               residual.data_ptr() if residual is not None else None, out.data_ptr(), B, Hi, Wi,
-                                              Ci, Co, stride, act, self.zeros.data_ptr(), _stream())
+                                              Ci, Co, stride, act, self.zeros.data_ptr(), _stream(self.dev))
             _lib.check(rc, "fvit_conv3x3_nhwc")
             return out
         y = F.conv2d(x, wcl, None, stride, 1)
@@ -165,7 +172,12 @@ class DeployPlan:
                              self._padv(ds.norm.bias.float(), self._cp(cin)).contiguous(), float(ds.norm.eps),
                              self._cw(ds.reduction[0].weight.float()), cin)
             t["levels"].append(e)
-        hw, hb = m.head.weight.float(), m.head.bias.float()
+        if isinstance(m.head, torch.nn.Linear):
+            hw = m.head.weight.float()
+            hb = m.head.bias.float() if m.head.bias is not None else torch.zeros(hw.shape[0], device=hw.device)
+        else:   # num_classes = 0: nn.Identity head, the pooled (normalised) features are the output (FV:927)
+            nf = m.norm.weight.numel()
+            hw, hb = torch.eye(nf, device=m.norm.weight.device), torch.zeros(nf, device=m.norm.weight.device)
         if isinstance(m.norm, torch.nn.BatchNorm2d):
             s, sh = _bn_scale_shift(m.norm)
             t["head"] = ((hw * s.view(1, -1)).contiguous(), (hb + hw @ sh).contiguous(), None)
@@ -178,7 +190,7 @@ class DeployPlan:
     def _bias_act(self, x, bias, act):
         B, C, H, W = x.shape
         assert x.is_contiguous(memory_format=torch.channels_last) and x.dtype == self.dtype
-        _lib.check(_lib.lib().fvit_bias_act_cl(self.code, x.data_ptr(), bias.data_ptr(), B * H * W, C, act, _stream()),
+        _lib.check(_lib.lib().fvit_bias_act_cl(self.code, x.data_ptr(), bias.data_ptr(), B * H * W, C, act, _stream(self.dev)),
                    "fvit_bias_act_cl")
         return x
 
@@ -186,7 +198,7 @@ class DeployPlan:
         B, C, H, W = x.shape
         assert x.is_contiguous(memory_format=torch.channels_last) and y.is_contiguous(memory_format=torch.channels_last)
         _lib.check(_lib.lib().fvit_bias_residual_cl(self.code, x.data_ptr(), y.data_ptr(), bias.data_ptr(), B * H * W, C,
-                                                    _stream()), "fvit_bias_residual_cl")
+                                                    _stream(self.dev)), "fvit_bias_residual_cl")
         return x
 
     def _ln2d(self, x, w, b, eps, c_valid=None):
@@ -199,7 +211,7 @@ class DeployPlan:
             return y.to(self.dtype).contiguous(memory_format=torch.channels_last)
         out = torch.empty_like(x)
         _lib.check(_lib.lib().fvit_layernorm2d_cl(self.code, x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(), eps,
-                                                  B * H * W, C, cv, _stream()), "fvit_layernorm2d_cl")
+                                                  B * H * W, C, cv, _stream(self.dev)), "fvit_layernorm2d_cl")
         return out
 
     def _tokenizer(self, tok):
@@ -221,43 +233,66 @@ class DeployPlan:
                 self._build()
             self.sig = sig
 
+    def _enter(self, x):
+        """Per-call checks: GPU input on the model's device; launches below go to torch's current stream on that device."""
+        if not x.is_cuda:
+            raise RuntimeError("deploy plan: the input must be on a HIP device (no CPU fallback)")
+        p0 = next(self.model.parameters())
+        if p0.device != x.device:
+            raise RuntimeError(f"deploy plan: model parameters are on {p0.device} but the input is on {x.device}")
+        self.dev = x.device
+
+    def _hat_prepared(self, device):
+        return self.zeros is not None and self.zeros.device == device and all(
+            hat_runtime.is_prepared(lvl, device) for lvl in self.model.levels if lvl.transformer_block and len(lvl.blocks))
+
     def forward_single(self, x):
         """One shard on the caller's stream and current workspace slot (no sharding)."""
-        self._refresh()
-        return self._forward_one(x)
+        self._enter(x)
+        with torch.cuda.device(x.device):
+            self._refresh()
+            return self._forward_one(x)
 
     def forward(self, x):
-        self._refresh()
+        self._enter(x)
+        with torch.cuda.device(x.device):
+            self._refresh()
+            return self._forward_sharded(x)
+
+    def _forward_sharded(self, x):
         n = self.streams
         if n <= 1 or x.shape[0] < 2 * n:
-            hat_runtime.set_workspace_slot(0)
-            return self._forward_one(x)
+            with hat_runtime.workspace_slot(0):
+                return self._forward_one(x)
         # the batch as n independent shards on n HIP streams (fork / join with events; capturable in a hipGraph): every kernel
         # of this pipeline runs its HBM-bound prologue / epilogue and its MFMA phase in lockstep across workgroups, so two
         # half-size pipelines interleave better than one full-size one
         sizes = getattr(self, "shard_sizes", None)
         parts = x.split(list(sizes), dim=0) if sizes and sum(sizes) == x.shape[0] and len(sizes) == n else x.chunk(n, dim=0)
         outs = [None] * n
-        if getattr(self, "serialize_shards", False):
-            # measurement aid (bench.py's HIP-event pass): the same shard-sized launches, one after the other on the caller's
-            # stream, so that a kernel's event-pair duration is its own and not shared with the other shards' kernels
+        # weight packing (hat_runtime._prepare) and the zero page are created lazily by the first shard that needs them, on ITS
+        # stream; the other streams forked before that work was enqueued and would read half-written packed weights.  Until
+        # everything is packed for this device, run the shards one after the other on the caller's stream (first call, or the
+        # first call after a weight update).
+        serial = getattr(self, "serialize_shards", False) or not self._hat_prepared(x.device)
+        if serial:
+            # also the measurement aid of bench.py's HIP-event pass: the same shard-sized launches, one after the other on the
+            # caller's stream, so that a kernel's event-pair duration is its own and not shared with the other shards' kernels
             for i in range(n):
-                hat_runtime.set_workspace_slot(i)
-                outs[i] = self._forward_one(parts[i])
-            hat_runtime.set_workspace_slot(0)
+                with hat_runtime.workspace_slot(i):
+                    outs[i] = self._forward_one(parts[i])
             return torch.cat(outs, dim=0)
-        if self.side is None or len(self.side) != n - 1:
+        if self.side is None or len(self.side) != n - 1 or self.side[0].device != x.device:
             self.side = [torch.cuda.Stream(device=x.device) for _ in range(n - 1)]
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(x.device)
         for i, s in enumerate(self.side):
             s.wait_stream(main)
-            with torch.cuda.stream(s):
-                hat_runtime.set_workspace_slot(i + 1)
+            with torch.cuda.stream(s), hat_runtime.workspace_slot(i + 1):
                 outs[i + 1] = self._forward_one(parts[i + 1])
-        hat_runtime.set_workspace_slot(0)
-        outs[0] = self._forward_one(parts[0])
+        with hat_runtime.workspace_slot(0):
+            outs[0] = self._forward_one(parts[0])
         for s in self.side:
-            main.wait_stream(s)
+            main.wait_stream(s)   # join: everything the caller enqueues next (the cat below, its own later work) is ordered after the shards
         return torch.cat(outs, dim=0)
 
     def shard_runner(self, x, n=None):
@@ -277,7 +312,7 @@ class DeployPlan:
                                 memory_format=torch.channels_last)
                 view = hat_runtime._map_view(x)
                 _lib.check(_lib.lib().fvit_stem_fused(self.code, view, t["stem_k"].data_ptr(), b0.data_ptr(), wk1.data_ptr(),
-                                                      b1.data_ptr(), y.data_ptr(), B, Hi, Wi, _stream()), "fvit_stem_fused")
+                                                      b1.data_ptr(), y.data_ptr(), B, Hi, Wi, _stream(self.dev)), "fvit_stem_fused")
                 x = y
             elif t["stem_k"] is not None and x.shape[1] == 3 and x.dtype in hat_runtime._DT:
                 B, _, Hi, Wi = x.shape   # fused stem kernel reads the caller's image in place (any strides, fp32/16-bit)
@@ -285,7 +320,7 @@ class DeployPlan:
                                 memory_format=torch.channels_last)
                 view = hat_runtime._map_view(x)
                 _lib.check(_lib.lib().fvit_stem_conv3x3s2(self.code, view, t["stem_k"].data_ptr(), b0.data_ptr(), y.data_ptr(),
-                                                          B, Hi, Wi, _stream()), "fvit_stem_conv3x3s2")
+                                                          B, Hi, Wi, _stream(self.dev)), "fvit_stem_conv3x3s2")
                 x = self._conv(y, w1, b1, 2, 1)
             else:
                 x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
@@ -338,18 +373,15 @@ class ShardRunner:
         self.graphs, self.outs = [], []
         torch.cuda.synchronize()
         for i, (st, xi) in enumerate(zip(self.streams, self.inputs)):
-            with torch.cuda.stream(st), torch.no_grad():
-                hat_runtime.set_workspace_slot(i)
+            with torch.cuda.stream(st), torch.no_grad(), hat_runtime.workspace_slot(i):
                 for _ in range(2):           # warm-up on this stream: packs weights, sizes this slot's workspaces
                     plan.forward_single(xi)
             st.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g, stream=st):
-                hat_runtime.set_workspace_slot(i)
+            with torch.no_grad(), torch.cuda.graph(g, stream=st), hat_runtime.workspace_slot(i):
                 y = plan.forward_single(xi)
             self.graphs.append(g)
             self.outs.append(y)
-        hat_runtime.set_workspace_slot(0)
         torch.cuda.synchronize()
 
     def set_input(self, x):

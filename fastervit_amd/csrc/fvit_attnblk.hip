@@ -51,6 +51,9 @@ struct AttnBlkParams {
     float scale;
     int ablate;  // timing experiments only (wrong results): 1 = no weight DMA inside the head loop, 2 = skip P1 MFMAs,
                  // 4 = skip exchange + P2, 8 = skip P3
+    int stagger; // 1: workgroup b walks the heads starting at head (b / 8) % heads (b % 8 = XCD, observed): the workgroups of an XCD
+                 // stream different weight slices at any time, so a slice is fetched from the memory side once per XCD and found in
+                 // L2 by the other workgroups (in lockstep they all wait on the same outstanding miss)
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
@@ -120,7 +123,9 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
     if (NRB == 1) {   // the upper half of every 32-key group never gets written: keep it finite
         for (int i = tid; i < VX_BYTES / 4; i += 64 * NW) ((float*)(smem + OFF_VX))[i] = 0.f;
     }
-    dma_qkv(0);
+    const int hrot = p.stagger ? (int)((blockIdx.x >> 3) % (unsigned)p.heads) : 0;
+    auto head_of = [&](int it) { const int hh = it + hrot; return hh >= p.heads ? hh - p.heads : hh; };
+    dma_qkv(head_of(0));
 
     const float* src;
     const float* addp = nullptr;
@@ -194,7 +199,8 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
     char* kx = smem + OFF_KX;
     char* vx = smem + OFF_VX;
 
-    for (int h = 0; h < p.heads; ++h) {
+    for (int hit = 0; hit < p.heads; ++hit) {
+        const int h = head_of(hit);
         // ---- barrier A: qkv slice of head h landed; every wave is done with P2/P3 of head h-1 ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
         // ---- barrier B: proj / bias slices landed, k / v visible, qkv buffer free ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (h + 1 < p.heads && !(p.ablate & 1)) dma_qkv(h + 1);
+        if (hit + 1 < p.heads && !(p.ablate & 1)) dma_qkv(head_of(hit + 1));
 
         // ---- P2: scores^T, softmax over keys, O^T ----
         f4 sc[NRB];
@@ -360,6 +366,7 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
     p.wqkv_f = c.wqkv_f; p.bqkv = c.bqkv; p.wproj_f = c.wproj_f; p.bproj = c.bproj; p.gamma = c.gamma; p.bias = c.bias;
     p.x_out = c.x_out; p.nwin = c.nwin; p.S = c.S; p.heads = c.heads; p.scale = c.scale;
     p.ablate = tune_get("ab_ablate", 0);
+    p.stagger = tune_get("ab_stagger", 0);
     const double rows = (double)c.nwin * c.S;
     const double flops = 2.0 * rows * c.C * 4.0 * c.C + 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * 32.0;
     const double bytes = 8.0 * rows * c.C + 8.0 * c.C * c.C;

@@ -38,6 +38,7 @@ struct GemmParams {
     int lda, ldw, ldo;
     int M, N, K;
     int tiles_m, tiles_n;
+    int stagger;  // 1: workgroup (tm, tn) walks the K tiles starting at a tile-dependent offset (see gemm_kernel)
 };
 
 // swizzle of the 16-byte chunk index inside a 128-byte LDS row.
@@ -111,13 +112,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
         for (int j = 0; j < MI; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
+    // K-order stagger: the workgroups of an XCD that share an activation panel (same tm) or a weight panel (same tn) start at
+    // different K tiles, so a panel chunk is fetched from the memory side by ONE of them and found in L2 by the others when
+    // they get there; in lockstep every sharer waits on the same outstanding miss (hit-under-miss = full memory latency for
+    // all of them, every K step).  The sum order changes per tile but is fixed per (tm, tn): results stay bit-reproducible.
+    int rot = 0;
+    if (p.stagger) {
+        const int per = p.tiles_n < nk ? nk / p.tiles_n : 1;
+        rot = (tn * per + tm) % nk;
+    }
+    auto ktile = [&](int kt) { const int k = kt + rot; return k >= nk ? k - nk : k; };
     char* const xring = smem;
     char* const wring = smem + NSTAGE * XT_BYTES;
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st) {
         if (st < nk) {
-            stage_tile<T, false, BMT, NW>(A, p.lda, m0, st * BK, xring + st * XT_BYTES, wave, lane);
-            stage_tile<T, true, 128, NW>(W, p.ldw, n0, st * BK, wring + st * TILE_BYTES, wave, lane);
+            stage_tile<T, false, BMT, NW>(A, p.lda, m0, ktile(st) * BK, xring + st * XT_BYTES, wave, lane);
+            stage_tile<T, true, 128, NW>(W, p.ldw, n0, ktile(st) * BK, wring + st * TILE_BYTES, wave, lane);
         }
     }
 
@@ -146,8 +157,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             int slot = cur + NSTAGE - 1;
             if (slot >= NSTAGE) slot -= NSTAGE;
             if (nxt < nk) {
-                stage_tile<T, false, BMT, NW>(A, p.lda, m0, nxt * BK, xring + slot * XT_BYTES, wave, lane);
-                stage_tile<T, true, 128, NW>(W, p.ldw, n0, nxt * BK, wring + slot * TILE_BYTES, wave, lane);
+                stage_tile<T, false, BMT, NW>(A, p.lda, m0, ktile(nxt) * BK, xring + slot * XT_BYTES, wave, lane);
+                stage_tile<T, true, 128, NW>(W, p.ldw, n0, ktile(nxt) * BK, wring + slot * TILE_BYTES, wave, lane);
             }
         }
         const char* xt = xring + cur * XT_BYTES;
@@ -238,6 +249,7 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.lda = c.lda; p.ldw = c.ldw; p.ldo = c.ldo;
     p.M = c.M; p.N = c.N; p.K = c.K;
     p.tiles_n = (c.N + BN - 1) / BN;
+    p.stagger = tune_get("gemm_stagger", 0);
     const int grid128 = ((c.M + 127) / 128) * p.tiles_n;
     // tile / workgroup shape by grid size (fvit_tune knobs for A/B):
     //   grid128 <= bm64_max : 64-row tiles (twice the workgroups; +2 % images/s on shard-sized launches), else 128-row tiles

@@ -42,7 +42,7 @@ struct MlpParams {
     const float* gamma;  // [C] or null
     float eps;
     int M, hidden;
-    int stagger;  // 1: workgroup b walks the hidden chunks starting at chunk b % nchunk (spreads the L2 channel load)
+    int stagger;  // 1: workgroup b walks the hidden chunks starting at chunk b % nchunk; 2: offsets spread evenly over the workgroups of an XCD
     int ablate;   // timing experiments only (results are wrong): bit 0 = GELU -> identity, bit 1 = skip weight staging
 };
 
@@ -82,7 +82,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
     const int g = lane >> 4, s = lane & 15;
     const int row0 = blockIdx.x * (NW * ROWS_PER_WAVE) + wave * ROWS_PER_WAVE;
     const int nchunk = p.hidden / 32;
-    const int jofs = p.stagger ? (int)(blockIdx.x % (unsigned)nchunk) : 0;
+    int jofs = 0;
+    if (p.stagger == 1) jofs = (int)(blockIdx.x % (unsigned)nchunk);
+    else if (p.stagger == 2) {   // even spread over the workgroups of one XCD (blockIdx % 8 = XCD, observed)
+        const int per_xcd = (gridDim.x + 7) >> 3, idx = blockIdx.x >> 3;
+        jofs = per_xcd < nchunk ? (idx * nchunk) / per_xcd : idx % nchunk;
+    }
     auto chunk_of = [&](int it) { int j = it + jofs; return j >= nchunk ? j - nchunk : j; };
 
     const char* __restrict__ W1 = (const char*)p.w1f;

@@ -17,7 +17,10 @@ Constant folding (done once per weight version):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
+import warnings
 from typing import Optional
 
 import torch
@@ -42,8 +45,19 @@ def _require_gpu(t: torch.Tensor, what: str) -> None:
             "there is no CPU or eager fallback. Move the model and input to the GPU.")
 
 
-def _stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream_ptr(device=None) -> int:
+    """Raw hipStream_t of torch's current stream ON ``device`` (not on the thread's current device: a model moved with
+    ``.to('cuda:1')`` and called while cuda:0 is current must launch on a cuda:1 stream)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _check_device(x: torch.Tensor, layer, what: str) -> None:
+    """The kernels dereference raw pointers: parameters and input must live on the same GPU."""
+    for p in layer.parameters():
+        if p.device != x.device:
+            raise RuntimeError(f"{what}: parameters are on {p.device} but the input is on {x.device}; move the model with "
+                               f".to('{x.device}') (there is no implicit cross-device copy on the HIP path)")
+        break
 
 
 def _map_view(t: torch.Tensor) -> FvitMapView:
@@ -233,8 +247,16 @@ def pack_block(blk, S: int, G: int, dpad: int, op_dtype, keep: _Keep) -> FvitBlo
     return w
 
 
-def _signature(blocks, device, op_name):
+def _signature(blocks, device, op_name, replica=False):
+    """Identity of the weights the packed copies were made from: (data_ptr, version) of every parameter.  Replicas made by
+    ``nn.DataParallel`` are fresh broadcast copies on every forward (version 0, addresses reused by the caching allocator), so for
+    them the signature is a content checksum instead (one small reduction + host sync per stage: DataParallel is the reference's
+    legacy multi-GPU path, validate.py:243-244; the per-process runner scripts/run_sharded_validate.py has no such cost)."""
     sig = [str(device), op_name]
+    if replica:
+        ps = [p.detach().float().sum() for blk in blocks for p in blk.parameters()]
+        sig.append(tuple(torch.stack(ps).double().cpu().tolist()) if ps else ())
+        return tuple(sig)
     for blk in blocks:
         for p in blk.parameters():
             sig.append((p.data_ptr(), p._version))
@@ -244,23 +266,45 @@ def _signature(blocks, device, op_name):
 # --------------------------------------------------------------------------------------------
 # per-layer runtime state
 # --------------------------------------------------------------------------------------------
+class _Workspace:
+    """One zero-initialised scratch allocation of a stage geometry + the bookkeeping that makes sharing it between HIP streams safe."""
+    __slots__ = ("desc", "buf", "last_stream", "event")
+
+    def __init__(self, desc, buf):
+        self.desc, self.buf = desc, buf
+        self.last_stream = None
+        self.event = None
+
+
 class StageState:
-    """Packed weights + tables + workspaces of one FasterViTLayer (cached on the module)."""
+    """Packed weights + tables + workspaces of one FasterViTLayer ON ONE DEVICE (cached on the module, keyed by device)."""
 
     def __init__(self):
         self.sig = None
         self.keep = None
         self.blocks_c = None
         self.tables = {}      # (Hp, Wp) -> (dict of device tensors, FvitStageTables)
-        self.workspaces = {}  # (B, Hp, Wp, H, W) -> (desc, uint8 tensor)
+        self.workspaces = {}  # (B, Hp, Wp, H, W, operand dtype, slot) -> _Workspace
+        self.lock = threading.RLock()   # packing and the launches of one stage are enqueued under this lock
 
 
-def _state(layer) -> StageState:
-    st = layer.__dict__.get("_fvit_state")
-    if st is None:
-        st = StageState()
-        layer.__dict__["_fvit_state"] = st  # plain attribute: not a submodule, not in state_dict
-    return st
+_STATE_LOCK = threading.Lock()
+
+
+def _state(layer, device) -> StageState:
+    """Per-device runtime state.  ``nn.DataParallel.replicate()`` shallow-copies ``__dict__``, so every replica of a layer sees the SAME
+    dict object here; keying it by device gives each replica (one per GPU, driven by its own host thread) its own packed weights,
+    tables and workspaces."""
+    with _STATE_LOCK:
+        states = layer.__dict__.get("_fvit_state")
+        if states is None:
+            states = {}
+            layer.__dict__["_fvit_state"] = states  # plain attribute: not a submodule, not in state_dict
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        st = states.get(key)
+        if st is None:
+            st = states[key] = StageState()
+        return st
 
 
 def _geometry(layer, Hp: int, Wp: int):
@@ -275,7 +319,7 @@ def _geometry(layer, Hp: int, Wp: int):
 
 
 def _prepare(layer, x_dev, Hp: int, Wp: int):
-    st = _state(layer)
+    st = _state(layer, x_dev)
     op_name = getattr(layer, "hat_operand_dtype", "f16")
     op_code, op_dtype = _OP[op_name]
     ws, hier, sr0, sr1 = _geometry(layer, Hp, Wp)
@@ -295,7 +339,7 @@ def _prepare(layer, x_dev, Hp: int, Wp: int):
                              dev_t["up_idx"].data_ptr())
         st.tables[tkey] = (tb, dev_t, ct)
     tb, _, ctables = st.tables[tkey]
-    sig = _signature(layer.blocks, x_dev, op_name) + (tb["S"], tb["G"])
+    sig = _signature(layer.blocks, x_dev, op_name, bool(getattr(layer, "_is_replica", False))) + (tb["S"], tb["G"])
     if st.sig != sig:
         keep = _Keep(op_dtype)
         arr = (FvitBlockWeights * len(layer.blocks))()
@@ -313,15 +357,32 @@ def _prepare(layer, x_dev, Hp: int, Wp: int):
     return st, tb, ctables, desc_common
 
 
-_WS_SLOT = [0]   # workspace slot of the current caller: concurrent forwards on different streams must not share scratch
+_TLS = threading.local()   # workspace slot of the calling thread (default 0)
 
 
 def set_workspace_slot(slot: int) -> None:
-    _WS_SLOT[0] = int(slot)
+    """Scratch slot used by the stage calls of THIS thread from now on.  Forwards that are meant to overlap on different HIP streams
+    (the stream shards of the deploy plan) take different slots; forwards that share a slot are serialised on the GPU
+    (``_acquire`` inserts an event wait when a slot changes streams)."""
+    _TLS.slot = int(slot)
 
 
-def _workspace(st: StageState, desc_common: dict, B: int, H: int, W: int, device):
-    key = (B, desc_common["Hp"], desc_common["Wp"], H, W, desc_common["operand_dtype"], _WS_SLOT[0])
+def _slot() -> int:
+    return getattr(_TLS, "slot", 0)
+
+
+@contextlib.contextmanager
+def workspace_slot(slot: int):
+    prev = _slot()
+    set_workspace_slot(slot)
+    try:
+        yield
+    finally:
+        set_workspace_slot(prev)
+
+
+def _workspace(st: StageState, desc_common: dict, B: int, H: int, W: int, device) -> _Workspace:
+    key = (B, desc_common["Hp"], desc_common["Wp"], H, W, desc_common["operand_dtype"], _slot())
     hit = st.workspaces.get(key)
     if hit is not None:
         return hit
@@ -331,116 +392,181 @@ def _workspace(st: StageState, desc_common: dict, B: int, H: int, W: int, device
     if nbytes == 0:
         _lib.check(-1, "fvit_stage_workspace_bytes")
     ws_t = torch.zeros(nbytes, dtype=torch.uint8, device=device)  # zero-filled once, dedicated to this geometry
-    st.workspaces[key] = (desc, ws_t)
-    return desc, ws_t
+    ws = st.workspaces[key] = _Workspace(desc, ws_t)
+    return ws
 
 
-@torch.no_grad()
+def _acquire(ws: _Workspace, device) -> int:
+    """Make the current stream the owner of ``ws``: if its last user was another stream, wait for that user's stage to finish
+    (scratch is reused, not copied).  Returns the raw stream.  Inside a hipGraph capture no cross-stream bookkeeping is done:
+    a captured forward uses the slots it was warmed up with, and its fork / join edges are the plan's own events."""
+    stream = torch.cuda.current_stream(device)
+    ptr = stream.cuda_stream
+    if not torch.cuda.is_current_stream_capturing():
+        if ws.last_stream is not None and ws.last_stream != ptr and ws.event is not None:
+            stream.wait_event(ws.event)
+    return ptr
+
+
+def _release(ws: _Workspace, device) -> None:
+    if torch.cuda.is_current_stream_capturing():
+        return
+    stream = torch.cuda.current_stream(device)
+    if ws.event is None:
+        ws.event = torch.cuda.Event()
+    ws.event.record(stream)
+    ws.last_stream = stream.cuda_stream
+
+
 def token_init(tok, xp: torch.Tensor) -> torch.Tensor:
     """TokenInitializer.forward (AR:745-750) through fvit_token_init: depthwise conv + bias + avg-pool + per-window reorder
     in one HIP kernel, f32 (B, G, C) out.  (MIOpen runs this depthwise conv on its naive path: ~150 us at B = 256.)"""
     _require_gpu(xp, "TokenInitializer")
-    st = tok.__dict__.get("_fvit_tok")
-    sig = (tok.pos_embed.weight.data_ptr(), tok.pos_embed.weight._version, tok.pos_embed.bias._version, str(xp.device))
-    if st is None or st[0] != sig:
-        w = tok.pos_embed.weight.detach().float().reshape(-1, 9).contiguous().to(xp.device)
-        b = tok.pos_embed.bias.detach().float().contiguous().to(xp.device)
-        st = (sig, w, b)
-        tok.__dict__["_fvit_tok"] = st
-    _, w, b = st
-    pool = tok.to_global_feature.pool
-    kh, kw = pool.kernel_size if isinstance(pool.kernel_size, (tuple, list)) else (pool.kernel_size,) * 2
-    sh, sw = pool.stride if isinstance(pool.stride, (tuple, list)) else (pool.stride,) * 2
-    B, Cc, Hp, Wp = xp.shape
-    Ho, Wo = (Hp - kh) // sh + 1, (Wp - kw) // sw + 1
-    ct = torch.empty((B, Ho * Wo, Cc), dtype=torch.float32, device=xp.device)
-    view = _map_view(xp)
-    rc = _lib.lib().fvit_token_init(C.byref(view), w.data_ptr(), b.data_ptr(), ct.data_ptr(), B, Cc, Hp, Wp, kh, kw, sh, sw,
-                                    tok.window_size, _stream_ptr())
-    _lib.check(rc, "fvit_token_init")
-    return ct
+    with torch.no_grad(), torch.cuda.device(xp.device):
+        key = "_fvit_tok"
+        cache = tok.__dict__.get(key)
+        if not isinstance(cache, dict):
+            cache = tok.__dict__[key] = {}
+        wt, bs = tok.pos_embed.weight, tok.pos_embed.bias
+        if wt.device != xp.device:
+            raise RuntimeError(f"TokenInitializer: parameters are on {wt.device} but the input is on {xp.device}")
+        replica = bool(getattr(tok, "_is_replica", False))
+        sig = (float(wt.detach().float().sum()), float(bs.detach().float().sum())) if replica else \
+            (wt.data_ptr(), wt._version, bs.data_ptr(), bs._version)
+        st = cache.get(str(xp.device))
+        if st is None or st[0] != sig:
+            w = wt.detach().float().reshape(-1, 9).contiguous()
+            b = bs.detach().float().contiguous()
+            st = cache[str(xp.device)] = (sig, w, b)
+        _, w, b = st
+        pool = tok.to_global_feature.pool
+        kh, kw = pool.kernel_size if isinstance(pool.kernel_size, (tuple, list)) else (pool.kernel_size,) * 2
+        sh, sw = pool.stride if isinstance(pool.stride, (tuple, list)) else (pool.stride,) * 2
+        B, Cc, Hp, Wp = xp.shape
+        Ho, Wo = (Hp - kh) // sh + 1, (Wp - kw) // sw + 1
+        ct = torch.empty((B, Ho * Wo, Cc), dtype=torch.float32, device=xp.device)
+        view = _map_view(xp)
+        rc = _lib.lib().fvit_token_init(C.byref(view), w.data_ptr(), b.data_ptr(), ct.data_ptr(), B, Cc, Hp, Wp, kh, kw, sh, sw,
+                                        tok.window_size, _stream_ptr(xp.device))
+        _lib.check(rc, "fvit_token_init")
+        return ct
 
 
-def _check_mode(layer):
-    if layer.training and torch.is_grad_enabled():
-        raise RuntimeError("the MI355X HAT path is inference-only (forward kernels); call model.eval() and run under "
-                           "torch.no_grad(). Backward kernels are listed under SURVEY.md §8(f).")
+_WARNED = set()
 
 
-@torch.no_grad()
+def _check_mode(layer, x: torch.Tensor, what: str):
+    """The HIP path has forward kernels only and implements eval semantics (DropPath / Dropout identity, AR:636-637, 657-658).
+      * train mode                      -> RuntimeError (stochastic depth / dropout would silently be skipped);
+      * grad enabled + x.requires_grad  -> RuntimeError (the caller is differentiating through the stage: outputs are detached);
+      * grad enabled otherwise          -> one warning (outputs are detached; wrap inference in torch.no_grad())."""
+    if layer.training:
+        raise RuntimeError(f"{what}: the MI355X HAT path is inference-only (forward kernels, eval semantics); call model.eval(). "
+                           "Backward kernels for the HAT block are not built (DESIGN.md, SURVEY.md §8f-4); the head-only training "
+                           "step (fastervit_amd.head_train) keeps the backbone in eval mode.")
+    if torch.is_grad_enabled():
+        if x.requires_grad:
+            raise RuntimeError(f"{what}: the input requires grad, but the HIP HAT stage has no backward: its output would be silently "
+                               "detached. Run under torch.no_grad() (or detach the input).")
+        if what not in _WARNED:
+            _WARNED.add(what)
+            warnings.warn(f"{what}: called with grad enabled; the HIP HAT path returns detached outputs (no backward kernels). "
+                          "Wrap inference in torch.no_grad().", stacklevel=3)
+
+
+def is_prepared(layer, device) -> bool:
+    """True if the packed weights of ``layer`` on ``device`` are current (no packing work will be enqueued by the next call)."""
+    states = layer.__dict__.get("_fvit_state")
+    if not states or getattr(layer, "_is_replica", False):
+        return False
+    st = states.get((device.type, device.index if device.index is not None else torch.cuda.current_device()))
+    if st is None or st.sig is None:
+        return False
+    op_name = getattr(layer, "hat_operand_dtype", "f16")
+    return st.sig[:-2] == _signature(layer.blocks, device, op_name)
+
+
 def stage_forward(layer, x: torch.Tensor, tokenizer=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Transformer branch of FasterViTLayer.forward (AR:848-869) minus the Downsample.  ``x`` and the optional preallocated
     ``out`` (same shape and dtype) may be arbitrary strided views, e.g. the leading channels of a channel-padded map.
 
     ``tokenizer`` (optional) replaces the layer's TokenInitializer module with an equivalent callable
     returning f32 (B, G, C) carrier tokens (deploy mode passes a 16-bit channels_last version)."""
-    _check_mode(layer)
     _require_gpu(x, "FasterViTLayer")
-    lib = _lib.lib()
-    B, Cc, H, W = x.shape
-    ws = layer.window_size
-    pad_r = (ws - W % ws) % ws
-    pad_b = (ws - H % ws) % ws
-    xp = F.pad(x, (0, pad_r, 0, pad_b)) if (pad_r or pad_b) else x
-    Hp, Wp = H + pad_b, W + pad_r
-    ct = None
-    blk0 = layer.blocks[0] if len(layer.blocks) else None
-    if blk0 is None:
+    _check_mode(layer, x, "FasterViTLayer")
+    if len(layer.blocks) == 0:
         return x
-    if layer.do_gt and blk0.do_sr_hat:
-        # TokenInitializer stays a PyTorch-ROCm dwconv + pool (north_star); runs in the model's dtype
-        if tokenizer is not None:
-            ct = tokenizer(xp)
-        else:
-            ct = token_init(layer.global_tokenizer, xp)
-    st, tb, ctables, dc = _prepare(layer, x.device, Hp, Wp)
-    desc, ws_t = _workspace(st, dc, B, H, W, x.device)
-    if out is None:
-        out = torch.empty_like(x)  # keeps dtype and memory format (NCHW or channels_last)
-    elif out.shape != x.shape or out.dtype != x.dtype or out.device != x.device:
-        raise RuntimeError(f"stage_forward: out {tuple(out.shape)} {out.dtype} does not match x {tuple(x.shape)} {x.dtype}")
-    vin, vout = _map_view(xp), _map_view(out)
-    rc = lib.fvit_hat_stage_forward(C.byref(desc), st.blocks_c, C.byref(ctables), C.byref(vin),
-                                    ct.data_ptr() if ct is not None else None, C.byref(vout), ws_t.data_ptr(),
-                                    ws_t.numel(), _stream_ptr())
-    _lib.check(rc, "fvit_hat_stage_forward")
-    return out
+    _check_device(x, layer, "FasterViTLayer")
+    lib = _lib.lib()
+    with torch.no_grad(), torch.cuda.device(x.device):
+        B, Cc, H, W = x.shape
+        ws = layer.window_size
+        pad_r = (ws - W % ws) % ws
+        pad_b = (ws - H % ws) % ws
+        xp = F.pad(x, (0, pad_r, 0, pad_b)) if (pad_r or pad_b) else x
+        Hp, Wp = H + pad_b, W + pad_r
+        ct = None
+        blk0 = layer.blocks[0]
+        if layer.do_gt and blk0.do_sr_hat:
+            # TokenInitializer (AR:745-750): fvit_token_init in both modes
+            ct = tokenizer(xp) if tokenizer is not None else token_init(layer.global_tokenizer, xp)
+        st = _state(layer, x.device)
+        with st.lock:
+            st, tb, ctables, dc = _prepare(layer, x.device, Hp, Wp)
+            wsp = _workspace(st, dc, B, H, W, x.device)
+            if out is None:
+                out = torch.empty_like(x)  # keeps dtype and memory format (NCHW or channels_last)
+            elif out.shape != x.shape or out.dtype != x.dtype or out.device != x.device:
+                raise RuntimeError(f"stage_forward: out {tuple(out.shape)} {out.dtype} does not match x {tuple(x.shape)} {x.dtype}")
+            vin, vout = _map_view(xp), _map_view(out)
+            stream = _acquire(wsp, x.device)
+            rc = lib.fvit_hat_stage_forward(C.byref(wsp.desc), st.blocks_c, C.byref(ctables), C.byref(vin),
+                                            ct.data_ptr() if ct is not None else None, C.byref(vout), wsp.buf.data_ptr(),
+                                            wsp.buf.numel(), stream)
+            _lib.check(rc, "fvit_hat_stage_forward")
+            _release(wsp, x.device)
+        return out
 
 
-@torch.no_grad()
 def block_forward(blk, x: torch.Tensor, carrier_tokens: Optional[torch.Tensor]):
     """HAT.forward(x, carrier_tokens) with the reference signature (AR:668-707)."""
-    _check_mode(blk)
     _require_gpu(x, "HAT")
+    _check_mode(blk, x, "HAT")
+    _check_device(x, blk, "HAT")
     lib = _lib.lib()
-    Bw, T, Cc = x.shape
-    ws = blk.window_size
-    hier = bool(blk.do_sr_hat)
-    sr0, sr1 = (blk.sr_ratio if hier else (1, 1))
-    nW = sr0 * sr1
-    if Bw % nW:
-        raise ValueError(f"HAT.forward: {Bw} windows is not a multiple of {nW} windows per image")
-    B = Bw // nW
-    # a one-block pseudo layer so packing / tables are shared with the stage path
-    holder = blk.__dict__.get("_fvit_holder")
-    if holder is None:
-        holder = _BlockHolder(blk)
-        blk.__dict__["_fvit_holder"] = holder
-    st, tb, ctables, dc = _prepare(holder, x.device, sr0 * ws, sr1 * ws)
-    dc = dict(dc, depth=1)
-    desc, ws_t = _workspace(st, dc, B, sr0 * ws, sr1 * ws, x.device)
-    xf = x.float().contiguous().clone()
-    ctf = None
-    if hier:
-        if carrier_tokens is None:
-            raise ValueError("hierarchical HAT block needs carrier tokens")
-        ctf = carrier_tokens.float().contiguous().clone()
-    rc = lib.fvit_hat_block_forward(C.byref(desc), st.blocks_c, C.byref(ctables), xf.data_ptr(),
-                                    ctf.data_ptr() if ctf is not None else None, ws_t.data_ptr(), ws_t.numel(), _stream_ptr())
-    _lib.check(rc, "fvit_hat_block_forward")
-    if hier:
-        return xf.to(x.dtype), ctf.to(carrier_tokens.dtype)
-    return xf.to(x.dtype), carrier_tokens
+    with torch.no_grad(), torch.cuda.device(x.device):
+        Bw, T, Cc = x.shape
+        ws = blk.window_size
+        hier = bool(blk.do_sr_hat)
+        sr0, sr1 = (blk.sr_ratio if hier else (1, 1))
+        nW = sr0 * sr1
+        if Bw % nW:
+            raise ValueError(f"HAT.forward: {Bw} windows is not a multiple of {nW} windows per image")
+        B = Bw // nW
+        # a one-block pseudo layer so packing / tables are shared with the stage path
+        holder = blk.__dict__.get("_fvit_holder")
+        if holder is None or holder.blocks[0] is not blk:   # a DataParallel replica inherits the original's holder through __dict__
+            holder = _BlockHolder(blk)
+            blk.__dict__["_fvit_holder"] = holder
+        st = _state(holder, x.device)
+        with st.lock:
+            st, tb, ctables, dc = _prepare(holder, x.device, sr0 * ws, sr1 * ws)
+            dc = dict(dc, depth=1)
+            wsp = _workspace(st, dc, B, sr0 * ws, sr1 * ws, x.device)
+            xf = x.float().contiguous().clone()
+            ctf = None
+            if hier:
+                if carrier_tokens is None:
+                    raise ValueError("hierarchical HAT block needs carrier tokens")
+                ctf = carrier_tokens.float().contiguous().clone()
+            stream = _acquire(wsp, x.device)
+            rc = lib.fvit_hat_block_forward(C.byref(wsp.desc), st.blocks_c, C.byref(ctables), xf.data_ptr(),
+                                            ctf.data_ptr() if ctf is not None else None, wsp.buf.data_ptr(), wsp.buf.numel(), stream)
+            _lib.check(rc, "fvit_hat_block_forward")
+            _release(wsp, x.device)
+        if hier:
+            return xf.to(x.dtype), ctf.to(carrier_tokens.dtype)
+        return xf.to(x.dtype), carrier_tokens
 
 
 class _BlockHolder:
@@ -452,11 +578,18 @@ class _BlockHolder:
         self.training = False
 
     @property
+    def _is_replica(self):
+        return bool(getattr(self.blocks[0], "_is_replica", False))
+
+    def parameters(self):
+        return self.blocks[0].parameters()
+
+    @property
     def hat_operand_dtype(self):
         return getattr(self.blocks[0], "hat_operand_dtype", "f16")
 
 
 def workspace_bytes(layer) -> int:
-    """Bytes of HIP workspace currently held for this layer (all cached geometries)."""
-    st = layer.__dict__.get("_fvit_state")
-    return 0 if st is None else sum(t.numel() for _, t in st.workspaces.values())
+    """Bytes of HIP workspace currently held for this layer (all devices, all cached geometries)."""
+    states = layer.__dict__.get("_fvit_state") or {}
+    return sum(w.buf.numel() for st in states.values() for w in st.workspaces.values())

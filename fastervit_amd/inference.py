@@ -1,0 +1,119 @@
+"""Library-level inference runners (replaces the eval loop plumbing of validate.py:243-344 for throughput runs).
+
+``CompiledInference``  one GPU: the deploy plan (BN folded, 16-bit channels_last conv side on the HIP conv kernels, HAT stages on
+                       the HIP kernels) run as stream shards and captured into ONE hipGraph with static buffers -- the
+                       configuration ``bench.py`` measures, as a reusable object instead of caller code.
+``evaluate``           a minimal eval loop with the reference's semantics (validate.py:286-344: no_grad, optional channels_last and
+                       autocast, top-1 / top-5 accumulation), used by scripts/run_sharded_validate.py (one process per GPU,
+                       images sharded with ``dp.shard_bounds``; no nn.DataParallel scatter / gather per step).
+
+There is no CPU fallback: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional, Tuple
+
+import torch
+
+
+class CompiledInference:
+    """``model.compile_inference(example)``: capture once, then ``runner(x)`` = copy-in + hipGraph replay.
+
+    * ``example`` fixes the device, the maximum batch and the image size; shorter batches are zero-padded (images are independent in
+      eval mode), other image sizes raise.
+    * the returned logits are a view of the runner's static output buffer: they are overwritten by the next call (clone to keep).
+    * a weight update after compilation is NOT picked up by the graph (its packed copies are baked in); call ``recompile()``.
+    """
+
+    def __init__(self, model, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True):
+        if not example.is_cuda:
+            raise RuntimeError("compile_inference: the example input must be on a HIP device (no CPU fallback)")
+        if model.training:
+            raise RuntimeError("compile_inference: call model.eval() first (inference-only path)")
+        from .conv_runtime import DeployPlan
+        self.model = model
+        self.device = example.device
+        self.plan = DeployPlan(model, dtype)
+        self.plan.streams = max(1, int(streams))
+        self.use_graph = bool(graph)
+        self.static_x = example.detach().clone()
+        self.graph = None
+        self.static_y = None
+        self.recompile()
+
+    def recompile(self):
+        with torch.no_grad(), torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):   # packs weights, sizes every slot's workspaces, creates the side streams -- outside the capture
+                    y = self.plan.forward(self.static_x)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            if not self.use_graph:
+                self.graph, self.static_y = None, y
+                return
+            g = torch.cuda.CUDAGraph()   # a hipGraph on ROCm
+            with torch.cuda.graph(g):
+                self.static_y = self.plan.forward(self.static_x)
+            self.graph = g
+            torch.cuda.synchronize(self.device)
+
+    @property
+    def max_batch(self) -> int:
+        return self.static_x.shape[0]
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda or x.device != self.device:
+            raise RuntimeError(f"CompiledInference: input is on {x.device}, the runner was compiled for {self.device} (no implicit copy)")
+        n = x.shape[0]
+        if tuple(x.shape[1:]) != tuple(self.static_x.shape[1:]) or n > self.max_batch:
+            raise RuntimeError(f"CompiledInference: input {tuple(x.shape)} does not fit the compiled shape {tuple(self.static_x.shape)}")
+        with torch.no_grad(), torch.cuda.device(self.device):
+            if n == self.max_batch:
+                self.static_x.copy_(x, non_blocking=True)
+            else:
+                self.static_x[:n].copy_(x, non_blocking=True)
+                self.static_x[n:].zero_()
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self.static_y = self.plan.forward(self.static_x)
+        return self.static_y[:n]
+
+
+def accuracy_counts(logits: torch.Tensor, target: torch.Tensor, topk=(1, 5)) -> Tuple[int, ...]:
+    """Number of samples whose target is within the top-k logits (timm.utils.accuracy counts instead of percentages, so that
+    per-GPU shards can be summed exactly)."""
+    k = min(max(topk), logits.shape[1])
+    pred = logits.float().topk(k, dim=1).indices
+    hit = pred.eq(target.view(-1, 1))
+    return tuple(int(hit[:, :min(kk, k)].any(dim=1).sum().item()) for kk in topk)
+
+
+@torch.no_grad()
+def evaluate(model, loader: Iterable, device, amp_dtype: Optional[torch.dtype] = None, channels_last: bool = False,
+             runner: Optional[CompiledInference] = None):
+    """Eval loop with the semantics of the reference's validate() (validate.py:286-344): for every (input, target) batch move to the
+    device (validate.py:291-293), optional channels_last (294-295), forward under ``amp_autocast`` (297-298), accumulate top-1 /
+    top-5.  Returns (n_samples, top1_count, top5_count, logits of the last batch).  With ``runner`` the forward is the captured
+    hipGraph (``model.compile_inference``) instead of ``model(x)``."""
+    n = c1 = c5 = 0
+    last = None
+    for inp, tgt in loader:
+        inp = inp.to(device, non_blocking=True)
+        tgt = tgt.to(device, non_blocking=True)
+        if channels_last:
+            inp = inp.contiguous(memory_format=torch.channels_last)
+        if runner is not None:
+            out = runner(inp)
+        elif amp_dtype is not None:
+            with torch.autocast(device_type="cuda", dtype=amp_dtype):
+                out = model(inp)
+        else:
+            out = model(inp)
+        a1, a5 = accuracy_counts(out, tgt)
+        n, c1, c5 = n + inp.shape[0], c1 + a1, c5 + a5
+        last = out
+    return n, c1, c5, last

@@ -462,6 +462,13 @@ class FasterViT(nn.Module):
     auto_deploy = os.environ.get("FVIT_AUTO_DEPLOY", "1") != "0"
     auto_deploy_streams = 3   # stream shards of the automatic plan (batches of fewer than 2 x this many images run unsharded)
 
+    def _has_hooks(self):
+        """Forward (pre-)hooks on any submodule: the deploy plan calls kernels, not submodule forwards, and would bypass them."""
+        from torch.nn.modules import module as _m
+        if _m._global_forward_hooks or _m._global_forward_pre_hooks:
+            return True
+        return any(m._forward_hooks or m._forward_pre_hooks for m in self.modules())
+
     def _autocast_plan(self, x):
         if (not self.auto_deploy or self.training or not x.is_cuda or torch.is_grad_enabled() or not torch.is_autocast_enabled()
                 or getattr(self, "_is_replica", False) or x.dim() != 4 or x.shape[1] != 3):
@@ -469,6 +476,8 @@ class FasterViT(nn.Module):
         dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
         if dt not in (torch.float16, torch.bfloat16) or next(self.parameters()).device != x.device:
             return None
+        if not isinstance(self.head, (nn.Linear, nn.Identity)) or self._has_hooks():
+            return None   # a replaced head or registered hooks: stay on the plain nn.Module path
         plans = self.__dict__.setdefault("_auto_plans", {})
         if dt not in plans:
             from ..conv_runtime import DeployPlan
@@ -476,9 +485,19 @@ class FasterViT(nn.Module):
             plans[dt].streams = int(self.auto_deploy_streams)
         return plans[dt], dt
 
+    def compile_inference(self, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True):
+        """Throughput entry point: the deploy plan with ``streams`` stream shards captured ONCE into a hipGraph
+        with static input / output buffers; returns a callable ``runner(x) -> logits`` that copies ``x`` in and replays the
+        graph (any batch size up to the example's; shorter batches are zero-padded and the result sliced).  See
+        ``fastervit_amd.inference.CompiledInference``."""
+        from ..inference import CompiledInference
+        return CompiledInference(self, example, dtype=dtype, streams=streams, graph=graph)
+
     def forward(self, x):
         plan = self.__dict__.get("_deploy_plan")
-        if plan is not None and x.is_cuda and not self.training:
+        # nn.DataParallel replicas share __dict__ with the original: the plan's folded weights live on the original's device, so
+        # replicas run the module path (per-device HAT state in hat_runtime)
+        if plan is not None and x.is_cuda and not self.training and not getattr(self, "_is_replica", False):
             return plan.forward(x)
         auto = self._autocast_plan(x)
         if auto is not None:

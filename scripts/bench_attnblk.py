@@ -57,6 +57,8 @@ def run(name, n=20):
     if name == "unfused":
         fn = unfused
     else:
+        _lib.tune("ab_stagger", 1 if name.endswith("g") else 0)
+        name = name.rstrip("g")
         _lib.tune("ab_ablate", int(name[1:].split("v")[0]))
         _lib.tune("ab_variant", int(name.split("v")[1]) if "v" in name else 0)
         fn = fused

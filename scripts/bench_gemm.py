@@ -14,11 +14,18 @@ dt, code = torch.float16, 1
 SHAPES = [  # name, M, N, K, epilogue (0 bias, 1 gelu, 2 residual)
     ("s3 fc2 shard", 4165, 512, 2048, 2), ("s3 proj shard", 4165, 512, 512, 2), ("s3 fc1 shard", 4165, 2048, 512, 1),
     ("s3 qkv shard", 4165, 1536, 512, 0), ("ct fc2 shard", 1360, 256, 1024, 2), ("ct proj shard", 1360, 256, 256, 2),
-    ("s3 fc2 full", 12544, 512, 2048, 2), ("s3 fc1 full", 12544, 2048, 512, 1)]
-VARIANTS = [("8 waves, 64-row (default)", dict(gemm_nw8_max_grid=400, gemm_bm64_max_grid=400)),
-            ("8 waves, 128-row", dict(gemm_nw8_max_grid=400, gemm_bm64_max_grid=0)),
-            ("4 waves, 64-row", dict(gemm_nw8_max_grid=0, gemm_bm64_max_grid=400)),
-            ("4 waves, 128-row", dict(gemm_nw8_max_grid=0, gemm_bm64_max_grid=0))]
+    ("ct fc1 shard", 1360, 1024, 256, 1), ("ct qkv shard", 1360, 768, 256, 0),
+    ("s3 fc2 full", 12544, 512, 2048, 2), ("s3 fc1 full", 12544, 2048, 512, 1), ("s3 qkv full", 12544, 1536, 512, 0),
+    ("s3 proj full", 12544, 512, 512, 2), ("s2 qkv full", 54272, 768, 256, 0), ("s2 fc2 full", 54272, 256, 1024, 2)]
+VARIANTS = [("64-row", dict(gemm_bm64_max_grid=400, gemm_stagger=0)),
+            ("64-row stagger", dict(gemm_bm64_max_grid=400, gemm_stagger=1)),
+            ("128-row", dict(gemm_bm64_max_grid=0, gemm_stagger=0)),
+            ("128-row stagger", dict(gemm_bm64_max_grid=0, gemm_stagger=1))]
+if len(sys.argv) > 1 and sys.argv[1] == "old":   # r01 sweep: waves per workgroup x tile height
+    VARIANTS = [("8 waves, 64-row", dict(gemm_nw8_max_grid=400, gemm_bm64_max_grid=400)),
+                ("8 waves, 128-row", dict(gemm_nw8_max_grid=400, gemm_bm64_max_grid=0)),
+                ("4 waves, 64-row", dict(gemm_nw8_max_grid=0, gemm_bm64_max_grid=400)),
+                ("4 waves, 128-row", dict(gemm_nw8_max_grid=0, gemm_bm64_max_grid=0))]
 g = torch.Generator(device="cpu").manual_seed(0)
 for name, M, N, K, epi in SHAPES:
     Mp = (M + 127) // 128 * 128

@@ -1,0 +1,85 @@
+"""Bitwise repeatability of the HIP path on an MI355X (VERDICT r01 "what's weak" #1d): the same HAT stage run twice on identical
+input must give identical bits -- for the fused C = 256 / 512 kernels of FasterViT-0 AND for the unfused path of the other widths
+(C = 320 / 640 with head_dim 40 -> dpad 64, C = 384 / 768, FasterViT-4's head_dim 49 with layer scale and propagation).  Only then is a
+run-to-run difference of the whole model MIOpen's (module-mode fp32 convolutions), not ours.
+
+Also: the order-staggered variants of the GEMM / fused kernels (fvit_tune knobs) are results-equivalent to the default order
+within fp32 summation-order noise, and themselves repeatable.
+"""
+import pytest
+import torch
+
+from fastervit_amd import _lib, hat_runtime
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(entry, **kw):
+    import fastervit_amd
+    torch.manual_seed(0)
+    m = fastervit_amd.create_model(entry, **kw).eval().cuda()
+    # 'stress'-like perturbation so that gamma / biases are not the trivial init values
+    g = torch.Generator(device="cpu").manual_seed(7)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith(".bias") or "gamma" in n:
+                p.add_(torch.randn(p.shape, generator=g).to(p.device) * 0.02)
+    return m
+
+
+@pytest.mark.parametrize("entry,batch", [("faster_vit_0_224", 5), ("faster_vit_1_224", 3), ("faster_vit_2_224", 3), ("faster_vit_4_224", 2)])
+def test_hat_stages_are_bitwise_repeatable(entry, batch):
+    model = _model(entry)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for li in (2, 3):
+        lvl = model.levels[li]
+        C = lvl.blocks[0].attn.qkv.in_features
+        R = 14 if li == 2 else 7
+        for dtype, fmt in ((torch.float32, torch.contiguous_format), (torch.float16, torch.channels_last)):
+            x = torch.randn(batch, C, R, R, generator=g).cuda().to(dtype).contiguous(memory_format=fmt)
+            outs = []
+            for _ in range(3):
+                outs.append(hat_runtime.stage_forward(lvl, x.clone()).clone())
+            torch.cuda.synchronize()
+            assert torch.isfinite(outs[0].float()).all()
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"{entry} level {li} {dtype}: repeat call differs"
+
+
+def test_deploy_forward_is_bitwise_repeatable_across_graph_replays():
+    """The whole deploy-mode forward (our conv kernels, no MIOpen) is bit-repeatable, eager and replayed from a hipGraph."""
+    model = _model("faster_vit_0_224")
+    x = torch.randn(12, 3, 224, 224, generator=torch.Generator().manual_seed(3)).cuda()
+    model.switch_to_deploy(torch.float16, streams=3)
+    with torch.no_grad():
+        a = model(x).clone()
+        b = model(x).clone()
+    assert torch.equal(a, b)
+    runner = model.compile_inference(x)
+    y1 = runner(x).clone()
+    y2 = runner(x).clone()
+    assert torch.equal(y1, y2)
+    assert (y1.float() - a.float()).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("knobs", [dict(gemm_stagger=1), dict(ab_stagger=1, mlp_stagger=2), dict(mlp_stagger=0)])
+def test_order_stagger_knobs_keep_the_result(knobs):
+    """K / chunk / head order stagger only permutes fp32 sums: same stage output within summation-order noise, still repeatable."""
+    model = _model("faster_vit_0_224")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    try:
+        for li, R, C in ((2, 14, 256), (3, 7, 512)):
+            lvl = model.levels[li]
+            x = torch.randn(96, C, R, R, generator=g).cuda()
+            ref = hat_runtime.stage_forward(lvl, x).clone()
+            for k, v in knobs.items():
+                _lib.tune(k, v)
+            a = hat_runtime.stage_forward(lvl, x).clone()
+            b = hat_runtime.stage_forward(lvl, x).clone()
+            for k in knobs:
+                _lib.tune(k, {"gemm_stagger": 0, "ab_stagger": 0, "mlp_stagger": 1}[k])
+            assert torch.equal(a, b)
+            err = (a - ref).abs().max().item()
+            assert err < 2e-5 * max(ref.abs().max().item(), 1.0), f"level {li}: {err}"
+    finally:
+        for k, v in (("gemm_stagger", 0), ("ab_stagger", 0), ("mlp_stagger", 1)):
+            _lib.tune(k, v)
