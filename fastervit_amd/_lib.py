@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libfvit_hip.so")
 
-FVIT_ABI_VERSION = 2
+FVIT_ABI_VERSION = 3
 FVIT_F32, FVIT_F16, FVIT_BF16 = 0, 1, 2
 FVIT_TILE_N, FVIT_TILE_K = 128, 64
 FVIT_MASK_BIAS = -30000.0
@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "fvit_workspace_init", "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_token_init", "fvit_window_partition",
     "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_window_attention", "fvit_window_attention_long",
     "fvit_gather_layernorm", "fvit_attn_block_supported", "fvit_attn_block_fused", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl", "fvit_conv3x3_nhwc", "fvit_stem_conv3x3s2", "fvit_stem_fused",
+    "fvit_head_logits", "fvit_head_softmax_xent", "fvit_head_grad", "fvit_sgd_momentum",
     "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_kind_name",
 )
 
@@ -135,6 +136,14 @@ def _declare(lib):
     lib.fvit_stem_conv3x3s2.argtypes = [i32, C.POINTER(FvitMapView), vp, vp, vp, i32, i32, i32, vp]
     lib.fvit_stem_fused.restype = C.c_int
     lib.fvit_stem_fused.argtypes = [i32, C.POINTER(FvitMapView), vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.fvit_head_logits.restype = C.c_int
+    lib.fvit_head_logits.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.fvit_head_softmax_xent.restype = C.c_int
+    lib.fvit_head_softmax_xent.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp]
+    lib.fvit_head_grad.restype = C.c_int
+    lib.fvit_head_grad.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, vp]
+    lib.fvit_sgd_momentum.restype = C.c_int
+    lib.fvit_sgd_momentum.argtypes = [vp, vp, vp, C.c_int64, f32, f32, f32, vp]
     lib.fvit_tune.restype = C.c_int
     lib.fvit_tune.argtypes = [C.c_char_p, i32]
     lib.fvit_prof_enable.restype = C.c_int

@@ -49,8 +49,8 @@ struct AttnBlkParams {
     float* x_out;         // f32  [rows][C]
     int nwin, S, heads;
     float scale;
-    int ablate;  // timing experiments only (wrong results): 1 = no weight DMA inside the head loop, 2 = skip P1 MFMAs,
-                 // 4 = skip exchange + P2, 8 = skip P3
+    int ablate;  // timing experiments only (wrong results): 1 = no weight DMA inside the head loop (bits 2 / 4 / 8 -- skip P1 / P2 / P3 --
+                 // were removed in r02: runtime branches around the phases kept the compiler from scheduling across them)
     int stagger; // 1: workgroup b walks the heads starting at head (b / 8) % heads (b % 8 = XCD, observed): the workgroups of an XCD
                  // stream different weight slices at any time, so a slice is fetched from the memory side once per XCD and found in
                  // L2 by the other workgroups (in lockstep they all wait on the same outstanding miss)
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
     constexpr int OFF_PROJ = QKV_BYTES, OFF_BIAS = OFF_PROJ + PROJ_BYTES, OFF_KX = OFF_BIAS + ((BIAS_BYTES + 1023) / 1024) * 1024;
     constexpr int OFF_VX = OFF_KX + KX_BYTES, OFF_BQ = OFF_VX + VX_BYTES;
     constexpr int MAX_HEADS = CC / 32;
-    __shared__ __attribute__((aligned(16))) char smem[OFF_BQ + MAX_HEADS * 96 * 4];
+    constexpr int OFF_BP = OFF_BQ + MAX_HEADS * 96 * 4;   // proj bias and gamma (2 x C floats): no global loads in the epilogue
+    __shared__ __attribute__((aligned(16))) char smem[OFF_BP + 2 * CC * 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
     const bool row_ok = win_ok && tok < p.S;
     const int64_t row = (int64_t)(win_ok ? win : p.nwin - 1) * p.S + (tok < p.S ? tok : p.S - 1);   // clamped: always a real row
     float* bqs = (float*)(smem + OFF_BQ);
+    float* bps = (float*)(smem + OFF_BP);
+    float* gms = bps + CC;
 
     const char* __restrict__ Wq = (const char*)p.wqkv_f;
     const char* __restrict__ Wp = (const char*)p.wproj_f;
@@ -120,6 +123,10 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
 
     // ---- prologue: qkv bias to LDS, first weight slice in flight, gather + LayerNorm into B/A fragments ----
     for (int i = tid; i < p.heads * 96; i += 64 * NW) bqs[i] = p.bqkv[i];
+    for (int i = tid; i < CC; i += 64 * NW) {
+        bps[i] = p.bproj[i];
+        gms[i] = p.gamma ? p.gamma[i] : 1.0f;
+    }
     if (NRB == 1) {   // the upper half of every 32-key group never gets written: keep it finite
         for (int i = tid; i < VX_BYTES / 4; i += 64 * NW) ((float*)(smem + OFF_VX))[i] = 0.f;
     }
@@ -213,21 +220,36 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
         if (!(p.ablate & 1)) dma_proj_bias(h);
 
         // ---- P1: q^T, k^T, v ----
+        // software-pipelined over the k steps with two fragment register sets: the 6 fragments of step kk + 1 are requested before
+        // the 6 MFMAs of step kk issue, so a wave that is alone on its SIMD sees ONE exposed LDS round trip per head here instead
+        // of one per MFMA pair (r02 ISA audit: the compiler's own order was "2 ds_read, s_waitcnt lgkmcnt(0), 1-2 MFMA" x 24)
         f4 acc[6];
 #pragma unroll
         for (int ub = 0; ub < 6; ++ub) acc[ub] = (f4){0.f, 0.f, 0.f, 0.f};
-        if (!(p.ablate & 2))
+        {
+            v8 wa[6], wb[6];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
+            for (int ub = 0; ub < 6; ++ub) wa[ub] = *(const v8*)(wq_l + (ub * KK + 0) * 1024);
 #pragma unroll
-            for (int ub = 0; ub < 4; ++ub) {   // q0 q1 k0 k1: weights are the A operand
-                const v8 wf = *(const v8*)(wq_l + (ub * KK + kk) * 1024);
-                acc[ub] = Op16<T>::mfma(wf, xf[kk], acc[ub]);
-            }
+            for (int kk = 0; kk < KK; kk += 2) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ub = 4; ub < 6; ++ub) {   // v0 v1: activations are the A operand => D[key][dim]
-                const v8 wf = *(const v8*)(wq_l + (ub * KK + kk) * 1024);
-                acc[ub] = Op16<T>::mfma(xf[kk], wf, acc[ub]);
+                for (int ub = 0; ub < 6; ++ub) wb[ub] = *(const v8*)(wq_l + (ub * KK + kk + 1) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ub = 0; ub < 4; ++ub) acc[ub] = Op16<T>::mfma(wa[ub], xf[kk], acc[ub]);       // q0 q1 k0 k1: weights are the A operand
+#pragma unroll
+                for (int ub = 4; ub < 6; ++ub) acc[ub] = Op16<T>::mfma(xf[kk], wa[ub], acc[ub]);       // v0 v1: activations are A => D[key][dim]
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < KK) {
+#pragma unroll
+                    for (int ub = 0; ub < 6; ++ub) wa[ub] = *(const v8*)(wq_l + (ub * KK + kk + 2) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int ub = 0; ub < 4; ++ub) acc[ub] = Op16<T>::mfma(wb[ub], xf[kk + 1], acc[ub]);
+#pragma unroll
+                for (int ub = 4; ub < 6; ++ub) acc[ub] = Op16<T>::mfma(xf[kk + 1], wb[ub], acc[ub]);
             }
         }
         const float* bq = bqs + h * 96;
@@ -261,10 +283,6 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
         // ---- P2: scores^T, softmax over keys, O^T ----
         f4 sc[NRB];
         float mx = -3.0e38f;
-        if (p.ablate & 4) {
-#pragma unroll
-            for (int kb = 0; kb < NRB; ++kb) sc[kb] = (f4){(float)qf[0], (float)kf[1], 0.f, 0.f};
-        } else
 #pragma unroll
         for (int kb = 0; kb < NRB; ++kb) {
             const v8 kfa = *(const v8*)(kx + (wi * NRB + kb) * 1024 + lane16);
@@ -312,12 +330,29 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
             of[r] = (T)(o[0][r] * inv);
             of[4 + r] = (T)(o[1][r] * inv);
         }
-        // ---- P3: out^T += Wproj[:, head h] . O^T ----
-        if (!(p.ablate & 8))
+        // ---- P3: out^T += Wproj[:, head h] . O^T (fragment batches of 4, batch c + 1 requested before the MFMAs of batch c) ----
+        {
+            constexpr int PB = 4;
+            v8 pa[PB], pb[PB];
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            const v8 wf = *(const v8*)(wp_l + cb * 1024);
-            oacc[cb] = Op16<T>::mfma(wf, of, oacc[cb]);
+            for (int i = 0; i < PB; ++i) pa[i] = *(const v8*)(wp_l + i * 1024);
+#pragma unroll
+            for (int c0 = 0; c0 < CB; c0 += 2 * PB) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < PB; ++i) pb[i] = *(const v8*)(wp_l + (c0 + PB + i) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < PB; ++i) oacc[c0 + i] = Op16<T>::mfma(pa[i], of, oacc[c0 + i]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c0 + 2 * PB < CB) {
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) pa[i] = *(const v8*)(wp_l + (c0 + 2 * PB + i) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < PB; ++i) oacc[c0 + PB + i] = Op16<T>::mfma(pb[i], of, oacc[c0 + PB + i]);
+            }
         }
     }
 
@@ -336,8 +371,8 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
                     xv = *(const f4*)(src + c0 + q * 4);
                     if (addp) xv += *(const f4*)(addp + c0 + q * 4);
                 }
-                const f4 bv = *(const f4*)(p.bproj + c0 + q * 4);
-                const f4 gv = p.gamma ? *(const f4*)(p.gamma + c0 + q * 4) : (f4){1.f, 1.f, 1.f, 1.f};
+                const f4 bv = *(const f4*)(bps + c0 + q * 4);
+                const f4 gv = *(const f4*)(gms + c0 + q * 4);
                 const f4 a = oacc[cg * 4 + q];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xv[r] += gv[r] * (a[r] + bv[r]);

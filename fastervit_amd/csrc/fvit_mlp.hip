@@ -43,7 +43,8 @@ struct MlpParams {
     float eps;
     int M, hidden;
     int stagger;  // 1: workgroup b walks the hidden chunks starting at chunk b % nchunk; 2: offsets spread evenly over the workgroups of an XCD
-    int ablate;   // timing experiments only (results are wrong): bit 0 = GELU -> identity, bit 1 = skip weight staging
+    int ablate;   // timing experiments only (results are wrong): bit 1 = skip weight staging (bit 0, GELU -> identity, was removed in r02:
+                  // a runtime branch around every GELU serialised the chunk body)
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
@@ -73,8 +74,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
     constexpr int ROWS_PER_WAVE = RB * 16;
     constexpr int MAX_HIDDEN = 4 * C;      // fc1 bias staged in LDS once: no ordinary global loads inside the chunk loop
                                            // (they queue behind the LDS-DMA prefetch in the in-order vmcnt counter and drain it)
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES + MAX_HIDDEN * 4];
+    // + fc2 bias and gamma (2 x C floats): the epilogue then has no global loads, so its 16-byte stores issue back to back (with
+    // b2 / gamma fetched from L2 the compiler put an s_waitcnt vmcnt(0) -- which also waits for the PREVIOUS store -- in front of
+    // every one of the C/16 store groups: 16 serial memory round trips per workgroup)
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES + MAX_HIDDEN * 4 + 2 * C * 4];
     float* b1s = (float*)(smem + NBUF * BUF_BYTES);
+    float* b2s = b1s + MAX_HIDDEN;
+    float* gms = b2s + C;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -105,6 +111,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
     };
 
     for (int i = tid; i < p.hidden; i += 64 * NW) b1s[i] = p.b1[i];
+    for (int i = tid; i < C; i += 64 * NW) {
+        b2s[i] = p.b2[i];
+        gms[i] = p.gamma ? p.gamma[i] : 1.0f;
+    }
     stage(chunk_of(0), smem);
 
     // ---- LayerNorm of this wave's rows straight into B-operand fragments ----
@@ -167,40 +177,121 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
         if (NBUF == 2) {
             if (it + 1 < nchunk && !(p.ablate & 2)) stage(chunk_of(it + 1), smem + ((it + 1) & 1) * BUF_BYTES);
         }
-        // ---- GEMM1: H^T[unit][row], 2 unit blocks x RB row blocks; unit = hb*16 + 4g + r ----
-        f4 acc1[2][RB];
+        if constexpr (RB == 1) {
+            // The chunk body is written for a wave that is ALONE on its SIMD (small grids: the carrier-token branch, stage 3, the
+            // shard-sized launches of the stream-sharded plan): left to the compiler the loop was "2 ds_read, s_waitcnt lgkmcnt(0),
+            // 2 MFMA" sixteen times over plus eight serial GELU chains behind runtime branches -- ~3100 cycles per chunk for 512
+            // cycles of MFMA issue (r02 ISA audit).  Here every fragment of a GEMM is requested before its first MFMA (one exposed
+            // LDS round trip per GEMM instead of eight), GEMM1 runs KSPLIT independent accumulator chains per (unit block, row
+            // block), and GEMM2's fragments are in flight while the VALU does bias + GELU.
+            constexpr int FB = RB == 1 ? 16 : 4;         // fragments requested per batch (64 / 16 VGPRs; RB = 2 already holds 128 accumulators)
+            constexpr bool W2_EARLY = RB == 1;           // GEMM2's first batch requested BEFORE the GELU block
+            constexpr int KSPLIT = RB == 1 ? 2 : 1;      // independent accumulator chains per output block in GEMM1
+            constexpr int KH = KK / KSPLIT;
+            // ---- GEMM1: H^T[unit][row], 2 unit blocks x RB row blocks; unit = hb*16 + 4g + r ----
+            f4 acc1[2][RB][KSPLIT];
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb)
+            for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc1[hb][rb] = (f4){0.f, 0.f, 0.f, 0.f};
+                for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
+                    for (int ks = 0; ks < KSPLIT; ++ks) acc1[hb][rb][ks] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                const v8 wf = *(const v8*)(buf + (hb * KK + kk) * 1024);
+            for (int f0 = 0; f0 < W1_FRAGS; f0 += FB) {
+                v8 wf[FB];
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) acc1[hb][rb] = Op16<T>::mfma(wf, xf[rb][kk], acc1[hb][rb]);
+                for (int i = 0; i < FB; ++i) wf[i] = *(const v8*)(buf + (f0 + i) * 1024);   // fragment index = hb * KK + kk
+                __builtin_amdgcn_sched_barrier(0);
+                // issue order kk-major inside the batch so that consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int i = 0; i < FB; ++i) {
+                    const int f = f0 + i, hb = f / KK, kk = f - hb * KK;
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) acc1[hb][rb][kk / KH] = Op16<T>::mfma(wf[i], xf[rb][kk], acc1[hb][rb][kk / KH]);
+                }
             }
-        }
-        // ---- bias + GELU, straight into GEMM2's B operand (k slot 8g + i <-> unit (i>>2)*16 + 4g + (i&3)) ----
-        const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
-        const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
-        v8 pf[RB];
+            // ---- GEMM2's first fragment batch goes in flight now and lands while the VALU runs bias + GELU (pinned: left alone the
+            // compiler sinks these reads below the GELU block again to save registers) ----
+            constexpr int HB2 = 8;                   // fragments per GEMM2 batch (32 VGPRs)
+            v8 w2a[HB2], w2b[HB2];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
+            for (int i = 0; i < HB2; ++i) w2a[i] = *(const v8*)(buf + W1_BYTES + i * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- bias + GELU, straight into GEMM2's B operand (k slot 8g + i <-> unit (i>>2)*16 + 4g + (i&3)) ----
+            const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
+            const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
+            v8 pf[RB];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float u0 = acc1[0][rb][r] + bA[r], u1 = acc1[1][rb][r] + bB[r];
-                pf[rb][r] = (T)((p.ablate & 1) ? u0 : gelu_fast(u0));
-                pf[rb][4 + r] = (T)((p.ablate & 1) ? u1 : gelu_fast(u1));
+            for (int rb = 0; rb < RB; ++rb) {
+                f4 h0 = acc1[0][rb][0], h1 = acc1[1][rb][0];
+#pragma unroll
+                for (int ks = 1; ks < KSPLIT; ++ks) { h0 += acc1[0][rb][ks]; h1 += acc1[1][rb][ks]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[rb][r] = (T)gelu_fast(h0[r] + bA[r]);
+                    pf[rb][4 + r] = (T)gelu_fast(h1[r] + bB[r]);
+                }
             }
-        }
-        // ---- GEMM2: OUT^T[channel][row] += W2[channel][chunk units] . H^T ----
+            // ---- GEMM2: OUT^T[channel][row] += W2[channel][chunk units] . H^T; batch c+1 is requested before the MFMAs of batch c ----
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            const v8 wf = *(const v8*)(buf + W1_BYTES + cb * 1024);
+            for (int c0 = 0; c0 < CB; c0 += 2 * HB2) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc2[cb][rb] = Op16<T>::mfma(wf, pf[rb], acc2[cb][rb]);
+                for (int i = 0; i < HB2; ++i) w2b[i] = *(const v8*)(buf + W1_BYTES + (c0 + HB2 + i) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < HB2; ++i)
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) acc2[c0 + i][rb] = Op16<T>::mfma(w2a[i], pf[rb], acc2[c0 + i][rb]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c0 + 2 * HB2 < CB) {
+#pragma unroll
+                    for (int i = 0; i < HB2; ++i) w2a[i] = *(const v8*)(buf + W1_BYTES + (c0 + 2 * HB2 + i) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < HB2; ++i)
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) acc2[c0 + HB2 + i][rb] = Op16<T>::mfma(w2b[i], pf[rb], acc2[c0 + HB2 + i][rb]);
+            }
+        } else {
+            // 32 rows per wave (whole-batch launches, two workgroups per CU): 128 accumulator registers leave no room for fragment
+            // batches (they spill); the partner wave on the SIMD hides the LDS round trips instead
+            // ---- GEMM1: H^T[unit][row], 2 unit blocks x RB row blocks; unit = hb*16 + 4g + r ----
+            f4 acc1[2][RB];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc1[hb][rb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    const v8 wf = *(const v8*)(buf + (hb * KK + kk) * 1024);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) acc1[hb][rb] = Op16<T>::mfma(wf, xf[rb][kk], acc1[hb][rb]);
+                }
+            }
+            // ---- bias + GELU, straight into GEMM2's B operand (k slot 8g + i <-> unit (i>>2)*16 + 4g + (i&3)) ----
+            const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
+            const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
+            v8 pf[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u0 = acc1[0][rb][r] + bA[r], u1 = acc1[1][rb][r] + bB[r];
+                    pf[rb][r] = (T)gelu_fast(u0);
+                    pf[rb][4 + r] = (T)gelu_fast(u1);
+                }
+            }
+            // ---- GEMM2: OUT^T[channel][row] += W2[channel][chunk units] . H^T ----
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const v8 wf = *(const v8*)(buf + W1_BYTES + cb * 1024);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc2[cb][rb] = Op16<T>::mfma(wf, pf[rb], acc2[cb][rb]);
+            }
         }
         if (NBUF == 1) {
             __syncthreads();
@@ -220,8 +311,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
                 float* px = p.x + (size_t)row * C + c0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f4 bv = *(const f4*)(p.b2 + c0 + q * 4);
-                    const f4 gv = p.gamma ? *(const f4*)(p.gamma + c0 + q * 4) : (f4){1.f, 1.f, 1.f, 1.f};
+                    const f4 bv = *(const f4*)(b2s + c0 + q * 4);
+                    const f4 gv = *(const f4*)(gms + c0 + q * 4);
                     f4 xv;
                     if (KEEPX) xv = xk[KEEPX ? rb : 0][2 * cg + (q >> 1)][q & 1];
                     else xv = *(f4*)(px + q * 4);

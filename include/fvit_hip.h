@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FVIT_ABI_VERSION 2
+#define FVIT_ABI_VERSION 3
 
 /* error codes */
 #define FVIT_OK 0
@@ -295,10 +295,32 @@ int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const void* weight
 int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2,
                     void* out, int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream);
 
+/* ---- head-only training step (north_star's training clause; csrc/fvit_head.hip) ----
+ * The classifier FasterViT.head = nn.Linear(F, N) (FV:927, 959) is trained on the pooled features of the frozen HIP backbone; the
+ * reference wraps the WHOLE model in DistributedDataParallel (train.py:542-551) and reduces the loss for logging (train.py:910).
+ * All tensors fp32, row-major, caller-owned; no atomics (bit-reproducible gradients).  F must be a multiple of 16. */
+/* logits[b][n] = feat[b][:] . W[n][:] + bias[n]   (exact-fp32 MFMA v_mfma_f32_16x16x4_f32) */
+int fvit_head_logits(const float* feat, const float* W, const float* bias, float* logits, int32_t B, int32_t N, int32_t F,
+                     fvit_stream_t stream);
+/* Label-smoothed cross entropy (timm LabelSmoothingCrossEntropy, selected at train.py:685; smoothing 0 = nn.CrossEntropyLoss,
+ * train.py:687): loss_rows[b] = (1 - eps) * (-log p[b][t_b]) + eps * mean_n(-log p[b][n]); then IN PLACE
+ * logits[b][n] <- (p[b][n] - q[b][n]) * inv_global_batch with q = (1 - eps) * onehot(t_b) + eps / N, i.e. d(mean loss)/d(logits).
+ * row_stats: scratch f32 [2 * B]. */
+int fvit_head_softmax_xent(float* logits_inout, const int64_t* target, float* loss_rows, float* row_stats, int32_t B, int32_t N,
+                           float smoothing, float inv_global_batch, fvit_stream_t stream);
+/* grad_flat = [ dW (N x F) = dlogits^T . feat | db (N) = column sums of dlogits | loss (1) = sum(loss_rows) * inv_global_batch ]:
+ * ONE contiguous buffer of N*F + N + 1 floats, so that a single all-reduce (SUM over ranks) yields the global-batch gradient AND
+ * the global mean loss. */
+int fvit_head_grad(const float* dlogits, const float* feat, const float* loss_rows, float* grad_flat, int32_t B, int32_t N, int32_t F,
+                   float inv_global_batch, fvit_stream_t stream);
+/* SGD with momentum and (coupled) weight decay on a flat buffer: m = mu * m + (g + wd * p);  p -= lr * m. */
+int fvit_sgd_momentum(float* param, float* momentum, const float* grad, int64_t n, float lr, float mu, float weight_decay,
+                      fvit_stream_t stream);
+
 /* Performance-experiment knobs for A/B runs inside one process; the same keys can be preset through the environment as
  * FVIT_TUNE_<key>=<int> (read once per key).  Kernel-selection knobs never change results beyond fp32 summation order:
  *   "mlp_fused", "attn_fused" 0/1; "mlp_fused_min_rows", "attn_fused_min_rows", "mlp_fused512_min_rows", "attn_fused512_min_rows";
- *   "mlp_variant" (-1 auto), "ab_variant", "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
+ *   "mlp_variant" (-1 auto), "ab_variant", "gemm_stagger", "ab_stagger", "mlp_stagger" (0 / 1 / 2), "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
  *   "conv_halo_grid", "conv64_variant", "conv128_narrow", "stem_fused_grid".
  * The "*_ablate" keys ("mlp_ablate", "ab_ablate", "conv_ablate", "conv_halo_ablate") switch off parts of a kernel for timing and
  * DO produce wrong results.  Guarded by a mutex; launches read the values at launch time. */
