@@ -5,17 +5,29 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A step is one forward pass of faster_vit_0_224 over one synthetic batch of 256 images per GPU
-(BASELINE configs[1]); inputs are resident in HBM before the timed region.  Inference is
-embarrassingly data parallel: every rank runs its own shard, there is no data-path collective
-(SURVEY.md §8e); the only collectives are the barrier and the MAX over ranks of the elapsed time.
-Rank 0 prints one JSON line.  The roofline entry is measured live with HIP events (the library's
-built-in kernel timer, on the launch stream); cpu_baseline times the CPU oracle (a port of the
-reference's fp32 PyTorch path) on a bounded sample on the host cores.
+A step is one forward pass of faster_vit_0_224 over one synthetic batch of 256 images per GPU (BASELINE configs[1]); inputs are
+resident in HBM before the timed region.  Inference is embarrassingly data parallel: every rank runs its own shard, there is no
+data-path collective; the only collectives are the barrier and the MAX / SUM reductions that turn per-rank
+timings into one whole-job figure.  Rank 0 prints ONE JSON line:
+
+  value / ms_per_step     W untimed + exactly K timed hipGraph replays, barrier + synchronize on both sides, MAX over ranks
+  step_ms                 min / median / max of individually event-timed steps (a separate pass; dispersion of the number above)
+  roofline                ONE (kernel, launch shape) row: the shape with the largest summed time in the timed configuration; live
+                          HIP-event duration per launch (library kernel timer, on the launch stream), algorithmic bytes / FLOPs of
+                          THAT shape, PMC traffic of THAT (kernel, grid) from the committed rocprofv3 passes (null when the
+                          committed file has no such row)
+  roofline_shapes         every (kernel, launch shape) of the step with the same columns (what DESIGN.md §4 quotes)
+  parity / parity_bf16    logits max-abs error vs the fp32 CPU oracle, 8 images from EACH stream shard (fp16 operands = the timed
+                          configuration; bf16 operands reported beside it)
+  secondary               BASELINE configs 3 and 5 (faster_vit_4_224 bs 128; faster_vit_4_any_res 576x960 bs 8): a few timed steps
+                          each + parity on 2 images (N = 1 only)
+  cpu_baseline            the CPU oracle (a port of the reference's fp32 PyTorch path) on the host cores, batch 8 and batch 64
 """
 import argparse
+import ast
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,6 +39,8 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+RIDGE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+PMC_FILE = os.path.join("profiles", "r02_pmc_hbm_traffic_by_kernel.json")   # scripts/gpu_pmc_traffic.sh -> scripts/pmc_traffic_summary.py
 
 
 def parse():
@@ -39,23 +53,297 @@ def parse():
     ap.add_argument("--model-kwargs", default="", help="python dict literal passed to create_model (secondary configs)")
     ap.add_argument("--input-size", default="", help="HxW override (secondary configs, e.g. 576x960)")
     ap.add_argument("--operand", default="f16", choices=["f16", "bf16"], help="MFMA operand type of the HAT kernels")
-    ap.add_argument("--conv-dtype", default="f16", choices=["f16", "bf16", "f32"], help="dtype of the PyTorch-ROCm conv side")
+    ap.add_argument("--conv-dtype", default="f16", choices=["f16", "bf16", "f32"], help="dtype of the conv side")
     ap.add_argument("--mode", default="deploy", choices=["deploy", "module", "auto"],
-                    help="deploy: BN folded into convs + fused glue kernels (switch_to_deploy); module: nn.Module forward under autocast")
+                    help="deploy: BN folded into convs + fused HIP conv kernels (model.compile_inference); module: nn.Module forward under "
+                         "autocast; auto: model(x) under autocast (automatic deploy plan)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="deploy mode: run the batch as this many shards on separate HIP streams (fork/join inside the hipGraph); "
-                         "r01: 57.2k / 61.4k / 62.6k / 59.4k img/s for 1 / 2 / 3 / 4")
+    ap.add_argument("--streams", type=int, default=3, help="deploy mode: stream shards of the batch (fork / join inside the hipGraph)")
     ap.add_argument("--shard-sizes", type=str, default="", help="comma list of images per stream shard (default: equal split)")
     ap.add_argument("--shard-launch", choices=["free", "forkjoin"], default="forkjoin",
-                    help="deploy mode with --streams > 1: 'free' = one hipGraph per shard on its own stream, replayed back to back with no "
-                         "join between steps (streams drift apart, consecutive steps overlap); 'forkjoin' = one graph per step that "
-                         "forks the shards and joins them (model.forward semantics; measured faster: 62.9k vs 44.9k / 62.5k / 60.0k img/s for free-running "
-                         "3 / 2 / 4 streams, profiles/r01_shard_launch_sweep.log)")
+                    help="'free' = one hipGraph per shard on its own stream, no join between steps (r01: slower); 'forkjoin' = one graph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
-    ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline sample")
+    ap.add_argument("--prof-steps", type=int, default=3, help="eager HIP-event passes for the roofline rows (0: skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 3 and 5")
+    ap.add_argument("--secondary-steps", type=int, default=10)
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# one configuration: build, warm up, capture, time
+# ------------------------------------------------------------------------------------------------------------------------
+class Config:
+    def __init__(self, args, dev, rank, model_name, batch, hw=None, model_kwargs=None, streams=3):
+        import fastervit_amd
+        self.args, self.dev, self.name, self.batch = args, dev, model_name, batch
+        torch.manual_seed(0)  # same random-init weights on every rank
+        self.model = fastervit_amd.create_model(model_name, **(model_kwargs or {})).eval()
+        self.sd_cpu = {k: v.clone() for k, v in self.model.state_dict().items()}
+        self.model = self.model.to(dev).to(memory_format=torch.channels_last)
+        self.model.set_hat_operand_dtype(args.operand)
+        H = W = self.model.pretrained_cfg["input_size"][-1]
+        if hw:
+            H, W = hw
+        self.H, self.W = H, W
+        gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+        self.x_cpu = torch.randn(batch, 3, H, W, generator=gen)
+        self.x = self.x_cpu.to(dev).contiguous(memory_format=torch.channels_last)
+        self.conv_dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": None}[args.conv_dtype]
+        self.deploy = args.mode == "deploy" and self.conv_dt is not None
+        self.streams = streams if self.deploy else 1
+        self.runner = self.graph = self.static_y = self.free_runner = None
+        self.plan = None
+
+    def eager(self, inp):
+        with torch.no_grad():
+            if self.deploy:
+                return self.plan.forward(inp)
+            if self.conv_dt is None:
+                return self.model(inp)
+            with torch.autocast("cuda", dtype=self.conv_dt):
+                return self.model(inp)
+
+    def prepare(self):
+        a = self.args
+        if self.deploy:
+            # the library-level runner: deploy plan + stream shards + ONE hipGraph with static buffers
+            self.runner = self.model.compile_inference(self.x, dtype=self.conv_dt, streams=self.streams, graph=not a.no_graph)
+            self.plan = self.runner.plan
+            if a.shard_sizes:
+                self.plan.shard_sizes = [int(v) for v in a.shard_sizes.split(",")]
+                self.plan.streams = len(self.plan.shard_sizes)
+                self.runner.recompile()
+            if self.streams > 1 and not a.no_graph and a.shard_launch == "free":
+                self.free_runner = self.plan.shard_runner(self.x, self.streams)
+            return
+        self.model.auto_deploy = a.mode == "auto"
+        for _ in range(2):
+            self.eager(self.x)
+        torch.cuda.synchronize()
+        if not a.no_graph:
+            static_x = self.x.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.eager(static_x)
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_y = self.eager(static_x)
+            torch.cuda.synchronize()
+
+    def step(self):
+        if self.free_runner is not None:
+            self.free_runner.launch()
+            return None
+        if self.runner is not None:
+            if self.runner.graph is not None:
+                self.runner.graph.replay()     # inputs already resident in the static buffer (HBM) before the timed region
+                return self.runner.static_y
+            self.runner.static_y = self.plan.forward(self.runner.static_x)
+            return self.runner.static_y
+        if self.graph is not None:
+            self.graph.replay()
+            return self.static_y
+        return self.eager(self.x)
+
+    def logits(self):
+        out = self.free_runner.outputs() if self.free_runner is not None else self.step()
+        torch.cuda.synchronize()
+        return out.float().cpu()
+
+    def launch_desc(self):
+        if self.free_runner is not None:
+            return f"{self.streams} free-running stream shards, one hipGraph replay per shard and step"
+        g = "eager" if (self.args.no_graph or (self.runner is None and self.graph is None)) else "hipGraph replay"
+        return g + (f", {self.streams} stream shards (fork/join inside the graph; fastervit_amd.inference.CompiledInference)" if self.deploy and self.streams > 1 else "")
+
+
+def step_dispersion(cfg, n):
+    """min / median / max over n individually timed steps (event pair per step; not the throughput measurement)."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    torch.cuda.synchronize()
+    for a, b in evs:
+        a.record()
+        cfg.step()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    return {"n": n, "min": round(ms[0], 4), "median": round(statistics.median(ms), 4), "max": round(ms[-1], 4),
+            "note": "one event pair per step, steps issued back to back (includes the replay launch gap)"}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# roofline rows per (kernel, launch shape)
+# ------------------------------------------------------------------------------------------------------------------------
+def profile_shapes(cfg, prof_steps, serialize=True):
+    """Eager pass with the SAME launches as the timed region (shard-sized), shards issued one after the other on one stream, an
+    event pair around every launch: a kernel's duration is then its own (the regime rocprofv3 --kernel-trace measures too)."""
+    from fastervit_amd import _lib
+    plan = cfg.plan
+    if plan is not None:
+        plan.serialize_shards = serialize
+    cfg.eager(cfg.x)   # sizes anything the serialized order needs, outside the recorded pass
+    torch.cuda.synchronize()
+    _lib.prof_enable(True)
+    for _ in range(prof_steps):
+        cfg.eager(cfg.x)
+    torch.cuda.synchronize()
+    recs = _lib.prof_records()
+    _lib.prof_enable(False)
+    if plan is not None:
+        plan.serialize_shards = False
+    rows = {}
+    for r in recs:
+        key = (r["kind"], r["name"], r["grid"], round(r["flops"]), round(r["bytes"]))
+        e = rows.setdefault(key, dict(kind=r["kind"], kernel=r["name"] or r["kind"], workgroups=r["grid"], launches=0, ms=0.0,
+                                      flops=r["flops"], bytes=r["bytes"]))
+        e["launches"] += 1
+        e["ms"] += r["ms"]
+    out = []
+    for e in rows.values():
+        us = e["ms"] * 1e3 / e["launches"]
+        inten = e["flops"] / max(e["bytes"], 1.0)
+        bound = "mfma" if inten >= RIDGE else "hbm"
+        tf, gbs = e["flops"] / us / 1e6, e["bytes"] / us / 1e3
+        out.append(dict(kernel=e["kernel"], kind=e["kind"], workgroups=e["workgroups"], launches_per_step=e["launches"] // prof_steps,
+                        avg_launch_us=round(us, 2), ms_per_step=round(e["ms"] / prof_steps, 4),
+                        algorithmic_mflop_per_launch=round(e["flops"] / 1e6, 2), algorithmic_mbyte_per_launch=round(e["bytes"] / 1e6, 3),
+                        flop_per_byte=round(inten, 1), bound=bound, tflops=round(tf, 2), gbs=round(gbs, 1),
+                        frac=round((tf / MFMA_PEAK_TFLOPS) if bound == "mfma" else (gbs / HBM_PEAK_GBS), 4)))
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
+
+
+def pmc_row(kernel, workgroups):
+    """HBM bytes per launch of (kernel family, workgroups) from the committed rocprofv3 PMC passes of THIS command in eager mode
+    (bench.py cannot sample PMCs on itself); None when the committed file has no row of that launch shape."""
+    path = os.path.join(ROOT, PMC_FILE)
+    if not os.path.exists(path):
+        return None
+    fam = kernel.split("<")[0].split(" ")[0]
+    best = None
+    for r in json.load(open(path)).get("kernels", []):
+        if r["kernel"].startswith(fam) and int(r.get("workgroups", -1)) == int(workgroups):
+            if kernel.startswith("gemm_kernel<"):   # epilogue id is the 2nd template argument of gemm_kernel<T,EPI,...>
+                targs = r["kernel"].split("<", 1)[1].split(",")
+                if len(targs) < 2 or targs[1].strip() != kernel[12]:
+                    continue
+            if best is None or r["total_us"] > best["total_us"]:
+                best = r
+    return best
+
+
+def roofline_entry(row, operand):
+    if row is None:
+        return None
+    e = {"kernel": f"{row['kernel']} <{operand}> x {row['workgroups']} workgroups", "bound": row["bound"],
+         "achieved": row["tflops"] if row["bound"] == "mfma" else row["gbs"], "peak": MFMA_PEAK_TFLOPS if row["bound"] == "mfma" else HBM_PEAK_GBS,
+         "unit": "TFLOP/s" if row["bound"] == "mfma" else "GB/s", "frac": row["frac"], "traffic": None, "traffic_source": None,
+         "flop_per_byte": row["flop_per_byte"], "tflops": row["tflops"], "gbs": row["gbs"], "launches_per_step": row["launches_per_step"],
+         "avg_launch_us": row["avg_launch_us"], "ms_per_step": row["ms_per_step"],
+         "algorithmic_mflop_per_launch": row["algorithmic_mflop_per_launch"], "algorithmic_mbyte_per_launch": row["algorithmic_mbyte_per_launch"],
+         "selection": "the (kernel, launch shape) with the largest summed time per step among the launches of the timed configuration"}
+    pm = pmc_row(row["kernel"], row["workgroups"])
+    if pm is not None:
+        e["traffic"] = int(pm["hbm_traffic_mb"] * 1e6)
+        e["traffic_over_algorithmic"] = round(pm["hbm_traffic_mb"] / max(row["algorithmic_mbyte_per_launch"], 1e-9), 2)
+        e["traffic_source"] = (f"{PMC_FILE}: {pm['kernel']} x {pm['workgroups']} workgroups, read {pm['hbm_read_mb']} MB (2 x FETCH_SIZE) + "
+                               f"write {pm['hbm_write_mb']} MB per launch, {pm.get('avg_us_under_pmc', '?')} us in that pass")
+    return e
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# parity and CPU baseline (the oracle is imported ONLY here, after the timed region)
+# ------------------------------------------------------------------------------------------------------------------------
+def oracle_arch(model_name, model_kwargs):
+    from tests.cases import CASES
+    for c in CASES.values():
+        if c["entry"] == model_name and c["kwargs"] == (model_kwargs or {}) and c["family"] == "init":
+            return dict(c["arch"])
+    return None
+
+
+def parity_vs_oracle(cfg, logits_gpu, arch, indices, what):
+    from oracle.model_reference import model_forward
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = model_forward(cfg.sd_cpu, cfg.x_cpu[indices], arch)
+    err = (logits_gpu[indices] - ref).abs().max().item()
+    return {"logits_max_abs_err": float(f"{err:.3e}"), "logits_abs_max": round(ref.abs().max().item(), 4), "images": len(indices),
+            "relative": float(f"{err / max(ref.abs().max().item(), 1e-30):.3e}"), "vs": what}, ref
+
+
+def cpu_baseline(cfg, arch, seconds):
+    from oracle.model_reference import model_forward
+    ncpu = os.cpu_count() or 1
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out = {}
+    gen = torch.Generator().manual_seed(77)
+    for nb in (8, 64):
+        xs = cfg.x_cpu[:nb] if nb <= cfg.batch else torch.randn(nb, 3, cfg.H, cfg.W, generator=gen)
+        cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu})
+        best_t, best_dt = cands[0], float("inf")
+        torch.set_num_threads(cands[0])
+        model_forward(cfg.sd_cpu, xs[:8], arch)   # warm-up
+        for t in cands:   # small-batch fp32 inference does not scale to hundreds of threads: pick the fastest of a few counts
+            torch.set_num_threads(t)
+            t1 = time.perf_counter()
+            model_forward(cfg.sd_cpu, xs, arch)
+            dt = time.perf_counter() - t1
+            if dt < best_dt:
+                best_t, best_dt = t, dt
+        torch.set_num_threads(best_t)
+        n, t_cpu = 0, 0.0
+        while t_cpu < seconds and n < 50:
+            t1 = time.perf_counter()
+            model_forward(cfg.sd_cpu, xs, arch)
+            t_cpu += time.perf_counter() - t1
+            n += 1
+        out[nb] = {"value": round(nb * n / t_cpu, 2), "unit": "images/s", "cores": best_t, "kind": "port", "cpu_model": model, "host_threads": ncpu,
+                   "sample": f"{cfg.name} fp32 oracle (port of the reference CPU path), batch {nb}, {n} iterations ({t_cpu:.1f} s), "
+                             f"{best_t} of {ncpu} host threads (fastest of {cands})"}
+    head = dict(out[8])
+    head["batch_64"] = out[64]
+    return head
+
+
+def run_secondary(args, dev):
+    """BASELINE configs 3 and 5, a few steps each (N = 1 only): throughput, parity on 2 images vs the oracle, dominant-shape roofline."""
+    from fastervit_amd import dp
+    res = []
+    specs = [("faster_vit_4_224", 128, None, {}),
+             ("faster_vit_4_any_res", 8, (576, 960), dict(resolution=[576, 960], window_size=[7, 7, 12, 6], ct_size=2))]
+    for name, batch, hw, kw in specs:
+        t0 = time.perf_counter()
+        try:
+            cfg = Config(args, dev, 0, name, batch, hw=hw, model_kwargs=kw, streams=args.streams)
+            cfg.prepare()
+            elapsed = dp.timed_steps(cfg.step, args.secondary_steps, 3, torch.cuda.synchronize, None, dev)
+            logits = cfg.logits()
+            arch = oracle_arch(name, kw)
+            par = None
+            if arch is not None:
+                idx = [0, batch - 1]
+                par, _ = parity_vs_oracle(cfg, logits, arch, idx, f"CPU oracle fp32, images {idx} of the batch")
+            shapes = profile_shapes(cfg, 1) if args.prof_steps > 0 else []
+            res.append({"workload": f"{name} inference, {cfg.H}x{cfg.W}, batch {batch}, random-init weights", "value": round(batch * args.secondary_steps / elapsed, 1),
+                        "unit": "images/s", "steps": args.secondary_steps, "ms_per_step": round(elapsed / args.secondary_steps * 1e3, 4),
+                        "launch": cfg.launch_desc(), "parity": par, "roofline": roofline_entry(shapes[0] if shapes else None, args.operand),
+                        "wall_s": round(time.perf_counter() - t0, 1)})
+            del cfg
+        except Exception as e:  # a secondary config must never take the headline line down with it
+            res.append({"workload": name, "error": f"{type(e).__name__}: {e}"[:300]})
+        torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -67,234 +355,88 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    import fastervit_amd
-    from fastervit_amd import _lib
-    torch.manual_seed(0)  # same random-init weights on every rank
-    import ast
     mk = ast.literal_eval(args.model_kwargs) if args.model_kwargs else {}
-    model = fastervit_amd.create_model(args.model, **mk).eval()
-    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
-    model = model.to(dev).to(memory_format=torch.channels_last)
-    model.set_hat_operand_dtype(args.operand)
-    H = W = model.pretrained_cfg["input_size"][-1]
-    if args.input_size:
-        H, W = (int(v) for v in args.input_size.lower().split("x"))
-    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    x_cpu = torch.randn(args.batch, 3, H, W, generator=gen)
-    x = x_cpu.to(dev).contiguous(memory_format=torch.channels_last)
-    conv_dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": None}[args.conv_dtype]
-    deploy = args.mode == "deploy" and conv_dt is not None
-    if deploy:
-        if args.shard_sizes:
-            sizes = [int(v) for v in args.shard_sizes.split(",")]
-            args.streams = len(sizes)
-        model.switch_to_deploy(conv_dt, streams=args.streams)
-        if args.shard_sizes:
-            model.__dict__["_deploy_plan"].shard_sizes = sizes
-
-    if not deploy:
-        # --mode module measures the plain nn.Module path (MIOpen convs); --mode auto the same call under autocast with the
-        # automatic deploy plan (what validate.py --amp gets)
-        model.auto_deploy = args.mode == "auto"
-
-    def forward(inp):
-        with torch.no_grad():
-            if deploy or conv_dt is None:
-                return model(inp)
-            with torch.autocast("cuda", dtype=conv_dt):
-                return model(inp)
-
-    # warm-up on the eager path (packs weights, allocates workspaces, lets MIOpen pick kernels)
-    for _ in range(2):
-        y = forward(x)
-    torch.cuda.synchronize()
-    graph = None
-    runner = None
-    if deploy and args.streams > 1 and not args.no_graph and args.shard_launch == "free":
-        runner = model.__dict__["_deploy_plan"].shard_runner(x, args.streams)
-    elif not args.no_graph:
-        try:
-            static_x = x.clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    forward(static_x)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()  # a hipGraph on ROCm
-            with torch.cuda.graph(graph):
-                static_y = forward(static_x)
-            torch.cuda.synchronize()
-        except Exception as e:  # report and measure eagerly rather than abort the bench
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-
-    def step():
-        if runner is not None:
-            runner.launch()
-            return None
-        if graph is not None:
-            graph.replay()
-            return static_y
-        return forward(x)
+    hw = tuple(int(v) for v in args.input_size.lower().split("x")) if args.input_size else None
+    cfg = Config(args, dev, rank, args.model, args.batch, hw=hw, model_kwargs=mk, streams=args.streams)
+    cfg.prepare()
 
     # W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks
-    elapsed = dp.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
+    elapsed = dp.timed_steps(cfg.step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
     value = dp.whole_job_rate(args.batch * args.steps, elapsed, dist, dev)
-    logits_gpu = (runner.outputs() if runner is not None else step()).float().cpu()
+    logits_gpu = cfg.logits()
+
+    def finish():
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
 
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
+        return finish()
     ms_per_step = elapsed / args.steps * 1e3
-
-    # ---- roofline of the dominant HAT kernel: live HIP-event timing of every launch (eager pass) ----
-    if args.prof_steps <= 0:  # timeline runs under rocprofv3 (scripts/gpu_trace.sh): no eager profiling pass
-        print(json.dumps({"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "roofline": None}))
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    def profile_pass():
-        _lib.prof_enable(True)
-        for _ in range(args.prof_steps):
-            forward(x)
-        torch.cuda.synchronize()
-        pr = _lib.prof_collect()
-        _lib.prof_enable(False)
-        return pr
-
-    def roofline_of(pr, dom=None):
-        # dominant HAT kernel = the MFMA kernel family with the largest summed time per step; its roof follows from its
-        # algorithmic intensity (FLOP per compulsory HBM byte) against the ridge 2.5e15 / 8e12 = 312 FLOP/B
-        if dom is None:
-            kinds = [k for k in pr if (k.startswith("gemm") or k in ("mlp_fused", "attn_block_fused")) and pr[k]["launches"]]
-            dom = max(kinds, key=lambda k: pr[k]["ms"])
-        e = pr[dom]
-        sec = e["ms"] * 1e-3
-        intensity = e["flops"] / max(e["bytes"], 1.0)
-        if intensity >= MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
-            bound, achieved, peak, unit = "mfma", e["flops"] / sec / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
-        else:
-            bound, achieved, peak, unit = "hbm", e["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
-        return dom, {"kernel": f"{dom} <{args.operand}>", "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                     "frac": round(achieved / peak, 4), "traffic": None,
-                     "flop_per_byte": round(intensity, 1), "tflops": round(e["flops"] / sec / 1e12, 2),
-                     "launches_per_step": e["launches"] // args.prof_steps,
-                     "avg_launch_us": round(e["ms"] * 1e3 / e["launches"], 2),
-                     "algorithmic_gflop_per_launch": round(e["flops"] / e["launches"] / 1e9, 3),
-                     "algorithmic_mbyte_per_launch": round(e["bytes"] / e["launches"] / 1e6, 3)}
-
-    def pmc_traffic(kind, shard_sized):
-        """HBM bytes per launch of the kernel family `kind` from the committed rocprofv3 PMC passes (profiles/, collected with
-        scripts/gpu_prof.sh + scripts/pmc_traffic_summary.py on the same command in eager mode): bench.py cannot sample PMCs on
-        itself.  Picks the (kernel, grid) row with the largest summed time, i.e. the launch shape that dominates the family."""
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic_by_kernel_v13.json")
-        prefix = {"mlp_fused": "mlp_fused_kernel", "attn_block_fused": "attnblk_kernel", "gemm_bias": f"gemm_kernel<{args.operand},0",
-                  "gemm_gelu": f"gemm_kernel<{args.operand},1", "gemm_residual": f"gemm_kernel<{args.operand},2"}.get(kind)
-        if not shard_sized or prefix is None or not os.path.exists(path) or args.model != "faster_vit_0_224" or args.batch != 256:
-            return None, None
-        rows = [r for r in json.load(open(path))["kernels"] if r["kernel"].startswith(prefix)]
-        if not rows:
-            return None, None
-        r = max(rows, key=lambda r: r["total_us"])
-        return int(r["hbm_traffic_mb"] * 1e6), (f"profiles/r01_pmc_hbm_traffic_by_kernel_v13.json: {r['kernel']} x {r['workgroups']} workgroups, "
-                                                f"read {r['hbm_read_mb']} MB (2 x FETCH_SIZE) + write {r['hbm_write_mb']} MB per launch")
-
-    def kernel_table(pr):
-        return {k: {"launches_per_step": v["launches"] // args.prof_steps, "ms_per_step": round(v["ms"] / args.prof_steps, 4),
-                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
-                for k, v in pr.items() if v["launches"]}
-
-    # ---- roofline of the dominant HAT kernel: live HIP-event timing of every launch in an eager pass with the SAME launches as
-    # the timed region (shard-sized), the shards issued one after the other on one stream: an event pair then brackets one
-    # kernel alone on the GPU -- the regime rocprofv3 --kernel-trace measures too (it serialises dispatches), so the two agree ----
-    plan = model.__dict__.get("_deploy_plan")
-    if plan is not None:
-        plan.serialize_shards = True
-    prof = profile_pass()
-    if plan is not None:
-        plan.serialize_shards = False
-    hat_ms = sum(e["ms"] for k, e in prof.items() if k not in ("other", "conv3x3")) / args.prof_steps
-    dom, roofline = roofline_of(prof)
-    roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, deploy and args.streams == 3)
-    kernels = kernel_table(prof)
-    # ---- the same kernels with the GPU to themselves: one stream, whole-batch launches (kernel quality, not job throughput) ----
-    roofline_isolated = None
-    if plan is not None and getattr(plan, "streams", 1) > 1:
-        shards = plan.streams
-        plan.streams = 1
-        forward(x)  # sizes the whole-batch workspace outside the profiled pass
-        torch.cuda.synchronize()
-        prof1 = profile_pass()
-        plan.streams = shards
-        _, roofline_isolated = roofline_of(prof1, dom)
-        roofline_isolated["launch"] = "eager, 1 stream, whole-batch launches"
-        roofline_isolated["kernels"] = kernel_table(prof1)
-
-    # ---- CPU baseline: the oracle (port of the reference fp32 CPU path) on a bounded sample ----
-    cpu = None
-    parity = None
-    if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0's host cores are shared with the other ranks otherwise)
-        from oracle.model_reference import model_forward
-        from tests.cases import CASES
-        arch = dict(CASES["fvit0_224"]["arch"]) if args.model == "faster_vit_0_224" else None
-        if arch is not None:
-            nb = 8
-            xs = x_cpu[:nb]
-            ncpu = os.cpu_count() or 1
-            # small-batch fp32 inference does not scale to hundreds of threads: pick the fastest of a few
-            # thread counts on one iteration each, then time the bounded sample with that count
-            cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu})
-            torch.set_num_threads(cands[0])
-            ref = model_forward(sd_cpu, xs, arch)  # warm-up + parity reference
-            best_t, best_dt = cands[0], float("inf")
-            for t in cands:
-                torch.set_num_threads(t)
-                model_forward(sd_cpu, xs, arch)
-                t1 = time.perf_counter()
-                model_forward(sd_cpu, xs, arch)
-                dt = time.perf_counter() - t1
-                if dt < best_dt:
-                    best_t, best_dt = t, dt
-            torch.set_num_threads(best_t)
-            n, t_cpu = 0, 0.0
-            while t_cpu < args.cpu_seconds and n < 50:
-                t1 = time.perf_counter()
-                model_forward(sd_cpu, xs, arch)
-                t_cpu += time.perf_counter() - t1
-                n += 1
-            cpu = {"value": round(nb * n / t_cpu, 2), "unit": "images/s", "cores": best_t, "kind": "port",
-                   "sample": f"{args.model} fp32 oracle (port of the reference CPU path), batch {nb}, {n} iterations "
-                             f"({t_cpu:.1f} s), {best_t} of {ncpu} host threads (fastest of {cands})"}
-            err = (logits_gpu[:nb] - ref).abs().max().item()
-            parity = {"logits_max_abs_err": float(f"{err:.3e}"), "logits_abs_max": round(ref.abs().max().item(), 4),
-                      "vs": "CPU oracle fp32, first 8 images of rank 0's batch", "weights": "random init (seed 0)"}
-
+    H, W = cfg.H, cfg.W
+    headline = (args.model, args.batch, H, W) == ("faster_vit_0_224", 256, 224, 224)
     out = {
-        "metric": ("images/sec FasterViT-0 224x224 inference, bs=256/GPU" if (args.model, args.batch, H) == ("faster_vit_0_224", 256, 224)
-                   else f"images/sec {args.model} {H}x{W} inference, bs={args.batch}/GPU (secondary config)"), "value": round(value, 1), "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.operand, "data": "synthetic",
+        "metric": ("images/sec FasterViT-0 224x224 inference, bs=256/GPU" if headline
+                   else f"images/sec {args.model} {H}x{W} inference, bs={args.batch}/GPU (secondary config)"),
+        "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.operand,
+        "data": "synthetic",
         "config": {"workload": f"{args.model} inference, {H}x{W}, batch {args.batch}/GPU, random-init weights",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent shards, no data-path collective)",
-                   "hat_operands": args.operand, "conv_side": (f"deploy plan: BN folded, {args.conv_dtype} channels_last, fused HIP conv3x3 (halo-tiled / implicit-GEMM) + stem + LayerNorm2d "
-                                               "kernels (MIOpen only for channel counts the kernels do not cover; none in this model)"
-                                 if deploy else (f"model(x) under autocast {args.conv_dtype}: automatic deploy plan ({model.auto_deploy_streams} stream shards)" if args.mode == "auto"
-                                                 else f"PyTorch-ROCm nn.Module forward, channels_last, autocast {args.conv_dtype}")),
-                   "launch": (f"{args.streams} free-running stream shards, one hipGraph replay per shard and step, no join between steps" if runner is not None
-                              else ("hipGraph replay" if graph is not None else "eager") + (f", {args.streams} stream shards (fork/join)" if deploy and args.streams > 1 else ""))},
-        "roofline": roofline, "roofline_isolated": roofline_isolated, "cpu_baseline": cpu, "parity": parity,
-        "hat_ms_per_step": round(hat_ms, 4), "hat_kernels": kernels,
+                   "hat_operands": args.operand,
+                   "conv_side": (f"deploy plan: BN folded, {args.conv_dtype} channels_last, HIP conv3x3 (halo-tiled / implicit-GEMM) + fused stem + LayerNorm2d kernels"
+                                 if cfg.deploy else (f"model(x) under autocast {args.conv_dtype}: automatic deploy plan" if args.mode == "auto"
+                                                     else f"PyTorch-ROCm nn.Module forward, channels_last, autocast {args.conv_dtype}")),
+                   "launch": cfg.launch_desc()},
     }
+    if args.prof_steps <= 0:   # timeline runs under rocprofv3 (scripts/gpu_trace.sh): nothing but the timed region
+        out["roofline"] = None
+        print(json.dumps(out))
+        return finish()
+
+    out["step_ms"] = step_dispersion(cfg, min(max(args.steps, 5), 30))
+    shapes = profile_shapes(cfg, args.prof_steps)
+    hat = [r for r in shapes if r["kind"] not in ("other", "conv3x3")]
+    dom = max((r for r in shapes if r["algorithmic_mflop_per_launch"] > 0 and r["kind"] != "conv3x3"), key=lambda r: r["ms_per_step"], default=None)
+    out["roofline"] = roofline_entry(dom, args.operand)
+    out["roofline_shapes"] = shapes[:24]
+    out["hat_ms_per_step"] = round(sum(r["ms_per_step"] for r in hat), 4)
+    out["kernel_ms_per_step_serialized"] = round(sum(r["ms_per_step"] for r in shapes), 4)
+    out["launches_per_step"] = sum(r["launches_per_step"] for r in shapes)
+    if cfg.plan is not None and cfg.plan.streams > 1:
+        # the same kernels with the GPU to themselves: one stream, whole-batch launches (kernel quality, not job throughput)
+        n = cfg.plan.streams
+        cfg.plan.streams = 1
+        iso = profile_shapes(cfg, 1, serialize=False)
+        cfg.plan.streams = n
+        out["roofline_isolated"] = {"launch": "eager, 1 stream, whole-batch launches", "shapes": iso[:12]}
+
+    cpu = parity = parity_bf16 = None
+    arch = oracle_arch(args.model, mk)
+    if world == 1 and arch is not None:   # N = 1 only: rank 0's host cores are shared with the other ranks otherwise
+        sizes = [p.shape[0] for p in cfg.x_cpu.chunk(cfg.streams)] if cfg.streams > 1 else [args.batch]
+        starts = [sum(sizes[:i]) for i in range(len(sizes))]
+        idx = [s + j for s, n in zip(starts, sizes) for j in range(min(8, n))]
+        parity, _ = parity_vs_oracle(cfg, logits_gpu, arch, idx, f"CPU oracle fp32; 8 images from each of the {len(sizes)} stream shards (shard starts {starts})")
+        parity["weights"] = "random init (seed 0)"
+        parity["tolerance"] = "north_star: logits max-abs < 1e-3"
+        # the other 16-bit operand type on the same images (eager, same plan): reported, not timed
+        other = "bf16" if args.operand == "f16" else "f16"
+        cfg.model.set_hat_operand_dtype(other)
+        y = cfg.eager(cfg.x).float().cpu()
+        cfg.model.set_hat_operand_dtype(args.operand)
+        pb, _ = parity_vs_oracle(cfg, y, arch, idx[:8], f"CPU oracle fp32, first 8 images, HAT operands {other} (conv side {args.conv_dtype})")
+        pb["meets_1e-3"] = bool(pb["logits_max_abs_err"] < 1e-3)
+        out["parity_" + other] = pb
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, arch, args.cpu_seconds)
+    out["cpu_baseline"], out["parity"] = cpu, parity
+    if world == 1 and headline and not args.no_secondary:
+        del cfg
+        torch.cuda.empty_cache()
+        out["secondary"] = run_secondary(args, dev)
     print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish()
 
 
 if __name__ == "__main__":

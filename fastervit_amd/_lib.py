@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_window_attention", "fvit_window_attention_long",
     "fvit_gather_layernorm", "fvit_attn_block_supported", "fvit_attn_block_fused", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl", "fvit_conv3x3_nhwc", "fvit_stem_conv3x3s2", "fvit_stem_fused",
     "fvit_head_logits", "fvit_head_softmax_xent", "fvit_head_grad", "fvit_sgd_momentum",
-    "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_kind_name",
+    "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_records", "fvit_prof_kind_name",
 )
 
 
@@ -64,6 +64,11 @@ class FvitMapView(C.Structure):
 
 class FvitProfEntry(C.Structure):
     _fields_ = [("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+class FvitProfRecord(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("grid", C.c_int32), ("ms", C.c_float), ("_pad", C.c_float), ("flops", C.c_double),
+                ("bytes", C.c_double), ("name", C.c_char * 40)]
 
 
 _lib = None
@@ -150,6 +155,8 @@ def _declare(lib):
     lib.fvit_prof_enable.argtypes = [C.c_int]
     lib.fvit_prof_collect.restype = C.c_int
     lib.fvit_prof_collect.argtypes = [C.POINTER(FvitProfEntry)]
+    lib.fvit_prof_records.restype = C.c_int
+    lib.fvit_prof_records.argtypes = [C.POINTER(FvitProfRecord), i32]
     lib.fvit_prof_kind_name.restype = C.c_char_p
     lib.fvit_prof_kind_name.argtypes = [C.c_int]
 
@@ -201,3 +208,14 @@ def prof_collect() -> dict:
         out[lib().fvit_prof_kind_name(k).decode()] = dict(launches=int(e.launches), ms=float(e.ms), flops=float(e.flops),
                                                          bytes=float(e.bytes))
     return out
+
+
+def prof_records(max_records: int = 65536) -> list:
+    """Per-launch records since prof_enable(True): dicts(kind, name, grid, ms, flops, bytes) in launch order."""
+    arr = (FvitProfRecord * max_records)()
+    n = lib().fvit_prof_records(arr, max_records)
+    if n < 0:
+        check(n, "fvit_prof_records")
+    kinds = [lib().fvit_prof_kind_name(k).decode() for k in range(FVIT_PROF_KINDS)]
+    return [dict(kind=kinds[arr[i].kind] if 0 <= arr[i].kind < FVIT_PROF_KINDS else "other", name=arr[i].name.decode("utf-8", "replace"),
+                 grid=int(arr[i].grid), ms=float(arr[i].ms), flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(n)]

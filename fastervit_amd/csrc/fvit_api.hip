@@ -70,6 +70,8 @@ int tune_get(const char* key, int dflt) {
 struct ProfRec {
     int kind;
     double flops, bytes;
+    int grid;
+    char name[40];
 };
 static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_events;  // 2 per record
@@ -83,12 +85,20 @@ ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t stream) :
         if (hipEventCreate(&e) != hipSuccess) { slot_ = -1; return; }
         g_events.push_back(e);
     }
-    g_recs.push_back({kind, flops, bytes});
+    g_recs.push_back({kind, flops, bytes, 0, {0}});
     hipEventRecord(g_events[2 * slot_], stream_);
 }
 
 ProfScope::~ProfScope() {
     if (slot_ >= 0) hipEventRecord(g_events[2 * slot_ + 1], stream_);
+}
+
+void prof_note(const char* kernel, int grid) {
+    if (!g_prof_on || g_recs.empty()) return;
+    ProfRec& r = g_recs.back();
+    r.grid = grid;
+    strncpy(r.name, kernel ? kernel : "", sizeof(r.name) - 1);
+    r.name[sizeof(r.name) - 1] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -165,7 +175,7 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
     GemmCall g1 = {dt, xn, L.ldn, w.w_qkv, L.ldn, w.b_qkv, nullptr, qkv, L.ldqkv, (int)rows, L.ldqkv, L.ldn, 0};
     FVIT_TRY(launch_gemm(g1, st));
     const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
-    AttnCall at = {dt, qkv, L.ldqkv, ao, L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale, w.rel_table, w.rel_w, w.rel_ng};
+    AttnCall at = {dt, qkv, L.ldqkv, ao, L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale, w.rel_table, w.rel_w, w.rel_ng, d.C / d.heads};
     FVIT_TRY(launch_attention(at, st));
     GemmCall g2 = {dt, ao, L.ldao, w.w_proj, L.ldao, w.b_proj, w.gamma, x, d.C, (int)rows, d.C, L.ldao, 2};
     FVIT_TRY(launch_gemm(g2, st));
@@ -396,14 +406,14 @@ int fvit_window_attention(int32_t operand_dtype, const void* qkv, int32_t ldq, v
         set_error("window_attention: S=%d at dpad=%d is outside the dense-bias kernel (fvit_attention_dense); use fvit_window_attention_long", S, dpad);
         return FVIT_EINVAL;
     }
-    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, bias, nwin, S, heads, dpad, scale, nullptr, 0, 0};
+    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, bias, nwin, S, heads, dpad, scale, nullptr, 0, 0, 0};
     return launch_attention(a, (hipStream_t)stream);
 }
 
 int fvit_window_attention_long(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, const float* rel_table,
                                int32_t rel_w, int32_t rel_ng, int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale,
                                fvit_stream_t stream) {
-    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, nullptr, nwin, S, heads, dpad, scale, rel_table, rel_w, rel_ng};
+    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, nullptr, nwin, S, heads, dpad, scale, rel_table, rel_w, rel_ng, 0};
     return launch_attention_long(a, (hipStream_t)stream);
 }
 
@@ -469,6 +479,29 @@ int fvit_prof_collect(FvitProfEntry* out) {
         e.bytes += r.bytes;
     }
     return FVIT_OK;
+}
+
+int fvit_prof_records(FvitProfRecord* out, int32_t max_records) {
+    if (!out || max_records < 0) return FVIT_EINVAL;
+    int n = 0;
+    for (size_t i = 0; i < g_recs.size() && n < max_records; ++i, ++n) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_events[2 * i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_events[2 * i], g_events[2 * i + 1]) != hipSuccess) {
+            set_error("profiler: event read failed (was the region captured into a graph?)");
+            (void)hipGetLastError();
+            return FVIT_ELAUNCH;
+        }
+        const ProfRec& r = g_recs[i];
+        FvitProfRecord& o = out[n];
+        o.kind = r.kind;
+        o.grid = r.grid;
+        o.ms = ms;
+        o.flops = r.flops;
+        o.bytes = r.bytes;
+        memcpy(o.name, r.name, sizeof(o.name));
+    }
+    return n;
 }
 
 const char* fvit_prof_kind_name(int kind) {

@@ -237,9 +237,11 @@ int launch_attention(const AttnCall& c, hipStream_t stream) {
     AttnParams p;
     p.qkv = c.qkv; p.out = c.out; p.bias = c.bias; p.ldq = c.ldq; p.ldo = c.ldo;
     p.nwin = c.nwin; p.S = c.S; p.heads = c.heads; p.scale = c.scale;
-    const double flops = 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * c.dpad;
+    // algorithmic FLOPs count the real head_dim (49 of FasterViT-4 runs on dpad = 64; padding work is not credited)
+    const double flops = 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * (c.d > 0 && c.d <= c.dpad ? c.d : c.dpad);
     const double bytes = 2.0 * c.nwin * (double)c.S * c.heads * c.dpad * 4.0;  // q,k,v read + o write (16-bit)
     ProfScope prof(FVIT_K_ATTENTION, flops, bytes, stream);
+    prof_note("attn_kernel", (c.nwin * c.heads + 3) / 4);
 #define FVIT_ATTN_DP(T) (c.dpad == 32 ? launch_sb<T, 32>(p, sb, stream) : c.dpad == 64 ? launch_sb<T, 64>(p, sb, stream) : launch_sb<T, 96>(p, sb, stream))
     if (c.dtype == FVIT_F16) return FVIT_ATTN_DP(_Float16);
     if (c.dtype == FVIT_BF16) return FVIT_ATTN_DP(__bf16);

@@ -406,6 +406,7 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
     const double flops = 2.0 * rows * c.C * 4.0 * c.C + 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * 32.0;
     const double bytes = 8.0 * rows * c.C + 8.0 * c.C * c.C;
     ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
+    prof_note(c.C == 256 ? (c.S <= 16 ? "attnblk_kernel<256,S16>" : "attnblk_kernel<256,S64>") : "attnblk_kernel<512,S64>", c.nwin);
     const bool small = c.S <= 16;
     // 0 (default): 4 waves / 1 window per workgroup, bias from L2, two workgroups per CU;
     // 1: 8 waves / 2 windows, bias table in LDS, one workgroup per CU -- equal on whole-batch launches (99.9 vs 96.7 us: the

@@ -272,7 +272,7 @@ int launch_attention_long(const AttnCall& c, hipStream_t stream) {
     p.w = c.rel_table ? c.rel_w : 1; p.ng = c.rel_table ? c.rel_ng : c.S;
     p.nqt = (c.S + 63) / 64;
     p.tab_in_lds = 0;
-    const double flops = 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * c.dpad;
+    const double flops = 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * (c.d > 0 && c.d <= c.dpad ? c.d : c.dpad);
     const double bytes = 2.0 * c.nwin * (double)c.S * c.heads * c.dpad * 4.0;
     ProfScope prof(FVIT_K_ATTENTION, flops, bytes, stream);
 #define FVIT_LONG_DP(T) (c.dpad == 32 ? launch_long_t<T, 32>(p, stream) : c.dpad == 64 ? launch_long_t<T, 64>(p, stream) : launch_long_t<T, 96>(p, stream))

@@ -95,6 +95,9 @@ struct ProfScope {
     int slot_;
     hipStream_t stream_;
 };
+// names the launch the innermost live ProfScope brackets: kernel family + launch shape (workgroups), so that the per-launch records
+// (fvit_prof_records) can be matched with a rocprofv3 kernel trace / PMC row of the same (kernel, grid).  No-op when the timer is off.
+void prof_note(const char* kernel, int grid);
 
 // ---- launchers (defined in the .hip files) ----
 struct GemmCall {
@@ -168,6 +171,7 @@ struct AttnCall {
     // S > FVIT_MAX_DENSE_SEQ: compact bias table f32 [heads][(2*rel_w-1)^2] (or null), n_g = rel_ng leading tokens without bias
     const float* rel_table;
     int rel_w, rel_ng;
+    int d;  // real head_dim (<= dpad) for the FLOP count of the kernel timer; 0 = unknown (dpad is used)
 };
 bool attention_dense(int S, int dpad);                               // in-register kernel + dense bias table, else the long kernel
 int launch_attention(const AttnCall& c, hipStream_t stream);        // dispatches on attention_dense(S, dpad)

@@ -541,6 +541,7 @@ int launch_halo_t(const ConvParams& c, hipStream_t stream) {
     const double flops = 2.0 * c.M * 64.0 * 576.0;
     const double bytes = 2.0 * ((double)c.M * 64 * (c.res ? 3.0 : 2.0) + 576.0 * 64);
     ProfScope prof(FVIT_K_CONV, flops, bytes, stream);
+    prof_note("conv3x3_c64_halo_kernel", grid);
     p.buf_bytes = c.res ? HALO_BUF : HALO_BYTES;
     const size_t lds = 1024 + 2 * (size_t)p.buf_bytes;
     static DeviceOnce once;   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device and kernel instance)
@@ -769,14 +770,17 @@ int launch_t(ConvParams& p, hipStream_t stream) {
     if (p.Cout % 128 == 0 && !narrow) {
         p.tiles_m = (p.M + 127) / 128;
         p.tiles_n = p.Cout / 128;
+        prof_note("conv3x3_kernel<2,2,4>", p.tiles_m * p.tiles_n);
         hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
     } else if (variant == 1) {  // 256 pixels x 64 channels, 80 KiB LDS
         p.tiles_m = (p.M + 255) / 256;
         p.tiles_n = p.Cout / 64;
+        prof_note("conv3x3_kernel<4,1,4>", p.tiles_m * p.tiles_n);
         hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
     } else {  // 128 pixels x 64 channels, 48 KiB LDS: three workgroups per CU
         p.tiles_m = (p.M + 127) / 128;
         p.tiles_n = p.Cout / 64;
+        prof_note("conv3x3_kernel<2,2,2>", p.tiles_m * p.tiles_n);
         hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
     }
     return check_launch("conv3x3_kernel");
@@ -869,6 +873,7 @@ extern "C" int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void*
     const double M1 = (double)B * p.H1 * p.W1, M2 = (double)B * p.H2 * p.W2;
     const double bytes = (double)B * 3 * Hi * Wi * (in->dtype == FVIT_F32 ? 4 : 2) + 2.0 * M2 * 64;
     ProfScope prof(FVIT_K_CONV, 2.0 * M1 * 64 * 27 + 2.0 * M2 * 64 * 576, bytes, (hipStream_t)stream);
+    prof_note("stem_fused_kernel", grid);
     if (dtype == FVIT_F16) {
         static DeviceOnce once;
         if (once.first_on_current_device())

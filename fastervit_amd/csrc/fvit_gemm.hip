@@ -270,6 +270,9 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
         kind = c.epilogue == 1 ? FVIT_K_GEMM_GELU : FVIT_K_GEMM_BIAS;
     }
     ProfScope prof(kind, flops, bytes, stream);
+    prof_note(c.epilogue == 2 ? (small ? "gemm_kernel<2> 64-row" : "gemm_kernel<2> 128-row")
+                              : c.epilogue == 1 ? (small ? "gemm_kernel<1> 64-row" : "gemm_kernel<1> 128-row")
+                                                : (small ? "gemm_kernel<0> 64-row" : "gemm_kernel<0> 128-row"), grid);
     // measured r01: a 3-stage ring with counted vmcnt gave no gain over 2 stages at 64..392 workgroups => opt-in only
     const bool deep = !small && !nw8 && grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
 #define FVIT_GEMM(E, NS, MI_, NW_) hipLaunchKernelGGL((gemm_kernel<T, E, NS, MI_, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p)

@@ -336,6 +336,7 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
     ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
+    prof_note(c.C == 256 ? "mlp_fused_kernel<256>" : "mlp_fused_kernel<512>", (c.M + 63) / 64);
     if (c.C == 256) {
         // variants for within-process A/B (fvit_tune "mlp_variant"); 0 (16 rows per wave, input rows kept in registers) is the default;
         // 3 = the r01 v1-v10 default (32 rows per wave, X re-read in the epilogue)

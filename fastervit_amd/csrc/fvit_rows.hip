@@ -367,6 +367,7 @@ int launch_gather_layernorm(const LnCall& c, hipStream_t stream) {
     p.rows_per_image = c.rows_per_image > 0 ? c.rows_per_image : 1; p.C = c.C;
     const double bytes = (double)c.rows * c.C * (4.0 + (c.x_out ? 4.0 : 0.0) + 2.0);
     ProfScope prof(FVIT_K_LAYERNORM, 8.0 * c.rows * (double)c.C, bytes, stream);
+    prof_note("ln_kernel", (c.rows + 3) / 4);
     if (c.dtype == FVIT_F16) return launch_ln_t<_Float16>(p, stream);
     if (c.dtype == FVIT_BF16) return launch_ln_t<__bf16>(p, stream);
     set_error("layernorm: operand dtype %d not supported", c.dtype);

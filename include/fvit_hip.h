@@ -346,8 +346,19 @@ typedef struct FvitProfEntry {
     double flops;  /* algorithmic FLOPs of those launches (2*M*N*K for GEMMs, 4*S*S*d per head for attention) */
     double bytes;  /* algorithmic HBM bytes (compulsory reads + writes) */
 } FvitProfEntry;
+/* one record per launch, in launch order: what bench.py builds its per-(kernel, launch shape) roofline rows from */
+typedef struct FvitProfRecord {
+    int32_t kind;   /* FVIT_K_* */
+    int32_t grid;   /* workgroups of the launch (0 when the launcher does not report it) */
+    float ms;       /* event-to-event time of THIS launch */
+    float _pad;
+    double flops;   /* algorithmic FLOPs of this launch */
+    double bytes;   /* algorithmic (compulsory) HBM bytes of this launch */
+    char name[40];  /* kernel family + variant, e.g. "gemm_residual bm64" */
+} FvitProfRecord;
 int fvit_prof_enable(int on);             /* starts/stops recording; enabling resets the counters */
 int fvit_prof_collect(FvitProfEntry* out); /* synchronises the recorded events; out[FVIT_PROF_KINDS] */
+int fvit_prof_records(FvitProfRecord* out, int32_t max_records); /* per-launch records since fvit_prof_enable(1); returns the count (<= max) or < 0 */
 const char* fvit_prof_kind_name(int kind);
 
 #ifdef __cplusplus

@@ -5,8 +5,8 @@ R=$GRAFT_REPO_ROOT
 T=${1:-p}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph"
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${T}_prof_stdout.log 2>&1
+CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-graph"
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $R/gpurun_out/${T}_prof_stdout.log 2>&1
 echo "stats rc=$?"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${T}_pmc_fetch -o p -- $CMD > $R/gpurun_out/${T}_pmc_fetch.log 2>&1
 echo "fetch rc=$?"

@@ -8,7 +8,7 @@ S=gpurun_out/${T}_sweep.log
 : > $S
 for E in "$@"; do
   if [ "$E" = "-" ]; then EV=""; else EV="$E"; fi
-  R=$(env $EV timeout 300 python bench.py --no-cpu-baseline --prof-steps 1 $ARGS 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')
+  R=$(env $EV timeout 300 python bench.py --no-cpu-baseline --no-secondary --prof-steps 1 $ARGS 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')
   echo "$E | $ARGS -> $R" >> $S
 done
 cat $S
