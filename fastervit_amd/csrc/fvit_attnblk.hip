@@ -65,7 +65,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 // BIAS_LDS: stage the head's bias table in LDS (else read it from L2 with ordinary loads issued ahead of the DMA)
 // CC: channels (256: stage 2 of FasterViT-0, 8 heads; 512: stage 3, 16 heads -- one 142-KiB workgroup per CU, one wave per SIMD,
 //     so the 128 + 128 + 64 VGPRs of input rows, proj accumulator and LayerNorm fragments fit without spilling)
-template <typename T, int CC, int NRB, int NW, bool BIAS_LDS>
+// DBQ: the per-head qkv weight slice is double buffered: the slice of head h + 1 is requested at the TOP of head h (behind this head's
+//      proj / bias pieces) and has the whole head to land; barrier B then waits with a COUNTED vmcnt for the proj / bias pieces only.
+//      Without it the next slice is requested after barrier B and needed ~0.3 us later (P2 + P3), i.e. one exposed LDS-DMA round trip
+//      per head.  Costs 48 KiB of LDS => one workgroup per CU: used with 8-wave workgroups (two windows, two waves per SIMD).
+template <typename T, int CC, int NRB, int NW, bool BIAS_LDS, bool DBQ = false>
 __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(AttnBlkParams p) {
     typedef typename Op16<T>::v8 v8;
     typedef typename Op16<T>::v4 v4;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
     constexpr int QKV_BYTES = QKV_FRAGS * 1024, PROJ_BYTES = CB * 1024, BIAS_BYTES = BIAS_LDS ? SP * SP * 4 : 0;
     constexpr int KX_BYTES = NW * 1024;       // one 1-KiB k fragment per wave
     constexpr int VX_BYTES = WPW * 2 * NKB32 * 1024;
-    constexpr int OFF_PROJ = QKV_BYTES, OFF_BIAS = OFF_PROJ + PROJ_BYTES, OFF_KX = OFF_BIAS + ((BIAS_BYTES + 1023) / 1024) * 1024;
+    constexpr int OFF_PROJ = (DBQ ? 2 : 1) * QKV_BYTES, OFF_BIAS = OFF_PROJ + PROJ_BYTES, OFF_KX = OFF_BIAS + ((BIAS_BYTES + 1023) / 1024) * 1024;
     constexpr int OFF_VX = OFF_KX + KX_BYTES, OFF_BQ = OFF_VX + VX_BYTES;
     constexpr int MAX_HEADS = CC / 32;
     constexpr int OFF_BP = OFF_BQ + MAX_HEADS * 96 * 4;   // proj bias and gamma (2 x C floats): no global loads in the epilogue
@@ -101,10 +105,11 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
     const char* __restrict__ Wq = (const char*)p.wqkv_f;
     const char* __restrict__ Wp = (const char*)p.wproj_f;
 
-    auto dma_qkv = [&](int h) {   // 48 fragments
+    auto dma_qkv = [&](int h, int slot) {   // 48 fragments into qkv buffer `slot` (always 0 without DBQ)
         const char* src = Wq + (size_t)h * QKV_BYTES + lane16;
+        char* dst = smem + slot * QKV_BYTES;
 #pragma unroll
-        for (int i = 0; i < QKV_FRAGS / NW; ++i) glds16(src + (wave + NW * i) * 1024, smem + (wave + NW * i) * 1024);
+        for (int i = 0; i < QKV_FRAGS / NW; ++i) glds16(src + (wave + NW * i) * 1024, dst + (wave + NW * i) * 1024);
     };
     auto dma_proj_bias = [&](int h) {   // 16 proj fragments + (BIAS_LDS) the head's bias table
         const char* src = Wp + (size_t)h * PROJ_BYTES + lane16;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
     }
     const int hrot = p.stagger ? (int)((blockIdx.x >> 3) % (unsigned)p.heads) : 0;
     auto head_of = [&](int it) { const int hh = it + hrot; return hh >= p.heads ? hh - p.heads : hh; };
-    dma_qkv(head_of(0));
+    dma_qkv(head_of(0), 0);
 
     const float* src;
     const float* addp = nullptr;
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) oacc[cb] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const char* wq_l = smem + lane16;                 // qkv fragments: + (ub * KK + kk) * 1024
+    const char* wq_base = smem + lane16;              // qkv fragments: + (ub * KK + kk) * 1024 (+ the buffer of this head with DBQ)
     const char* wp_l = smem + OFF_PROJ + lane16;      // proj fragments: + cb * 1024
     const float* bias_l = (const float*)(smem + OFF_BIAS);
     char* kx = smem + OFF_KX;
@@ -218,6 +223,9 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
             for (int kb = 0; kb < NRB; ++kb) bzg[kb] = *(const f4*)(bg + kb * 16);
         }
         if (!(p.ablate & 1)) dma_proj_bias(h);
+        const bool next_q = DBQ && hit + 1 < p.heads && !(p.ablate & 1);
+        if (next_q) dma_qkv(head_of(hit + 1), (hit + 1) & 1);
+        const char* wq_l = wq_base + (DBQ ? (hit & 1) * QKV_BYTES : 0);
 
         // ---- P1: q^T, k^T, v ----
         // software-pipelined over the k steps with two fragment register sets: the 6 fragments of step kk + 1 are requested before
@@ -276,9 +284,16 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
         }
 
         // ---- barrier B: proj / bias slices landed, k / v visible, qkv buffer free ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (hit + 1 < p.heads && !(p.ablate & 1)) dma_qkv(head_of(hit + 1));
+        if (DBQ) {
+            // the next head's qkv pieces (QKV_FRAGS / NW per wave, issued AFTER this head's proj / bias pieces) stay in flight; raw
+            // barrier: __syncthreads() would drain them
+            if (next_q) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(QKV_FRAGS / NW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (hit + 1 < p.heads && !(p.ablate & 1)) dma_qkv(head_of(hit + 1), 0);
+        }
 
         // ---- P2: scores^T, softmax over keys, O^T ----
         f4 sc[NRB];
@@ -417,12 +432,17 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
         if (c.C == 256) hipLaunchKernelGGL((attnblk_kernel<T, 256, NRB, NW, BL>), dim3((c.nwin + (NW / NRB) - 1) / (NW / NRB)), dim3(64 * NW), 0, stream, p); \
         else hipLaunchKernelGGL((attnblk_kernel<T, 512, 4, 4, false>), dim3(c.nwin), dim3(256), 0, stream, p); \
     } while (0)
+#define FVIT_AB_DBQ(T) hipLaunchKernelGGL((attnblk_kernel<T, 256, 4, 8, true, true>), dim3((c.nwin + 1) / 2), dim3(512), 0, stream, p)
+    // variant 2: 8 waves / 2 windows, bias in LDS, double-buffered qkv slices (one 149-KiB workgroup per CU)
+    const bool dbq = variant == 2 && c.C == 256 && !small;
     if (c.dtype == FVIT_F16) {
         if (small) FVIT_AB(_Float16, 1, 8, true);
+        else if (dbq) FVIT_AB_DBQ(_Float16);
         else if (variant == 1) FVIT_AB(_Float16, 4, 8, true);
         else FVIT_AB(_Float16, 4, 4, false);
     } else if (c.dtype == FVIT_BF16) {
         if (small) FVIT_AB(__bf16, 1, 8, true);
+        else if (dbq) FVIT_AB_DBQ(__bf16);
         else if (variant == 1) FVIT_AB(__bf16, 4, 8, true);
         else FVIT_AB(__bf16, 4, 4, false);
     } else {
@@ -430,6 +450,7 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
         return FVIT_EINVAL;
     }
 #undef FVIT_AB
+#undef FVIT_AB_DBQ
     return check_launch("attnblk_kernel");
 }
 

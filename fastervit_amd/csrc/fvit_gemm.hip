@@ -146,10 +146,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         } else {
-            // each wave issues 8 LDS-DMA instructions per stage (4 X + 4 W pieces): tile kt has landed once at most the
-            // 8 of tile kt+1 are still outstanding.  Raw barrier: __syncthreads() would drain the queue (vmcnt(0)).
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            // each wave issues PER LDS-DMA instructions per stage (X pieces + W pieces): tile kt has landed once at most the
+            // instructions of the (up to NSTAGE - 2) tiles after it are still outstanding.  Raw barrier: __syncthreads() would
+            // drain the queue (vmcnt(0)).
+            constexpr int PER = BMT / 8 / NW + 128 / 8 / NW;
+            const int ahead = min(NSTAGE - 2, nk - 1 - kt);
+            if (NSTAGE >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PER) : "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         {
             // refill the slot that was read in iteration kt-1 (every wave is past that: it arrived at this barrier)
@@ -275,11 +279,15 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
                                                 : (small ? "gemm_kernel<0> 64-row" : "gemm_kernel<0> 128-row"), grid);
     // measured r01: a 3-stage ring with counted vmcnt gave no gain over 2 stages at 64..392 workgroups => opt-in only
     const bool deep = !small && !nw8 && grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
+    // ring depth of the 64-row tiles (small grids): 2 (48 KiB, three workgroups per CU), 3 (72 KiB, two) or 4 (96 KiB, one)
+    const int ring = small && !nw8 && p.K / BK >= 4 ? tune_get("gemm_ring", 2) : 2;
 #define FVIT_GEMM(E, NS, MI_, NW_) hipLaunchKernelGGL((gemm_kernel<T, E, NS, MI_, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p)
 #define FVIT_GEMM_E(NS, MI_, NW_) \
     switch (c.epilogue) { case 0: FVIT_GEMM(0, NS, MI_, NW_); break; case 1: FVIT_GEMM(1, NS, MI_, NW_); break; default: FVIT_GEMM(2, NS, MI_, NW_); break; }
     if (nw8 && small) { FVIT_GEMM_E(2, 1, 8) }        // 64 rows = 4 waves along M x 16 rows
     else if (nw8) { FVIT_GEMM_E(2, 2, 8) }            // 128 rows = 4 waves x 32 rows
+    else if (small && ring == 4) { FVIT_GEMM_E(4, 2, 4) }
+    else if (small && ring == 3) { FVIT_GEMM_E(3, 2, 4) }
     else if (small) { FVIT_GEMM_E(2, 2, 4) }          // 64 rows = 2 waves x 32 rows
     else if (deep) { FVIT_GEMM_E(3, 4, 4) }
     else { FVIT_GEMM_E(2, 4, 4) }

@@ -61,9 +61,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 //     kch(kk, g, e) = (kk>>1)*64 + g*16 + (kk&1)*8 + e
 // (w_fc1_frag is packed in that order), so the 64 input values a lane loads per row are exactly the 64 output channels it owns
 // in GEMM2's accumulator layout (fragment cb, slot 4g + r <-> channel (cb>>2)*64 + 16g + (cb&3)*4 + r).
-template <typename T, int C, int RB, int NW, int MINW, bool KEEPX>
+// NB: depth of the weight-chunk ring in LDS.  2 = double buffer, drained barrier per chunk, two workgroups per CU (C = 256).  4 = three
+// chunks in flight behind a COUNTED s_waitcnt vmcnt + raw s_barrier, one workgroup per CU: for launches of <= ~1 workgroup per CU,
+// where the chunk loop is otherwise one LDS-DMA round trip per chunk (r02 probe, 32 KiB steps, small grids: 0.88 us per step with a
+// 2-deep ring and every workgroup in lockstep on a cold weight stream vs 0.30 us with a 4-deep ring and staggered chunk order).
+template <typename T, int C, int RB, int NW, int MINW, bool KEEPX, int NB = 2>
 __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
-    constexpr int NBUF = 2;
+    constexpr int NBUF = NB;
     typedef typename Op16<T>::v8 v8;
     constexpr int KK = C / 32;             // GEMM1 k-steps
     constexpr int CB = C / 16;             // output channel blocks
@@ -110,12 +114,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
         for (int i = 0; i < W2_FRAGS / NW; ++i) glds16(s2 + (wave + NW * i) * 1024, buf + W1_BYTES + (wave + NW * i) * 1024);
     };
 
+    constexpr int GLDS_PER_STAGE = (W1_FRAGS + W2_FRAGS) / NW;   // LDS-DMA instructions one wave issues per chunk
+    static_assert(NBUF == 2 || (NBUF - 2) * GLDS_PER_STAGE <= 48, "vmcnt is a 6-bit counter");
     for (int i = tid; i < p.hidden; i += 64 * NW) b1s[i] = p.b1[i];
     for (int i = tid; i < C; i += 64 * NW) {
         b2s[i] = p.b2[i];
         gms[i] = p.gamma ? p.gamma[i] : 1.0f;
     }
-    stage(chunk_of(0), smem);
+#pragma unroll
+    for (int st = 0; st < NBUF - 1; ++st)
+        if (st < nchunk) stage(chunk_of(st), smem + st * BUF_BYTES);
 
     // ---- LayerNorm of this wave's rows straight into B-operand fragments ----
     // lane (g, s) holds channels kch(kk, g, 0..7) = (kk>>1)*64 + g*16 + (kk&1)*8 .. +8 (kk = 0..KK-1) of row rb*16 + s
@@ -171,12 +179,20 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
 
     for (int it = 0; it < nchunk; ++it) {
         const int j = chunk_of(it);
-        const char* buf = smem + (NBUF == 2 ? (it & 1) : 0) * BUF_BYTES + lane16;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        const char* buf = smem + (it % NBUF) * BUF_BYTES + lane16;
         if (NBUF == 2) {
-            if (it + 1 < nchunk && !(p.ablate & 2)) stage(chunk_of(it + 1), smem + ((it + 1) & 1) * BUF_BYTES);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            // chunk `it` has landed once at most the groups of the chunks after it are outstanding; raw barrier: __syncthreads()
+            // would drain the whole DMA queue (vmcnt(0))
+            const int ahead = min(NBUF - 2, nchunk - 1 - it);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * GLDS_PER_STAGE) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(GLDS_PER_STAGE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        // refill the slot chunk it - 1 was read from (every wave is past it: it arrived at this barrier)
+        if (it + NBUF - 1 < nchunk && !(p.ablate & 2)) stage(chunk_of(it + NBUF - 1), smem + ((it + NBUF - 1) % NBUF) * BUF_BYTES);
         if constexpr (RB == 1) {
             // The chunk body is written for a wave that is ALONE on its SIMD (small grids: the carrier-token branch, stage 3, the
             // shard-sized launches of the stream-sharded plan): left to the compiler the loop was "2 ds_read, s_waitcnt lgkmcnt(0),
@@ -293,10 +309,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
                 for (int rb = 0; rb < RB; ++rb) acc2[cb][rb] = Op16<T>::mfma(wf, pf[rb], acc2[cb][rb]);
             }
         }
-        if (NBUF == 1) {
-            __syncthreads();
-            if (it + 1 < nchunk) stage(chunk_of(it + 1), smem);
-        }
     }
 
     // ---- epilogue: x[row][c] += gamma[c] * (acc2 + b2[c]) ----
@@ -331,7 +343,7 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
     MlpParams p;
     p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma;
     p.eps = c.eps; p.M = c.M; p.hidden = c.hidden;
-    p.stagger = tune_get("mlp_stagger", 1);
+    p.stagger = tune_get("mlp_stagger", 2);
     p.ablate = tune_get("mlp_ablate", 0);
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
@@ -344,6 +356,13 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
         // auto: 32 rows per wave (half the weight traffic per row) once 128-row workgroups fill the chip with two per CU, else 16 rows per
         // wave with the input rows kept in registers (M = 54272: 96-107 vs 117-134 us; M = 18020: 72-74 vs 58-59 us, r01 sweep r27)
         if (variant < 0) variant = (c.M + 127) / 128 >= 400 ? 3 : 0;
+        // ring depth: 4 chunks (one workgroup per CU) while the launch has at most ~1.25 workgroups per CU, else the 2-deep ring (two per CU)
+        const int grid64 = (c.M + 63) / 64;
+        const bool deep = grid64 <= tune_get("mlp_ring4_max_grid", 320) && variant <= 0;
+        if (deep) {
+            hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, true, 4>), dim3(grid64), dim3(256), 0, stream, p);
+            return check_launch("mlp_fused_kernel");
+        }
         switch (variant) {
             case 2: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 8, 2, true>), dim3((c.M + 127) / 128), dim3(512), 0, stream, p); break;
             case 3: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2, false>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;

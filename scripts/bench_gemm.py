@@ -21,6 +21,9 @@ VARIANTS = [("64-row", dict(gemm_bm64_max_grid=400, gemm_stagger=0)),
             ("64-row stagger", dict(gemm_bm64_max_grid=400, gemm_stagger=1)),
             ("128-row", dict(gemm_bm64_max_grid=0, gemm_stagger=0)),
             ("128-row stagger", dict(gemm_bm64_max_grid=0, gemm_stagger=1))]
+if len(sys.argv) > 1 and sys.argv[1] == "ring":   # ring depth comes from FVIT_TUNE_gemm_ring in the environment
+    VARIANTS = [("64-row", dict(gemm_bm64_max_grid=400, gemm_stagger=0))]
+    SHAPES = [x for x in SHAPES if "shard" in x[0]]
 if len(sys.argv) > 1 and sys.argv[1] == "old":   # r01 sweep: waves per workgroup x tile height
     VARIANTS = [("8 waves, 64-row", dict(gemm_nw8_max_grid=400, gemm_bm64_max_grid=400)),
                 ("8 waves, 128-row", dict(gemm_nw8_max_grid=400, gemm_bm64_max_grid=0)),

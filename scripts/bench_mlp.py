@@ -48,7 +48,7 @@ def run(name, n=20):
     else:
         _lib.tune("mlp_variant", int(name[1:2]))
         _lib.tune("mlp_ablate", int(name.split("a")[1]) if "a" in name else 0)
-        _lib.tune("mlp_stagger", 0 if name.endswith("s0") else (2 if name.endswith("s2") else 1))
+        _lib.tune("mlp_stagger", 0 if name.endswith("s0") else (1 if name.endswith("s1") else 2))
         fn = fused
     for _ in range(3):
         fn()

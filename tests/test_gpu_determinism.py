@@ -61,9 +61,16 @@ def test_deploy_forward_is_bitwise_repeatable_across_graph_replays():
     assert (y1.float() - a.float()).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("knobs", [dict(gemm_stagger=1), dict(ab_stagger=1, mlp_stagger=2), dict(mlp_stagger=0)])
+_DEFAULTS = {"gemm_stagger": 0, "ab_stagger": 0, "mlp_stagger": 2, "ab_variant": 0, "gemm_ring": 2, "mlp_ring4_max_grid": 320,
+             "attn_fused_min_rows": 16384, "mlp_fused_min_rows": 16384}
+
+
+@pytest.mark.parametrize("knobs", [dict(gemm_stagger=1), dict(ab_stagger=1, mlp_stagger=1), dict(mlp_stagger=0), dict(ab_variant=2),
+                                   dict(ab_variant=1), dict(gemm_ring=3), dict(gemm_ring=4), dict(mlp_ring4_max_grid=0),
+                                   dict(attn_fused_min_rows=0, mlp_fused_min_rows=0)])
 def test_order_stagger_knobs_keep_the_result(knobs):
-    """K / chunk / head order stagger only permutes fp32 sums: same stage output within summation-order noise, still repeatable."""
+    """Kernel-selection knobs (K / chunk / head order stagger, LDS ring depths, workgroup shapes, fused vs unfused carrier branch) only
+    permute fp32 sums or change who computes what: same stage output within summation-order noise, still bit-repeatable."""
     model = _model("faster_vit_0_224")
     g = torch.Generator(device="cpu").manual_seed(5)
     try:
@@ -76,10 +83,10 @@ def test_order_stagger_knobs_keep_the_result(knobs):
             a = hat_runtime.stage_forward(lvl, x).clone()
             b = hat_runtime.stage_forward(lvl, x).clone()
             for k in knobs:
-                _lib.tune(k, {"gemm_stagger": 0, "ab_stagger": 0, "mlp_stagger": 1}[k])
+                _lib.tune(k, _DEFAULTS[k])
             assert torch.equal(a, b)
             err = (a - ref).abs().max().item()
             assert err < 2e-4 * max(ref.abs().max().item(), 1.0), f"level {li}: {err}"   # fp16 operands re-rounded after a different fp32 sum order
     finally:
-        for k, v in (("gemm_stagger", 0), ("ab_stagger", 0), ("mlp_stagger", 1)):
-            _lib.tune(k, v)
+        for k in knobs:
+            _lib.tune(k, _DEFAULTS[k])
