@@ -356,9 +356,12 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
         // auto: 32 rows per wave (half the weight traffic per row) once 128-row workgroups fill the chip with two per CU, else 16 rows per
         // wave with the input rows kept in registers (M = 54272: 96-107 vs 117-134 us; M = 18020: 72-74 vs 58-59 us, r01 sweep r27)
         if (variant < 0) variant = (c.M + 127) / 128 >= 400 ? 3 : 0;
-        // ring depth: 4 chunks (one workgroup per CU) while the launch has at most ~1.25 workgroups per CU, else the 2-deep ring (two per CU)
+        // ring depth 4 (137 KiB of LDS, ONE workgroup per CU) is an opt-in knob: measured r02 (scripts/bench_mlp.py, same box): no gain
+        // where it fits in one round (M = 1360: 35.7 vs 34.4 us: after the ILP rewrite the chunk loop is no longer DMA-bound, skipping
+        // the weight DMA altogether saves 10 %) and a second round of workgroups above 256 (M = 18020, 282 workgroups: 77.9 vs 52.7 us;
+        // end to end 66.7k vs 71.1k images/s)
         const int grid64 = (c.M + 63) / 64;
-        const bool deep = grid64 <= tune_get("mlp_ring4_max_grid", 320) && variant <= 0;
+        const bool deep = grid64 <= tune_get("mlp_ring4_max_grid", 0) && variant <= 0;
         if (deep) {
             hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, true, 4>), dim3(grid64), dim3(256), 0, stream, p);
             return check_launch("mlp_fused_kernel");
