@@ -41,23 +41,28 @@ def load(path, counter):
     return acc
 
 
-fetch = load(sys.argv[1], "FETCH_SIZE")
-write = load(sys.argv[2], "WRITE_SIZE")
-rows = []
-for key, a in fetch.items():
-    w = write.get(key)
-    if not w or "fvit" not in key[0] and "kernel" not in key[0]:
-        continue
-    fetch_mb = 2.0 * a[1] / a[0] * 1024 / 1e6
-    write_mb = w[1] / w[0] * 1024 / 1e6
-    rows.append({"kernel": key[0], "workgroups": key[1], "launches": a[0], "avg_us_under_pmc": round(a[2] / a[0], 2),
-                 "fetch_size_raw_kb": round(a[1] / a[0], 1), "write_size_raw_kb": round(w[1] / w[0], 1),
-                 "hbm_read_mb": round(fetch_mb, 3), "hbm_write_mb": round(write_mb, 3), "hbm_traffic_mb": round(fetch_mb + write_mb, 3),
-                 "total_us": round(a[2], 1)})
-rows.sort(key=lambda r: -r["total_us"])
-json.dump({"note": "HBM bytes per launch from rocprofv3 PMC passes of `bench.py --no-graph` (eager, default stream shards); "
-                   "read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE; units MB = 1e6 bytes",
-           "kernels": rows}, open(sys.argv[3], "w"), indent=1)
-print(f"{len(rows)} (kernel, grid) rows -> {sys.argv[3]}")
-for r in rows[:12]:
-    print(r["kernel"][:60], r["workgroups"], r["hbm_read_mb"], r["hbm_write_mb"])
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    rows = []
+    for key, a in fetch.items():
+        w = write.get(key)
+        if not w or "fvit" not in key[0] and "kernel" not in key[0]:
+            continue
+        fetch_mb = 2.0 * a[1] / a[0] * 1024 / 1e6
+        write_mb = w[1] / w[0] * 1024 / 1e6
+        rows.append({"kernel": key[0], "workgroups": key[1], "launches": a[0], "avg_us_under_pmc": round(a[2] / a[0], 2),
+                     "fetch_size_raw_kb": round(a[1] / a[0], 1), "write_size_raw_kb": round(w[1] / w[0], 1),
+                     "hbm_read_mb": round(fetch_mb, 3), "hbm_write_mb": round(write_mb, 3), "hbm_traffic_mb": round(fetch_mb + write_mb, 3),
+                     "total_us": round(a[2], 1)})
+    rows.sort(key=lambda r: -r["total_us"])
+    json.dump({"note": "HBM bytes per launch from rocprofv3 PMC passes of `bench.py --no-graph` (eager, default stream shards); "
+                       "read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE; units MB = 1e6 bytes",
+               "kernels": rows}, open(sys.argv[3], "w"), indent=1)
+    print(f"{len(rows)} (kernel, grid) rows -> {sys.argv[3]}")
+    for r in rows[:12]:
+        print(r["kernel"][:60], r["workgroups"], r["hbm_read_mb"], r["hbm_write_mb"])
+
+
+if __name__ == "__main__":
+    main()
