@@ -164,16 +164,25 @@ static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
         if (rc__ != FVIT_OK) return rc__; \
     } while (0)
 
+// LayerNorm folded into the following Linear's A staging (fvit_lngemm.hip): C = 256 / 512 and launches small enough that the separate
+// LayerNorm kernel is a dispatch-floor launch of its own (carrier-token branch, stage 3, shard-sized launches); large launches keep
+// LayerNorm + 128-row GEMM tiles (the prologue would be repeated per column group there)
+static bool use_ln_gemm(const FvitStageDesc& d, int N, int ldw, int ldo, int64_t rows) {
+    return ln_gemm_supported(d.C, N, ldw, ldo) && tune_get("ln_gemm", 1) && rows <= tune_get("ln_gemm_max_rows", 16384);
+}
+
 // LN -> qkv -> attention -> proj + gamma-residual, on `rows` rows of the f32 stream `x`
 static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttnWeights& w, float* x, int64_t rows, void* xn,
-                    void* qkv, void* ao, int nwin, int S, bool ln_done, hipStream_t st) {
+                    void* qkv, void* ao, int nwin, int S, bool ln_done, hipStream_t st, bool qkv_done = false) {
     const int dt = d.operand_dtype;
-    if (!ln_done) {
+    if (!ln_done && !qkv_done) {
         LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
         FVIT_TRY(launch_gather_layernorm(ln, st));
     }
-    GemmCall g1 = {dt, xn, L.ldn, w.w_qkv, L.ldn, w.b_qkv, nullptr, qkv, L.ldqkv, (int)rows, L.ldqkv, L.ldn, 0};
-    FVIT_TRY(launch_gemm(g1, st));
+    if (!qkv_done) {
+        GemmCall g1 = {dt, xn, L.ldn, w.w_qkv, L.ldn, w.b_qkv, nullptr, qkv, L.ldqkv, (int)rows, L.ldqkv, L.ldn, 0};
+        FVIT_TRY(launch_gemm(g1, st));
+    }
     const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
     AttnCall at = {dt, qkv, L.ldqkv, ao, L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale, w.rel_table, w.rel_w, w.rel_ng, d.C / d.heads};
     FVIT_TRY(launch_attention(at, st));
@@ -192,30 +201,55 @@ static bool fused_attn_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int 
 }
 
 // LN -> fc1 + GELU -> fc2 + gamma-residual
+struct NextPe {   // position-embedding rows of the NEXT block, applied in this block's fc2 epilogue (window branch, local-only stages)
+    const float* add = nullptr;
+    const int32_t* add_idx = nullptr;
+    int rows_per_image = 1;
+};
+
+static bool mlp_takes_fused_kernel(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t rows) {
+    const int64_t fused_min = d.C == 256 ? tune_get("mlp_fused_min_rows", 16384) : tune_get("mlp_fused512_min_rows", 1 << 30);
+    return w.w_fc1_frag && w.w_fc2_frag && mlp_fused_supported(d.C, d.hidden) && rows >= fused_min && tune_get("mlp_fused", 1);
+}
+
 static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWeights& w, float* x, int64_t rows, void* xn, void* h,
-                   hipStream_t st) {
+                   hipStream_t st, const NextPe* next_pe = nullptr) {
     const int dt = d.operand_dtype;
     // the fused kernel streams all MLP weights per 128-row workgroup: it wins once the launch fills the chip
     // (>= ~16k rows; 104 vs 137 us at 54k rows) and loses on the latency-bound carrier branch (4k rows: 83 vs 31 us)
     // C = 512 (stage 3): the fused instance is correct but slower than LN + 2 GEMMs at these row counts (65-196 workgroups, each
     // streaming 4 MiB of weights: 65.8k vs 71.0k images/s end to end, r01 sweep r31) => opt-in
-    const int64_t fused_min = d.C == 256 ? tune_get("mlp_fused_min_rows", 16384) : tune_get("mlp_fused512_min_rows", 1 << 30);
-    if (w.w_fc1_frag && w.w_fc2_frag && mlp_fused_supported(d.C, d.hidden) && rows >= fused_min &&
-        tune_get("mlp_fused", 1)) {
+    if (mlp_takes_fused_kernel(d, w, rows)) {
+        if (next_pe && next_pe->add) { set_error("internal: position-embedding pre-add requested on the fused MLP path"); return FVIT_EINVAL; }
         MlpFusedCall mc = {dt, x, (int)rows, d.C, d.hidden, w.ln_w, w.ln_b, 1e-5f, w.w_fc1_frag, w.b_fc1, w.w_fc2_frag, w.b_fc2, w.gamma};
         return launch_mlp_fused(mc, st);
     }
     LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
-    FVIT_TRY(launch_gather_layernorm(ln, st));
-    GemmCall g1 = {dt, xn, L.ldn, w.w_fc1, L.ldn, w.b_fc1, nullptr, h, L.ldh, (int)rows, d.hidden, L.ldn, 1};
-    FVIT_TRY(launch_gemm(g1, st));
+    if (use_ln_gemm(d, d.hidden, L.ldn, L.ldh, rows)) {
+        // norm2 -> fc1 -> GELU in one kernel (AR:697 with AR:401-403): the normalised rows never reach HBM
+        LnGemmCall lg = {ln, w.w_fc1, L.ldn, w.b_fc1, h, L.ldh, d.hidden, 1};
+        FVIT_TRY(launch_ln_gemm(lg, st));
+    } else {
+        FVIT_TRY(launch_gather_layernorm(ln, st));
+        GemmCall g1 = {dt, xn, L.ldn, w.w_fc1, L.ldn, w.b_fc1, nullptr, h, L.ldh, (int)rows, d.hidden, L.ldn, 1};
+        FVIT_TRY(launch_gemm(g1, st));
+    }
     GemmCall g2 = {dt, h, L.ldh, w.w_fc2, L.ldh, w.b_fc2, w.gamma, x, d.C, (int)rows, d.C, L.ldh, 2};
+    if (next_pe && next_pe->add) { g2.add = next_pe->add; g2.add_idx = next_pe->add_idx; g2.rows_per_image = next_pe->rows_per_image; }
     FVIT_TRY(launch_gemm(g2, st));
     return FVIT_OK;
 }
 
+// Local-only stages (no carrier tokens: stage 3 of FasterViT-0) with the LayerNorm-in-GEMM kernels: the in-place `x = x + pos_embed`
+// of block i + 1 (AR:671) is applied by block i's fc2 epilogue, so block i + 1's norm1 is a plain LayerNorm of X and folds into its
+// qkv GEMM.  Same two fp32 additions in the same order as the separate kernel (bitwise the same residual stream).
+static bool pe_preadd_chain(const FvitStageDesc& d, const StageLayout& L, const FvitBlockWeights& w) {
+    return !d.hier && use_ln_gemm(d, L.ldqkv, L.ldn, L.ldqkv, L.Mx) && !fused_attn_ok(d, w.attn, L.S, L.Mx) && !mlp_takes_fused_kernel(d, w.mlp, L.Mx) &&
+           tune_get("pe_preadd", 1);
+}
+
 static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlockWeights& w, const FvitStageTables& t, char* ws,
-                     hipStream_t st) {
+                     hipStream_t st, bool pe_preadded = false, const NextPe* next_pe = nullptr) {
     const int dt = d.operand_dtype;
     float* X = (float*)(ws + L.off_X);
     void* Xn = ws + L.off_Xn;
@@ -240,8 +274,16 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
             // ct_dewindow gather (+ hat_pos_embed) -> R, LN(hat_norm1) -> Rn
             LnCall ln = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), R, Rn, L.ldn,
                          w.hat_attn.ln_w, w.hat_attn.ln_b, 1e-5f, (int)L.Mc, L.G, d.C};
-            FVIT_TRY(launch_gather_layernorm(ln, st));
-            FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st));
+            if (use_ln_gemm(d, L.ldqkv, L.ldn, L.ldqkv, L.Mc)) {
+                // ct_dewindow gather + hat_pos_embed + hat_norm1 + hat_attn.qkv in one kernel (AR:679-683); R (the fp32 carrier stream)
+                // is written by the kernel's first column group
+                LnGemmCall lg = {ln, w.hat_attn.w_qkv, L.ldn, w.hat_attn.b_qkv, RQKV, L.ldqkv, L.ldqkv, 0};
+                FVIT_TRY(launch_ln_gemm(lg, st));
+                FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st, true));
+            } else {
+                FVIT_TRY(launch_gather_layernorm(ln, st));
+                FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st));
+            }
         }
         FVIT_TRY(run_mlp(d, L, w.hat_mlp, R, L.Mc, Rn, RH, st));
     }
@@ -252,6 +294,12 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
                           w.attn.w_qkv_frag, w.attn.b_qkv_heads, w.attn.w_proj_frag, w.attn.b_proj, w.attn.gamma, w.attn.bias, X,
                           d.batch * L.nW, L.S, d.heads, d.C, scale};
         FVIT_TRY(launch_attnblk(ab, st));
+    } else if (pe_preadded) {
+        // X already holds x + pos_embed (added by the previous block's fc2 epilogue): norm1 + qkv in one kernel
+        LnCall ln1 = {dt, X, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w.attn.ln_w, w.attn.ln_b, 1e-5f, (int)L.Mx, 1, d.C};
+        LnGemmCall lg = {ln1, w.attn.w_qkv, L.ldn, w.attn.b_qkv, QKV, L.ldqkv, L.ldqkv, 0};
+        FVIT_TRY(launch_ln_gemm(lg, st));
+        FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st, true));
     } else {
         // cat(ct_window(ct), x + pos_embed) gather -> X, LN(norm1) -> Xn
         LnCall ln1 = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, X, Xn, L.ldn,
@@ -259,7 +307,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         FVIT_TRY(launch_gather_layernorm(ln1, st));
         FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st));
     }
-    FVIT_TRY(run_mlp(d, L, w.mlp, X, L.Mx, Xn, Hb, st));
+    FVIT_TRY(run_mlp(d, L, w.mlp, X, L.Mx, Xn, Hb, st, next_pe));
     return FVIT_OK;
 }
 
@@ -329,7 +377,14 @@ int fvit_hat_stage_forward(const FvitStageDesc* desc, const FvitBlockWeights* bl
     float* X = (float*)(ws + L.off_X);
     PartitionCall pc = {*in, d.batch, d.C, d.Hp, d.Wp, d.ws, X, L.S, L.ncw, d.hier ? ct_init : nullptr, L.ncw};
     FVIT_TRY(launch_partition(pc, st));
-    for (int i = 0; i < d.depth; ++i) FVIT_TRY(run_block(d, L, blocks[i], *tables, ws, st));
+    bool pre = false;   // does X already include block i's position embedding?
+    for (int i = 0; i < d.depth; ++i) {
+        NextPe np;
+        const bool chain = i + 1 < d.depth && pe_preadd_chain(d, L, blocks[i]) && pe_preadd_chain(d, L, blocks[i + 1]) && blocks[i + 1].pe_x;
+        if (chain) { np.add = blocks[i + 1].pe_x; np.add_idx = tables->ln1_add; np.rows_per_image = L.nW * L.S; }
+        FVIT_TRY(run_block(d, L, blocks[i], *tables, ws, st, pre, chain ? &np : nullptr));
+        pre = chain;
+    }
     const bool prop = d.hier && d.do_propagation && d.depth > 0 && blocks[d.depth - 1].last;
     ReverseCall rc = {X, L.S, L.ncw, d.batch, d.C, d.Hp, d.Wp, d.H, d.W, d.ws, *out,
                       prop ? blocks[d.depth - 1].hat_attn.gamma : nullptr, prop ? tables->up_idx : nullptr};
@@ -424,6 +479,17 @@ int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rows
     LnCall c = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, x_out, n_out, ldn, ln_w, ln_b, eps, rows,
                 rows_per_image, C};
     return launch_gather_layernorm(c, (hipStream_t)stream);
+}
+
+int fvit_ln_gemm_supported(int32_t C, int32_t N, int32_t ldw, int32_t ldo) { return ln_gemm_supported(C, N, ldw, ldo) ? 1 : 0; }
+
+int fvit_ln_gemm(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                 const int32_t* add_idx, const float* add, float* x_out, const float* ln_w, const float* ln_b, float eps, int32_t rows,
+                 int32_t rows_per_image, int32_t C, const void* Wt, int32_t ldw, const float* bias, void* out, int32_t ldo, int32_t N,
+                 int32_t act, fvit_stream_t stream) {
+    LnCall ln = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, x_out, nullptr, 0, ln_w, ln_b, eps, rows, rows_per_image, C};
+    LnGemmCall c = {ln, Wt, ldw, bias, out, ldo, N, act ? 1 : 0};
+    return launch_ln_gemm(c, (hipStream_t)stream);
 }
 
 int fvit_attn_block_supported(int32_t C, int32_t heads, int32_t S) { return attnblk_supported(C, heads, S) ? 1 : 0; }

@@ -112,6 +112,12 @@ struct GemmCall {
     int ldo;
     int M, N, K;
     int epilogue;        // 0 bias, 1 bias+gelu, 2 gamma-residual into f32
+    // residual epilogue only (optional): after the residual update, x[m][:] += add[add_idx ? add_idx[m % rows_per_image] : m % rows_per_image]
+    // (rows of length N; negative index = none).  Used to apply the NEXT block's position embedding (AR:671: x = pos_embed(x)) in
+    // the fc2 epilogue of the current block, so that the next block's norm1 has no in-place add and folds into its qkv GEMM.
+    const float* add = nullptr;
+    const int32_t* add_idx = nullptr;
+    int rows_per_image = 1;
 };
 int launch_gemm(const GemmCall& c, hipStream_t stream);
 
@@ -195,6 +201,20 @@ struct LnCall {
     int rows, rows_per_image, C;
 };
 int launch_gather_layernorm(const LnCall& c, hipStream_t stream);
+
+// LayerNorm folded into the A-operand staging of the Linear layer that consumes it (fvit_lngemm.hip); ln.n_out / ln.ldn are unused
+struct LnGemmCall {
+    LnCall ln;           // row selection + LayerNorm parameters (x_out optional, must not alias the sources)
+    const void* W;       // weights op16 [pad128(N)][ldw]
+    int ldw;
+    const float* bias;   // [N] or null
+    void* out;           // op16 [..][ldo]
+    int ldo;
+    int N;
+    int epilogue;        // 0 bias, 1 bias + GELU
+};
+bool ln_gemm_supported(int C, int N, int ldw, int ldo);
+int launch_ln_gemm(const LnGemmCall& c, hipStream_t stream);
 
 struct PartitionCall {
     FvitMapView in;  // (B, C, Hp, Wp)

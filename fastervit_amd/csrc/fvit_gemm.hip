@@ -39,6 +39,9 @@ struct GemmParams {
     int M, N, K;
     int tiles_m, tiles_n;
     int stagger;  // 1: workgroup (tm, tn) walks the K tiles starting at a tile-dependent offset (see gemm_kernel)
+    const float* add;        // residual epilogue: optional row table added after the update (see GemmCall)
+    const int32_t* add_idx;
+    int rpi;
 };
 
 // swizzle of the 16-byte chunk index inside a 128-byte LDS row.
@@ -211,12 +214,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             const int m = m0 + wm * (16 * MI) + mi * 16 + s;
             if (m < p.M) {
                 float* px = X + (size_t)m * p.ldo + nb;
+                const float* pa = nullptr;
+                if (p.add) {
+                    const int pr = m % p.rpi;
+                    const int ai = p.add_idx ? p.add_idx[pr] : pr;
+                    if (ai >= 0) pa = p.add + (size_t)ai * p.N + nb;
+                }
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     f4 x = *(f4*)(px + ni * 4);
                     f4 a = acc[ni][mi];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[r] += gam[ni * 4 + r] * (a[r] + bias[ni * 4 + r]);
+                    if (pa) x += *(const f4*)(pa + ni * 4);
                     *(f4*)(px + ni * 4) = x;
                 }
             }
@@ -254,6 +264,9 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.M = c.M; p.N = c.N; p.K = c.K;
     p.tiles_n = (c.N + BN - 1) / BN;
     p.stagger = tune_get("gemm_stagger", 0);
+    p.add = c.epilogue == 2 ? c.add : nullptr;
+    p.add_idx = c.add_idx;
+    p.rpi = c.rows_per_image > 0 ? c.rows_per_image : 1;
     const int grid128 = ((c.M + 127) / 128) * p.tiles_n;
     // tile / workgroup shape by grid size (fvit_tune knobs for A/B):
     //   grid128 <= bm64_max : 64-row tiles (twice the workgroups; +2 % images/s on shard-sized launches), else 128-row tiles

@@ -201,8 +201,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
             // LDS round trip per GEMM instead of eight), GEMM1 runs KSPLIT independent accumulator chains per (unit block, row
             // block), and GEMM2's fragments are in flight while the VALU does bias + GELU.
             constexpr int FB = RB == 1 ? 16 : 4;         // fragments requested per batch (64 / 16 VGPRs; RB = 2 already holds 128 accumulators)
-            constexpr bool W2_EARLY = RB == 1;           // GEMM2's first batch requested BEFORE the GELU block
-            constexpr int KSPLIT = RB == 1 ? 2 : 1;      // independent accumulator chains per output block in GEMM1
+                constexpr int KSPLIT = RB == 1 ? 2 : 1;      // independent accumulator chains per output block in GEMM1
             constexpr int KH = KK / KSPLIT;
             // ---- GEMM1: H^T[unit][row], 2 unit blocks x RB row blocks; unit = hb*16 + 4g + r ----
             f4 acc1[2][RB][KSPLIT];
@@ -363,7 +362,7 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
         const int grid64 = (c.M + 63) / 64;
         const bool deep = grid64 <= tune_get("mlp_ring4_max_grid", 0) && variant <= 0;
         if (deep) {
-            hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, true, 4>), dim3(grid64), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 1, true, 4>), dim3(grid64), dim3(256), 0, stream, p);   // 137 KiB of LDS: one workgroup per CU
             return check_launch("mlp_fused_kernel");
         }
         switch (variant) {

@@ -236,6 +236,16 @@ int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rows
                           const float* ln_b, float eps, int32_t rows, int32_t rows_per_image, int32_t C,
                           fvit_stream_t stream);
 
+/* LayerNorm folded into the Linear layer that consumes it: out[i][n] = act( LN(v[i]) . Wt[n][:] + bias[n] ) with v[i], the optional f32
+ * copy x_out[i] = v[i] and the LayerNorm exactly as in fvit_gather_layernorm (AR:616, 648-649 + AR:560 / 402-403); the normalised rows
+ * never reach HBM.  C (= K) must be 256 or 512, N a multiple of 16, Wt op16 [pad128(N)][ldw] (fvit_ln_gemm_supported); x_out must not
+ * alias srcA / srcB (several column groups read every source row).  act 0: bias, 1: bias + exact-erf GELU.  out op16, ld ldo. */
+int fvit_ln_gemm_supported(int32_t C, int32_t N, int32_t ldw, int32_t ldo);
+int fvit_ln_gemm(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                 const int32_t* add_idx, const float* add, float* x_out, const float* ln_w, const float* ln_b, float eps, int32_t rows,
+                 int32_t rows_per_image, int32_t C, const void* Wt, int32_t ldw, const float* bias, void* out, int32_t ldo, int32_t N,
+                 int32_t act, fvit_stream_t stream);
+
 /* Fused attention sub-block: x_out[i] = x_in[i] + gamma * proj(softmax(q k^T * scale + bias) v), [q|k|v] = qkv(LayerNorm(x_in)),
  * x_in[i] = gathered source row + optional add row (exactly the row selection of fvit_gather_layernorm), per window of S rows
  * (AR:671-696).  One kernel; needs C == 256, heads == 8 (head_dim 32), S <= 16 or 48 < S <= 64 (fvit_attn_block_supported).
@@ -320,7 +330,7 @@ int fvit_sgd_momentum(float* param, float* momentum, const float* grad, int64_t 
 /* Performance-experiment knobs for A/B runs inside one process; the same keys can be preset through the environment as
  * FVIT_TUNE_<key>=<int> (read once per key).  Kernel-selection knobs never change results beyond fp32 summation order:
  *   "mlp_fused", "attn_fused" 0/1; "mlp_fused_min_rows", "attn_fused_min_rows", "mlp_fused512_min_rows", "attn_fused512_min_rows";
- *   "mlp_variant" (-1 auto), "ab_variant", "gemm_stagger", "ab_stagger", "mlp_stagger" (0 / 1 / 2), "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
+ *   "mlp_variant" (-1 auto), "ab_variant", "ln_gemm" 0/1, "ln_gemm_max_rows", "lngemm_nt", "gemm_ring", "mlp_ring4_max_grid", "gemm_stagger", "ab_stagger", "mlp_stagger" (0 / 1 / 2), "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
  *   "conv_halo_grid", "conv64_variant", "conv128_narrow", "stem_fused_grid".
  * The "*_ablate" keys ("mlp_ablate", "ab_ablate", "conv_ablate", "conv_halo_ablate") switch off parts of a kernel for timing and
  * DO produce wrong results.  Guarded by a mutex; launches read the values at launch time. */

@@ -572,3 +572,70 @@ def test_attn_block_fused(opname, dt, code, S, nwin, use_tables, use_gamma, C):
     assert torch.isfinite(out).all()
     tol = (4e-3 if dt == torch.float16 else 3e-2) * ref.abs().max().item()
     assert (out - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("M,C,N,act,gather", [(1360, 256, 768, 0, True), (1360, 256, 1024, 1, False), (4165, 512, 2048, 1, False),
+                                               (4165, 512, 1536, 0, False), (77, 256, 48, 0, True), (300, 512, 272, 1, True)])
+def test_ln_gemm(opname, dt, code, M, C, N, act, gather):
+    """fvit_ln_gemm (LayerNorm in the GEMM's A staging) vs fp32 torch: F.layer_norm(gathered rows + add rows) @ W^T + bias (+ GELU),
+    plus the fp32 copy of the gathered rows; rows beyond M / columns beyond N untouched."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M + C + N)
+    rows_per_image = next(d for d in (17, 10, 7, 5, 1) if M % d == 0) if gather else 1
+    B = M // rows_per_image
+    if gather:
+        rowsA, rowsB = 23, 9
+        srcA = torch.randn(B * rowsA, C, generator=g) * 2 + 0.5
+        srcB = torch.randn(B * rowsB, C, generator=g)
+        src_idx = torch.randint(-rowsB, rowsA, (rows_per_image,), generator=g).to(torch.int32)
+        add = torch.randn(11, C, generator=g)
+        add_idx = torch.randint(-1, 11, (rows_per_image,), generator=g).to(torch.int32)
+        rows = []
+        for b in range(B):
+            for pr in range(rows_per_image):
+                si = int(src_idx[pr])
+                v = srcA[b * rowsA + si] if si >= 0 else srcB[b * rowsB + (-si - 1)]
+                if int(add_idx[pr]) >= 0:
+                    v = v + add[int(add_idx[pr])]
+                rows.append(v)
+        v = torch.stack(rows)
+    else:
+        rowsA = rowsB = 0
+        srcA = torch.randn(M, C, generator=g) * 2 + 0.5
+        srcB = src_idx = add = add_idx = None
+        v = srcA
+    ln_w, ln_b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    W = (torch.randn(N, C, generator=g) / C ** 0.5).to(dt)
+    bias = torch.randn(N, generator=g)
+    Wp = _padded(W, _rup(N, 128), C).cuda()
+    ldo = _rup(N, 64)
+    out = torch.full((_rup(M, 128), ldo), float("nan"), dtype=dt, device="cuda")
+    x_out = torch.full((M, C), float("nan"), device="cuda") if gather else None
+    dev = lambda t: None if t is None else t.cuda()
+    sA, sB, si_d, ai_d, ad = dev(srcA), dev(srcB), dev(src_idx), dev(add_idx), dev(add)
+    lw, lb, bd = ln_w.cuda(), ln_b.cuda(), bias.cuda()
+    ptr = lambda t: None if t is None else t.data_ptr()
+    assert lib.fvit_ln_gemm_supported(C, N, C, ldo)
+    rc = lib.fvit_ln_gemm(code, ptr(sA), rowsA, ptr(sB), rowsB, ptr(si_d), ptr(ai_d), ptr(ad), ptr(x_out), lw.data_ptr(), lb.data_ptr(),
+                          ctypes.c_float(1e-5), M, rows_per_image, C, Wp.data_ptr(), C, bd.data_ptr(), out.data_ptr(), ldo, N, act, _stream())
+    _lib.check(rc, "ln_gemm")
+    torch.cuda.synchronize()
+    xn = F.layer_norm(v, (C,), ln_w, ln_b, 1e-5).to(dt).float()       # the kernel rounds the normalised rows to the operand type
+    ref = xn @ W.float().t() + bias
+    if act:
+        ref = F.gelu(ref)
+    got = out[:M, :N].float().cpu()
+    tol = (4e-3 if dt == torch.float16 else 2e-2) * max(ref.abs().max().item(), 1.0)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < tol
+    assert torch.isnan(out[M:].float()).all() and torch.isnan(out[:M, N:].float()).all()
+    if gather:
+        assert torch.equal(x_out.cpu(), v)
+    # bit-repeatable
+    out2 = torch.full_like(out, float("nan"))
+    rc = lib.fvit_ln_gemm(code, ptr(sA), rowsA, ptr(sB), rowsB, ptr(si_d), ptr(ai_d), ptr(ad), ptr(x_out), lw.data_ptr(), lb.data_ptr(),
+                          ctypes.c_float(1e-5), M, rows_per_image, C, Wp.data_ptr(), C, bd.data_ptr(), out2.data_ptr(), ldo, N, act, _stream())
+    _lib.check(rc, "ln_gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(out[:M, :N], out2[:M, :N])

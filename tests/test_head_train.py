@@ -136,11 +136,14 @@ def test_head_trainer_on_the_hip_backbone():
     x = case_input("tiny_hier").cuda()
     x = torch.cat([x, x.flip(-1), x.flip(-2), x * 0.5])
     tgt = torch.tensor([1, 3, 5, 7, 9, 11, 13, 15], device="cuda")
-    tr = head_train.HeadTrainer(model, lr=0.5, momentum=0.9, weight_decay=1e-4, smoothing=0.1)
+    with torch.no_grad():
+        fmax = torch.flatten(model.avgpool(model.forward_features(x)), 1).float().abs().max().item()
+    LR = 0.02 / max(fmax * fmax, 1.0)      # the 'stress' fixture's pooled features are O(10): keep the step stable
+    tr = head_train.HeadTrainer(model, lr=LR, momentum=0.9, weight_decay=1e-4, smoothing=0.1)
     feat = tr.features(x)
     W = tr.param[:tr.N * tr.F].view(tr.N, tr.F).detach().cpu().clone().requires_grad_(True)
     b = tr.param[tr.N * tr.F:].detach().cpu().clone().requires_grad_(True)
-    opt = torch.optim.SGD([W, b], lr=0.5, momentum=0.9, weight_decay=1e-4)
+    opt = torch.optim.SGD([W, b], lr=LR, momentum=0.9, weight_decay=1e-4)
     losses = []
     for _ in range(3):
         losses.append(float(tr.step(x, tgt)))
