@@ -165,10 +165,12 @@ static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
     } while (0)
 
 // LayerNorm folded into the following Linear's A staging (fvit_lngemm.hip): C = 256 / 512 and launches small enough that the separate
-// LayerNorm kernel is a dispatch-floor launch of its own (carrier-token branch, stage 3, shard-sized launches); large launches keep
-// LayerNorm + 128-row GEMM tiles (the prologue would be repeated per column group there)
+// LayerNorm kernel is a dispatch-floor launch of its own (carrier-token branch, stage 3, shard-sized launches).  OPT-IN (fvit_tune
+// "ln_gemm" = 1): measured r02 it removes 17-22 launches per stream shard but LOSES end to end (60.9k vs 74.3k images/s): its
+// resident operand panel needs 96-128 KiB of LDS per workgroup, so no other stream shard's kernel can share the CU with it -- and
+// that co-residency is what the stream shards' gain comes from (profiles/r02_ln_gemm_ab.log)
 static bool use_ln_gemm(const FvitStageDesc& d, int N, int ldw, int ldo, int64_t rows) {
-    return ln_gemm_supported(d.C, N, ldw, ldo) && tune_get("ln_gemm", 1) && rows <= tune_get("ln_gemm_max_rows", 16384);
+    return ln_gemm_supported(d.C, N, ldw, ldo) && tune_get("ln_gemm", 0) && rows <= tune_get("ln_gemm_max_rows", 16384);
 }
 
 // LN -> qkv -> attention -> proj + gamma-residual, on `rows` rows of the f32 stream `x`

@@ -12,8 +12,10 @@
 //     rows in registers (fp32, two-pass mean / variance, the arithmetic of ln_kernel) and writes them ONCE, as 16-bit MFMA operands,
 //     into an LDS panel [KC][64 rows][64 k] that stays resident for the whole workgroup -- in the swizzled layout gemm_kernel's
 //     fragment reads expect, so the main loop is gemm_kernel's with the activation tile already in place.
-//   * main loop over the NT * KC weight tiles (16 KiB each, 16-byte global_load_lds, 2-deep ring, one barrier per tile): only the
-//     WEIGHTS stream; the activation operand costs one fp32 row read per workgroup instead of one 16-bit tile read per K step.
+//   * main loop over the NT * KC weight tiles (16 KiB each, 16-byte global_load_lds, 4-deep ring behind a COUNTED s_waitcnt vmcnt + raw
+//     s_barrier: three tiles in flight; a 2-deep ring made every tile one exposed LDS-DMA round trip, 2-2.5 us per tile on the
+//     264-workgroup stage-3 launches, r02): only the WEIGHTS stream; the activation operand costs one fp32 row read per workgroup
+//     instead of one 16-bit tile read per K step.
 //   * epilogue per 128-column tile: bias (+ exact-erf GELU), packed 16-bit stores (gemm_kernel's swapped-operand layout).
 //   * the optional fp32 copy of the gathered rows (x_out: the carrier-token stream R) is written by the workgroups of column
 //     group 0 only; x_out must not alias the gather sources (the in-place `x += pos_embed` of the window branch keeps the
@@ -70,13 +72,14 @@ __device__ __forceinline__ void stage_w(const T* __restrict__ g, int ld, int row
 }
 
 template <typename T, int EPI, int KC>
-__global__ __launch_bounds__(256, KC == 4 ? 2 : 1) void lngemm_kernel(LnGemmParams p) {
+__global__ __launch_bounds__(256, 1) void lngemm_kernel(LnGemmParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int K = KC * 64;
     constexpr int LPR = K / 8;        // lanes per row: a lane owns 8 consecutive channels = one 16-byte operand chunk
     constexpr int RPS = 64 / LPR;     // rows a wave normalises per step (1 at K = 512, 2 at K = 256)
     constexpr int STEPS = 16 / RPS;   // 16 rows per wave
-    __shared__ __attribute__((aligned(16))) char smem[KC * A_CHUNK_BYTES + 2 * W_TILE_BYTES];
+    constexpr int NS = 4;             // weight ring depth
+    __shared__ __attribute__((aligned(16))) char smem[KC * A_CHUNK_BYTES + NS * W_TILE_BYTES];
     char* const apanel = smem;
     char* const wring = smem + KC * A_CHUNK_BYTES;
 
@@ -96,7 +99,13 @@ __global__ __launch_bounds__(256, KC == 4 ? 2 : 1) void lngemm_kernel(LnGemmPara
     const int total = ntiles * KC;   // weight tiles this workgroup streams
 
     const T* __restrict__ W = (const T*)p.W;
-    if (total > 0) stage_w<T>(W, p.ldw, tn0 * BN, 0, wring, wave, lane);
+    auto stage_tile_t = [&](int t) {   // weight tile t of this workgroup's sequence -> ring slot t % NS
+        const int n1 = t / KC, k1 = t - n1 * KC;
+        stage_w<T>(W, p.ldw, (tn0 + n1) * BN, k1 * BK, wring + (t % NS) * W_TILE_BYTES, wave, lane);
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < total) stage_tile_t(t);
 
     // ---- prologue: gather + add + LayerNorm of 16 rows per wave, straight into the LDS operand panel ----
     {
@@ -164,16 +173,16 @@ __global__ __launch_bounds__(256, KC == 4 ? 2 : 1) void lngemm_kernel(LnGemmPara
         for (int j = 0; j < 2; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < total; ++t) {
-        // weight tile t landed (and, at t = 0, the operand panel is complete); every wave is past tile t - 1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // weight tile t landed once at most the 4 LDS-DMA instructions per wave of each later tile are outstanding (and, at t = 0, the
+        // operand panel is complete: lgkmcnt(0)); every wave is past tile t - 1.  Raw barrier: __syncthreads() would drain the queue.
+        const int ahead = min(NS - 2, total - 1 - t);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int nti = t / KC, kt = t - nti * KC;
-        if (t + 1 < total) {
-            const int n1 = (t + 1) / KC, k1 = (t + 1) - n1 * KC;
-            stage_w<T>(W, p.ldw, (tn0 + n1) * BN, k1 * BK, wring + ((t + 1) & 1) * W_TILE_BYTES, wave, lane);
-        }
+        if (t + NS - 1 < total) stage_tile_t(t + NS - 1);   // refills the slot tile t - 1 was read from
         const char* xt = apanel + kt * A_CHUNK_BYTES;
-        const char* wt = wring + (t & 1) * W_TILE_BYTES;
+        const char* wt = wring + (t % NS) * W_TILE_BYTES;
         v8 xf[2][2], wf[2][4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -242,7 +251,7 @@ int launch_t(const LnGemmCall& c, hipStream_t stream) {
     const int K = c.ln.C;
     // column tiles per workgroup: as few as keep the launch within one round of workgroups (K = 512: one 96-KiB workgroup per CU;
     // K = 256: two 64-KiB workgroups per CU), so that the LayerNorm prologue is repeated for as few column groups as possible
-    const int cap = (K == 512 ? 256 : 512) + tune_get("lngemm_extra_wgs", 32);
+    const int cap = 256 + tune_get("lngemm_extra_wgs", 32);   // 96 / 128 KiB of LDS: one workgroup per CU
     int nt = tune_get("lngemm_nt", 0);
     if (nt <= 0) {
         nt = 1;

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
         }
         // refill the slot chunk it - 1 was read from (every wave is past it: it arrived at this barrier)
         if (it + NBUF - 1 < nchunk && !(p.ablate & 2)) stage(chunk_of(it + NBUF - 1), smem + ((it + NBUF - 1) % NBUF) * BUF_BYTES);
+        if (p.ablate & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // debug: synchronous weight DMA
         if constexpr (RB == 1) {
             // The chunk body is written for a wave that is ALONE on its SIMD (small grids: the carrier-token branch, stage 3, the
             // shard-sized launches of the stream-sharded plan): left to the compiler the loop was "2 ds_read, s_waitcnt lgkmcnt(0),
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
                 for (int rb = 0; rb < RB; ++rb) acc2[cb][rb] = Op16<T>::mfma(wf, pf[rb], acc2[cb][rb]);
             }
         }
+        if (p.ablate & 16) __syncthreads();   // debug: extra barrier at the end of the chunk body
     }
 
     // ---- epilogue: x[row][c] += gamma[c] * (acc2 + b2[c]) ----
@@ -342,7 +344,11 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
     MlpParams p;
     p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma;
     p.eps = c.eps; p.M = c.M; p.hidden = c.hidden;
-    p.stagger = tune_get("mlp_stagger", 2);
+    // chunk-order stagger is OFF by default: with it, concurrent stream shards are not bit-repeatable run to run (r02 race hunt:
+    // eager or hipGraph, 3 stream shards of batch 256: logits of the side-stream shards differ in the last fp16 bit between
+    // identical calls with stagger 1 / 2, never with 0; the kernel alone on 3 concurrent streams IS repeatable either way --
+    // profiles/r02_repeatability_hunt.log), and it buys no throughput (the chunk loop is not DMA-bound, r02_ring_depth_ab.log)
+    p.stagger = tune_get("mlp_stagger", 0);
     p.ablate = tune_get("mlp_ablate", 0);
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;

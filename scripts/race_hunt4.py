@@ -1,0 +1,38 @@
+"""Which kernel makes concurrent stream shards non-repeatable?  5 eager 3-stream forwards per knob setting; count consecutive pairs
+of calls whose logits differ (and in which shards)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fastervit_amd  # noqa: E402
+from fastervit_amd import _lib  # noqa: E402
+from fastervit_amd.conv_runtime import DeployPlan  # noqa: E402
+
+torch.manual_seed(0)
+model = fastervit_amd.create_model("faster_vit_0_224").eval().cuda().to(memory_format=torch.channels_last)
+x = torch.randn(256, 3, 224, 224, generator=torch.Generator().manual_seed(1000)).cuda().contiguous(memory_format=torch.channels_last)
+DEF = {"mlp_fused": 1, "attn_fused": 1, "ln_gemm": 0, "mlp_stagger": 0, "pe_preadd": 1, "mlp_variant": -1, "ab_variant": 0, "mlp_ablate": 0,
+       "ab_stagger": 0, "gemm_stagger": 0}
+SETS = [{}, {"mlp_stagger": 1}, {"mlp_stagger": 2}, {"mlp_stagger": 0}, {"mlp_stagger": 0, "ln_gemm": 1}, {"mlp_stagger": 2, "mlp_ablate": 16},
+        {"mlp_stagger": 2, "mlp_ablate": 32}, {"mlp_stagger": 2, "mlp_variant": 4}, {"mlp_stagger": 0, "ab_stagger": 1}, {"mlp_stagger": 0, "gemm_stagger": 1}]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+for knobs in SETS:
+    for k, v in DEF.items():
+        _lib.tune(k, knobs.get(k, v))
+    plan = DeployPlan(model, torch.float16)
+    plan.streams = 3
+    outs = []
+    with torch.no_grad():
+        for _ in range(n):
+            outs.append(plan.forward(x).clone())
+            torch.cuda.synchronize()
+    bad = 0
+    shards = set()
+    for a, b in zip(outs[1:-1], outs[2:]):     # skip the first (serial) call
+        if not torch.equal(a, b):
+            bad += 1
+            rows = ((a.float() - b.float()).abs().max(dim=1).values > 0).nonzero().flatten().tolist()
+            shards |= {0 if r < 86 else (1 if r < 172 else 2) for r in rows}
+    print(f"{knobs or 'defaults'}: {bad} of {n - 2} consecutive pairs differ; shards {sorted(shards)}", flush=True)
