@@ -27,8 +27,12 @@ EXPORTED_SYMBOLS = (
     "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_window_attention", "fvit_window_attention_long",
     "fvit_gather_layernorm", "fvit_ln_gemm_supported", "fvit_ln_gemm", "fvit_attn_block_supported", "fvit_attn_block_fused", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl", "fvit_conv3x3_nhwc", "fvit_stem_conv3x3s2", "fvit_stem_fused",
     "fvit_head_logits", "fvit_head_softmax_xent", "fvit_head_grad", "fvit_sgd_momentum",
-    "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_records", "fvit_prof_kind_name",
+    "fvit_debug_lds_poison", "fvit_debug_regs_poison", "fvit_debug_poison_launches", "fvit_debug_rowhash_begin", "fvit_debug_rowhash_end", "fvit_debug_rowhash_dump", "fvit_debug_mlp_trace_begin", "fvit_debug_mlp_trace_end", "fvit_debug_mlp_inputs_begin", "fvit_debug_mlp_inputs_end", "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_records", "fvit_prof_kind_name",
 )
+
+
+class FvitDebugRowhashRecord(C.Structure):
+    _fields_ = [("tag", C.c_char * 24), ("offset", C.c_int64), ("rows", C.c_int64)]
 
 
 class FvitStageDesc(C.Structure):
@@ -153,6 +157,26 @@ def _declare(lib):
     lib.fvit_head_grad.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, vp]
     lib.fvit_sgd_momentum.restype = C.c_int
     lib.fvit_sgd_momentum.argtypes = [vp, vp, vp, C.c_int64, f32, f32, f32, vp]
+    lib.fvit_debug_lds_poison.restype = C.c_int
+    lib.fvit_debug_lds_poison.argtypes = [vp, i32, i32, vp]
+    lib.fvit_debug_poison_launches.restype = C.c_int
+    lib.fvit_debug_poison_launches.argtypes = [vp, C.c_uint32]
+    lib.fvit_debug_regs_poison.restype = C.c_int
+    lib.fvit_debug_regs_poison.argtypes = [vp, i32, i32, C.c_uint32, vp]
+    lib.fvit_debug_rowhash_begin.restype = C.c_int
+    lib.fvit_debug_rowhash_begin.argtypes = [vp, C.c_int64]
+    lib.fvit_debug_rowhash_end.restype = C.c_int
+    lib.fvit_debug_rowhash_end.argtypes = [C.POINTER(FvitDebugRowhashRecord), i32]
+    lib.fvit_debug_rowhash_dump.restype = C.c_int
+    lib.fvit_debug_rowhash_dump.argtypes = [i32, vp, C.c_int64]
+    lib.fvit_debug_mlp_trace_begin.restype = C.c_int
+    lib.fvit_debug_mlp_trace_begin.argtypes = [vp, C.c_int64]
+    lib.fvit_debug_mlp_trace_end.restype = C.c_int
+    lib.fvit_debug_mlp_trace_end.argtypes = [C.POINTER(C.c_int64), C.POINTER(i32), i32]
+    lib.fvit_debug_mlp_inputs_begin.restype = C.c_int
+    lib.fvit_debug_mlp_inputs_begin.argtypes = [vp, C.c_int64]
+    lib.fvit_debug_mlp_inputs_end.restype = C.c_int
+    lib.fvit_debug_mlp_inputs_end.argtypes = [C.POINTER(C.c_int64), C.POINTER(i32), i32]
     lib.fvit_tune.restype = C.c_int
     lib.fvit_tune.argtypes = [C.c_char_p, i32]
     lib.fvit_prof_enable.restype = C.c_int

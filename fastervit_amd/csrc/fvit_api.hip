@@ -78,6 +78,7 @@ static std::vector<hipEvent_t> g_events;  // 2 per record
 static std::vector<ProfRec> g_recs;
 
 ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t stream) : slot_(-1), stream_(stream) {
+    dbg_poison_before_launch(stream);   // no-op unless fvit_debug_poison_launches(sink != null) is active
     if (!g_prof_on) return;
     slot_ = (int)g_recs.size();
     while ((int)g_events.size() < 2 * (slot_ + 1)) {
@@ -181,15 +182,19 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
         LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
         FVIT_TRY(launch_gather_layernorm(ln, st));
     }
+    dbg_rowhash("attn.xn", xn, rows, L.ldn * 2, st);
     if (!qkv_done) {
         GemmCall g1 = {dt, xn, L.ldn, w.w_qkv, L.ldn, w.b_qkv, nullptr, qkv, L.ldqkv, (int)rows, L.ldqkv, L.ldn, 0};
         FVIT_TRY(launch_gemm(g1, st));
     }
+    dbg_rowhash("attn.qkv", qkv, rows, L.ldqkv * 2, st);
     const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
     AttnCall at = {dt, qkv, L.ldqkv, ao, L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale, w.rel_table, w.rel_w, w.rel_ng, d.C / d.heads};
     FVIT_TRY(launch_attention(at, st));
+    dbg_rowhash("attn.ao", ao, rows, L.ldao * 2, st);
     GemmCall g2 = {dt, ao, L.ldao, w.w_proj, L.ldao, w.b_proj, w.gamma, x, d.C, (int)rows, d.C, L.ldao, 2};
     FVIT_TRY(launch_gemm(g2, st));
+    dbg_rowhash("attn.out", x, rows, d.C * 4, st);
     return FVIT_OK;
 }
 
@@ -224,7 +229,10 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
     if (mlp_takes_fused_kernel(d, w, rows)) {
         if (next_pe && next_pe->add) { set_error("internal: position-embedding pre-add requested on the fused MLP path"); return FVIT_EINVAL; }
         MlpFusedCall mc = {dt, x, (int)rows, d.C, d.hidden, w.ln_w, w.ln_b, 1e-5f, w.w_fc1_frag, w.b_fc1, w.w_fc2_frag, w.b_fc2, w.gamma};
-        return launch_mlp_fused(mc, st);
+        dbg_rowhash("mlpf.in", x, rows, d.C * 4, st);
+        FVIT_TRY(launch_mlp_fused(mc, st));
+        dbg_rowhash("mlpf.out", x, rows, d.C * 4, st);
+        return FVIT_OK;
     }
     LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
     if (use_ln_gemm(d, d.hidden, L.ldn, L.ldh, rows)) {
@@ -236,9 +244,11 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
         GemmCall g1 = {dt, xn, L.ldn, w.w_fc1, L.ldn, w.b_fc1, nullptr, h, L.ldh, (int)rows, d.hidden, L.ldn, 1};
         FVIT_TRY(launch_gemm(g1, st));
     }
+    dbg_rowhash("mlp.h", h, rows, L.ldh * 2, st);
     GemmCall g2 = {dt, h, L.ldh, w.w_fc2, L.ldh, w.b_fc2, w.gamma, x, d.C, (int)rows, d.C, L.ldh, 2};
     if (next_pe && next_pe->add) { g2.add = next_pe->add; g2.add_idx = next_pe->add_idx; g2.rows_per_image = next_pe->rows_per_image; }
     FVIT_TRY(launch_gemm(g2, st));
+    dbg_rowhash("mlp.out", x, rows, d.C * 4, st);
     return FVIT_OK;
 }
 
@@ -272,6 +282,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
                               1e-5f, L.G, w.hat_attn.w_qkv_frag, w.hat_attn.b_qkv_heads, w.hat_attn.w_proj_frag, w.hat_attn.b_proj,
                               w.hat_attn.gamma, w.hat_attn.bias, R, d.batch, L.G, d.heads, d.C, scale};
             FVIT_TRY(launch_attnblk(ab, st));
+            dbg_rowhash("ct.attnblk", R, L.Mc, d.C * 4, st);
         } else {
             // ct_dewindow gather (+ hat_pos_embed) -> R, LN(hat_norm1) -> Rn
             LnCall ln = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), R, Rn, L.ldn,
@@ -284,6 +295,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
                 FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st, true));
             } else {
                 FVIT_TRY(launch_gather_layernorm(ln, st));
+                dbg_rowhash("ct.gather", R, L.Mc, d.C * 4, st);
                 FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st));
             }
         }
@@ -296,6 +308,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
                           w.attn.w_qkv_frag, w.attn.b_qkv_heads, w.attn.w_proj_frag, w.attn.b_proj, w.attn.gamma, w.attn.bias, X,
                           d.batch * L.nW, L.S, d.heads, d.C, scale};
         FVIT_TRY(launch_attnblk(ab, st));
+        dbg_rowhash("win.attnblk", X, L.Mx, d.C * 4, st);
     } else if (pe_preadded) {
         // X already holds x + pos_embed (added by the previous block's fc2 epilogue): norm1 + qkv in one kernel
         LnCall ln1 = {dt, X, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w.attn.ln_w, w.attn.ln_b, 1e-5f, (int)L.Mx, 1, d.C};
@@ -307,6 +320,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         LnCall ln1 = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, X, Xn, L.ldn,
                       w.attn.ln_w, w.attn.ln_b, 1e-5f, (int)L.Mx, rpi, d.C};
         FVIT_TRY(launch_gather_layernorm(ln1, st));
+        dbg_rowhash("win.gather", X, L.Mx, d.C * 4, st);
         FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st));
     }
     FVIT_TRY(run_mlp(d, L, w.mlp, X, L.Mx, Xn, Hb, st, next_pe));
@@ -379,6 +393,7 @@ int fvit_hat_stage_forward(const FvitStageDesc* desc, const FvitBlockWeights* bl
     float* X = (float*)(ws + L.off_X);
     PartitionCall pc = {*in, d.batch, d.C, d.Hp, d.Wp, d.ws, X, L.S, L.ncw, d.hier ? ct_init : nullptr, L.ncw};
     FVIT_TRY(launch_partition(pc, st));
+    dbg_rowhash("partition", X, L.Mx, d.C * 4, st);
     bool pre = false;   // does X already include block i's position embedding?
     for (int i = 0; i < d.depth; ++i) {
         NextPe np;

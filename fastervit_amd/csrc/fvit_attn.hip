@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             }
             sc[jb] = a;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = max_xor32(max_xor16(mx));
         float sum = 0.f;
 #pragma unroll
         for (int jb = 0; jb < SB; ++jb) {
@@ -143,8 +142,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 sum += e;
             }
         }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = sum_xor32(sum_xor16(sum));
         const float inv = 1.0f / sum;
 
         // O^T[dim][q] = V^T . P^T

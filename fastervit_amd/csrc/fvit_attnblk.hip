@@ -172,8 +172,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
                 v[kk][h2] = t;
                 sum += (t[0] + t[1]) + (t[2] + t[3]);
             }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = sum_xor32(sum_xor16(sum));
         const float mean = sum / (float)C;
         float sq = 0.f;
 #pragma unroll
@@ -183,8 +182,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
                 const f4 d = v[kk][h2] - mean;
                 sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
-        sq += __shfl_xor(sq, 16);
-        sq += __shfl_xor(sq, 32);
+        sq = sum_xor32(sum_xor16(sq));
         const float rstd = rsqrtf(sq / (float)C + p.eps);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
@@ -310,8 +308,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
             }
             sc[kb] = a;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = max_xor32(max_xor16(mx));
         float sum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NRB; ++kb)
@@ -321,8 +318,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
                 sc[kb][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = sum_xor32(sum_xor16(sum));
         const float inv = 1.0f / sum;
         f4 o[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll

@@ -182,8 +182,7 @@ __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
             }
             sc[jb] = a;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = max_xor32(max_xor16(mx));
         const float mn = fmaxf(m, mx);
         const float alpha = __expf(m - mn);
         m = mn;
@@ -213,8 +212,7 @@ __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
                 for (int kd = 0; kd < KD; ++kd) kf[jb][kd] = kn[jb][kd];
         }
     }
-    lsum += __shfl_xor(lsum, 16);
-    lsum += __shfl_xor(lsum, 32);
+    lsum = sum_xor32(sum_xor16(lsum));
     const float inv = 1.0f / lsum;
 
     // lane holds channels g*(DP/4) + db*4 + r of query qi: DP/4 consecutive channels

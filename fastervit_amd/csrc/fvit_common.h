@@ -32,6 +32,62 @@ template <> struct Op16<__bf16> {
     }
 };
 
+// Cross-row lane exchanges on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap) instead of __shfl_xor, which is
+// ds_bpermute_b32 -- an LDS-pipeline instruction.  r02 finding (profiles/r02_repeatability_hunt.log): in kernels that have LDS-DMA
+// (global_load_lds) traffic landing in the workgroup's LDS, a ds_bpermute issued by a wave whose sibling waves' DMA is still in
+// flight occasionally returned a wrong lane value when kernels of another stream shared the CU (the LayerNorm row mean of one wave
+// off by a partial sum: all 16 rows of that wave shifted, ~1e-3 relative in the kernel's output, different run to run).  The swaps
+// touch no LDS hardware, and are two VALU instructions instead of an LDS round trip.
+//   v_permlane16_swap v, s: odd 16-lane rows of v <-> even rows of s; with v = s = x, {v, s} afterwards = {own or partner, partner or own}
+//   of lane ^ 16 in a fixed order per lane pair, so op(v, s) is bitwise the same in both lanes of a pair for commutative op.
+__device__ __forceinline__ float sum_xor16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float max_xor16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// all-reduce over groups of N consecutive lanes (N a power of two <= 64; every lane of a group gets the result): DPP inside a 16-lane
+// row, the swaps above across rows -- no LDS-pipeline instruction.  quad_perm [1,0,3,2] / [2,3,0,1] are lane ^ 1 / lane ^ 2; after them
+// every quad is uniform, so row_half_mirror (lane 7 - i of the 8-group) and row_mirror (lane 15 - i) pair each quad / half row with
+// the other one exactly like lane ^ 4 / lane ^ 8 would.
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ float group_sum(float x) {
+    static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "group size");
+    if constexpr (N >= 2) x += dpp_lane<0xB1>(x);
+    if constexpr (N >= 4) x += dpp_lane<0x4E>(x);
+    if constexpr (N >= 8) x += dpp_lane<0x141>(x);
+    if constexpr (N >= 16) x += dpp_lane<0x140>(x);
+    if constexpr (N >= 32) x = sum_xor16(x);
+    if constexpr (N >= 64) x = sum_xor32(x);
+    return x;
+}
+template <int N>
+__device__ __forceinline__ float group_max(float x) {
+    static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "group size");
+    if constexpr (N >= 2) x = fmaxf(x, dpp_lane<0xB1>(x));
+    if constexpr (N >= 4) x = fmaxf(x, dpp_lane<0x4E>(x));
+    if constexpr (N >= 8) x = fmaxf(x, dpp_lane<0x141>(x));
+    if constexpr (N >= 16) x = fmaxf(x, dpp_lane<0x140>(x));
+    if constexpr (N >= 32) x = max_xor16(x);
+    if constexpr (N >= 64) x = max_xor32(x);
+    return x;
+}
+
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): far below the 16-bit rounding of any GELU
 // output here, branch-free and much cheaper than libm erff inside fused epilogues.
 __device__ __forceinline__ float fast_erf(float x) {
@@ -98,6 +154,8 @@ struct ProfScope {
 // names the launch the innermost live ProfScope brackets: kernel family + launch shape (workgroups), so that the per-launch records
 // (fvit_prof_records) can be matched with a rocprofv3 kernel trace / PMC row of the same (kernel, grid).  No-op when the timer is off.
 void prof_note(const char* kernel, int grid);
+void dbg_poison_before_launch(hipStream_t st);   // diagnosis: register / LDS poison kernel in front of every launch (fvit_debug_poison_launches)
+void dbg_rowhash(const char* tag, const void* ptr, long long rows, int row_bytes, hipStream_t st);   // no-op unless fvit_debug_rowhash_begin is active
 
 // ---- launchers (defined in the .hip files) ----
 struct GemmCall {

@@ -77,8 +77,7 @@ __global__ __launch_bounds__(256) void ln2d_kernel(const T* __restrict__ in, T* 
             for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
         }
     }
-#pragma unroll
-    for (int o = LPP / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = group_sum<LPP>(sum);
     // Cv <= C real channels; the C - Cv trailing pad channels hold zeros (channel-padded deploy maps): they add nothing to
     // the sum and (0 - mean)^2 each to the squared deviations, which is taken out again below
     const float mean = sum / (float)Cv;
@@ -90,8 +89,7 @@ __global__ __launch_bounds__(256) void ln2d_kernel(const T* __restrict__ in, T* 
             for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
         }
     }
-#pragma unroll
-    for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    sq = group_sum<LPP>(sq);
     sq -= (float)(C - Cv) * mean * mean;
     const float rstd = rsqrtf(fmaxf(sq, 0.f) / (float)Cv + eps);
     if (!ok) return;
@@ -192,4 +190,121 @@ int fvit_layernorm2d_cl(int32_t dtype, const void* in, void* out, const float* w
     return FVIT_EINVAL;
 }
 
+/* Test / diagnosis aid: fills the LDS and the registers of every CU it lands on with a NaN pattern and exits.  Launched on a side
+ * stream beside a forward, it turns any read of uninitialised LDS (whose content is otherwise whatever the previous workgroup left --
+ * repeatable on one stream, timing-dependent with concurrent streams) into NaNs / large errors. */
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned* sink, int spin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned pl[];
+    for (int i = threadIdx.x; i < 16 * 1024; i += 256) pl[i] = 0x7fc07fc0u;   // 64 KiB: f32 NaN = two f16 NaNs
+    __syncthreads();
+    unsigned acc = 0;
+    for (int k = 0; k < spin; ++k) acc += pl[(threadIdx.x * 17 + k * 31) & (16 * 1024 - 1)];
+    if (acc == 1u) sink[0] = acc;
+}
+
+/* Test / diagnosis aid: one wave per SIMD that writes a NaN pattern into ALL 512 of its vector registers (256 VGPRs + 256 AGPRs) and
+ * into its share of the LDS, spins, and exits.  Registers and LDS are not cleared between waves, so a kernel that reads a register or an
+ * LDS byte it never wrote returns whatever the previous occupant left: the same value run after run on one stream (which is how such a
+ * read passes parity and repeatability tests) and something else when another stream's kernels share the CU.  Run before a kernel,
+ * this makes that read visible on ONE stream. */
+__global__ __launch_bounds__(64) void regs_poison_kernel(unsigned* sink, int spin, unsigned pattern) {
+    extern __shared__ __attribute__((aligned(16))) unsigned pl[];
+    for (int i = threadIdx.x; i < 10 * 1024; i += 64) pl[i] = pattern;   // 40 KiB per wave, 4 waves per CU
+    __syncthreads();
+    unsigned acc = 0;
+    for (int k = 0; k < spin; ++k) acc += pl[(threadIdx.x * 17 + k * 31) % (10 * 1024)];
+    asm volatile(
+        ".set fvit_i, 1\n"
+        ".rept 255\n"
+        "v_mov_b32 v[fvit_i], %0\n"
+        ".set fvit_i, fvit_i + 1\n"
+        ".endr\n"
+        ".set fvit_i, 0\n"
+        ".rept 256\n"
+        "v_accvgpr_write_b32 a[fvit_i], %0\n"
+        ".set fvit_i, fvit_i + 1\n"
+        ".endr\n"
+        :
+        : "s"(pattern)
+        : "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255",
+          "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+    if (acc == 1u) sink[0] = acc;
+}
+int fvit_debug_regs_poison(void* sink, int32_t blocks, int32_t spin, uint32_t pattern, fvit_stream_t stream) {
+    if (!sink || blocks <= 0) { set_error("debug_regs_poison: bad arguments"); return FVIT_EINVAL; }
+    hipLaunchKernelGGL(regs_poison_kernel, dim3(blocks), dim3(64), 40 * 1024, (hipStream_t)stream, (unsigned*)sink, spin, pattern);
+    return check_launch("regs_poison_kernel");
+}
+
+int fvit_debug_lds_poison(void* sink, int32_t blocks, int32_t spin, fvit_stream_t stream) {
+    if (!sink || blocks <= 0) { set_error("debug_lds_poison: bad arguments"); return FVIT_EINVAL; }
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(blocks), dim3(256), 64 * 1024, (hipStream_t)stream, (unsigned*)sink, spin);
+    return check_launch("lds_poison_kernel");
+}
+
+/* Diagnosis aid: one 32-bit hash per row of a device buffer, appended to a caller-provided trace buffer after selected launches of the
+ * stage driver (fvit_debug_rowhash_begin / _end).  Comparing the traces of two identical calls names the first kernel and the rows
+ * whose output differs. */
+__global__ __launch_bounds__(256) void rowhash_kernel(const unsigned* __restrict__ x, long long rows, int words, unsigned* __restrict__ out) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned* r = x + row * words;
+    unsigned h = 0x811C9DC5u + (unsigned)lane;
+    for (int i = lane; i < words; i += 64) h = (h ^ r[i]) * 0x01000193u;
+    h *= (unsigned)(2 * lane + 1);
+    for (int o = 32; o; o >>= 1) h ^= __shfl_xor(h, o);
+    if (lane == 0) out[row] = h;
+}
+
+}  // extern "C"
+
+namespace fvit {
+struct DbgTrace { unsigned* buf = nullptr; long long cap = 0, used = 0; int nrec = 0; int ndump = 0; int dump_rec[64]; void* dump_dst[64]; long long dump_cap[64]; FvitDebugRowhashRecord rec[FVIT_DEBUG_MAX_RECORDS]; };
+static DbgTrace g_dbg;
+void dbg_rowhash(const char* tag, const void* ptr, long long rows, int row_bytes, hipStream_t st) {
+    if (!g_dbg.buf || !ptr || rows <= 0) return;
+    if (g_dbg.nrec >= FVIT_DEBUG_MAX_RECORDS || g_dbg.used + rows > g_dbg.cap) return;
+    FvitDebugRowhashRecord& r = g_dbg.rec[g_dbg.nrec++];
+    snprintf(r.tag, sizeof(r.tag), "%s", tag);
+    r.offset = g_dbg.used; r.rows = rows;
+    hipLaunchKernelGGL(rowhash_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const unsigned*)ptr, rows, row_bytes / 4, g_dbg.buf + g_dbg.used);
+    g_dbg.used += rows;
+    for (int i = 0; i < g_dbg.ndump; ++i)
+        if (g_dbg.nrec - 1 == g_dbg.dump_rec[i] && g_dbg.dump_dst[i] && rows * row_bytes <= g_dbg.dump_cap[i])
+            (void)hipMemcpyAsync(g_dbg.dump_dst[i], ptr, (size_t)rows * row_bytes, hipMemcpyDeviceToDevice, st);
+}
+}  // namespace fvit
+
+namespace fvit {
+static unsigned* g_poison_sink = nullptr;
+static unsigned g_poison_pattern = 0;
+void dbg_poison_before_launch(hipStream_t st) {
+    if (!g_poison_sink) return;
+    hipLaunchKernelGGL(regs_poison_kernel, dim3(2048), dim3(64), 40 * 1024, st, g_poison_sink, 64, g_poison_pattern);
+}
+}  // namespace fvit
+
+extern "C" {
+int fvit_debug_poison_launches(void* sink, uint32_t pattern) {
+    fvit::g_poison_sink = (unsigned*)sink; fvit::g_poison_pattern = pattern;
+    return FVIT_OK;
+}
+int fvit_debug_rowhash_begin(void* buf, int64_t capacity_words) {
+    fvit::g_dbg.buf = (unsigned*)buf; fvit::g_dbg.cap = capacity_words; fvit::g_dbg.used = 0; fvit::g_dbg.nrec = 0;
+    return FVIT_OK;
+}
+int fvit_debug_rowhash_dump(int32_t record, void* dst, int64_t capacity_bytes) {
+    if (record < 0) { fvit::g_dbg.ndump = 0; return FVIT_OK; }
+    if (fvit::g_dbg.ndump >= 64) { set_error("debug_rowhash_dump: at most 64 records"); return FVIT_EINVAL; }
+    const int i = fvit::g_dbg.ndump++;
+    fvit::g_dbg.dump_rec[i] = record; fvit::g_dbg.dump_dst[i] = dst; fvit::g_dbg.dump_cap[i] = capacity_bytes;
+    return FVIT_OK;
+}
+int fvit_debug_rowhash_end(FvitDebugRowhashRecord* out, int32_t max_records) {
+    int n = fvit::g_dbg.nrec < max_records ? fvit::g_dbg.nrec : max_records;
+    for (int i = 0; i < n && out; ++i) out[i] = fvit::g_dbg.rec[i];
+    fvit::g_dbg.buf = nullptr;
+    return n;
+}
 }  // extern "C"

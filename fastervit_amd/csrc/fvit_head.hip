@@ -54,13 +54,11 @@ __global__ __launch_bounds__(256) void head_logits_kernel(const float* __restric
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+    v = group_max<64>(v);
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    v = group_sum<64>(v);
     return v;
 }
 
@@ -135,8 +133,7 @@ __global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict_
         if (nn < N) grad[(size_t)nn * F + tf * 16 + s] = acc[r];
     }
     if (tf == 0) {   // db: column sums of dlogits; lane (g, s) holds the samples {b0 + 4g + t} of class tn*16 + s
-        dsum += __shfl_xor(dsum, 16);
-        dsum += __shfl_xor(dsum, 32);
+        dsum = sum_xor32(sum_xor16(dsum));
         if (g == 0 && tn * 16 + s < N) grad[(size_t)N * F + tn * 16 + s] = dsum;
         if (tn == 0) {   // loss: fixed-order sum of the per-row losses
             float ls = 0.f;

@@ -134,14 +134,12 @@ __global__ __launch_bounds__(256, 1) void lngemm_kernel(LnGemmParams p) {
                 }
             }
             float sum = ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
-#pragma unroll
-            for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            sum = group_sum<LPR>(sum);
             const float mean = sum / (float)K;
             const f4 d0 = x0 - mean, d1 = x1 - mean;
             float sq = ((d0[0] * d0[0] + d0[1] * d0[1]) + (d0[2] * d0[2] + d0[3] * d0[3])) +
                        ((d1[0] * d1[0] + d1[1] * d1[1]) + (d1[2] * d1[2] + d1[3] * d1[3]));
-#pragma unroll
-            for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            sq = group_sum<LPR>(sq);
             const float rstd = rsqrtf(sq / (float)K + p.eps);
             if (p.x_out && tg == 0 && m0 + r < p.M) {
                 float* xo = p.x_out + (size_t)(m0 + r) * K + l * 8;

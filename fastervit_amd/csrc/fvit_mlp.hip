@@ -42,6 +42,8 @@ struct MlpParams {
     const float* gamma;  // [C] or null
     float eps;
     int M, hidden;
+    float* dbgx;     // diagnosis only: the kernel stores the input rows exactly as its loads returned them ([M][C])
+    unsigned* dbg;   // diagnosis only (fvit_debug_mlp_trace_begin): per-lane hashes of the kernel's intermediate state; null in production
     int stagger;  // 1: workgroup b walks the hidden chunks starting at chunk b % nchunk; 2: offsets spread evenly over the workgroups of an XCD
     int ablate;   // timing experiments only (results are wrong): bit 1 = skip weight staging (bit 0, GELU -> identity, was removed in r02:
                   // a runtime branch around every GELU serialised the chunk body)
@@ -65,7 +67,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 // chunks in flight behind a COUNTED s_waitcnt vmcnt + raw s_barrier, one workgroup per CU: for launches of <= ~1 workgroup per CU,
 // where the chunk loop is otherwise one LDS-DMA round trip per chunk (r02 probe, 32 KiB steps, small grids: 0.88 us per step with a
 // 2-deep ring and every workgroup in lockstep on a cold weight stream vs 0.30 us with a 4-deep ring and staggered chunk order).
-template <typename T, int C, int RB, int NW, int MINW, bool KEEPX, int NB = 2>
+template <typename T, int C, int RB, int NW, int MINW, bool KEEPX, int NB = 2, bool TRACE = false>
 __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
     constexpr int NBUF = NB;
     typedef typename Op16<T>::v8 v8;
@@ -103,6 +105,19 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
     const char* __restrict__ W1 = (const char*)p.w1f;
     const char* __restrict__ W2 = (const char*)p.w2f;
     const int lane16 = lane * 16;
+    // diagnosis trace: slot q of this wave = 64 lanes x 1 word; q = 0: LN fragments, 1 + 5 * it + {0: W1 fragments as read, 1: pre-GELU
+    // accumulators, 2: GELU output fragment, 3: W2 fragments as read, 4: output accumulators after the chunk}
+    unsigned* dq = TRACE && p.dbg ? p.dbg + ((size_t)(blockIdx.x * NW + wave) * (size_t)(4 + 5 * nchunk)) * 64 + lane : nullptr;
+    auto fold8 = [](unsigned h, const v8& v) {
+        const uint4 u = __builtin_bit_cast(uint4, v);
+        h = h * 31u + u.x; h = h * 31u + u.y; h = h * 31u + u.z; h = h * 31u + u.w;
+        return h;
+    };
+    auto fold4 = [](unsigned h, const f4& v) {
+        const uint4 u = __builtin_bit_cast(uint4, v);
+        h = h * 31u + u.x; h = h * 31u + u.y; h = h * 31u + u.z; h = h * 31u + u.w;
+        return h;
+    };
 
     // wave w copies fragments w, w+NW, w+2NW, ... of the chunk (W1 fragments first, then W2)
     auto stage = [&](int j, char* buf) {
@@ -141,8 +156,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
             v[kk][1] = *(const f4*)(xr + (kk >> 1) * 64 + (kk & 1) * 8 + 4);
             sum += (v[kk][0][0] + v[kk][0][1]) + (v[kk][0][2] + v[kk][0][3]) + (v[kk][1][0] + v[kk][1][1]) + (v[kk][1][2] + v[kk][1][3]);
         }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = sum_xor32(sum_xor16(sum));   // VALU lane swaps, not ds_bpermute: see fvit_common.h
         const float mean = sum / (float)C;
         float sq = 0.f;
 #pragma unroll
@@ -152,8 +166,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
                 const f4 d = v[kk][h] - mean;
                 sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
-        sq += __shfl_xor(sq, 16);
-        sq += __shfl_xor(sq, 32);
+        sq = sum_xor32(sum_xor16(sq));
         const float rstd = rsqrtf(sq / (float)C + p.eps);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
@@ -171,6 +184,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
         }
     }
 
+    if (TRACE && dq) {
+        unsigned h = 0;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) h = fold8(h, xf[0][kk]);
+        dq[0] = h;
+    }
+    if (TRACE && p.dbgx) {   // the normalised fragments themselves: [workgroup * NW + wave][kk][lane] x 16 bytes
+        uint4* dx = (uint4*)p.dbgx + ((size_t)(blockIdx.x * NW + wave) * KK) * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) dx[kk * 64] = __builtin_bit_cast(uint4, xf[0][kk]);
+    }
     f4 acc2[CB][RB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -192,7 +216,23 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         // refill the slot chunk it - 1 was read from (every wave is past it: it arrived at this barrier)
-        if (it + NBUF - 1 < nchunk && !(p.ablate & 2)) stage(chunk_of(it + NBUF - 1), smem + ((it + NBUF - 1) % NBUF) * BUF_BYTES);
+        if (TRACE && (p.ablate & 64)) { asm volatile("s_sleep 4\n\ts_barrier" ::: "memory"); }   // debug: settle time + second barrier between the DMA wait and the first read
+        if (TRACE && (p.ablate & 128)) {   // debug: stage through registers (plain loads + ds_write, no LDS-DMA), synchronously
+            if (it == 0) {      // chunk 0 was staged by DMA in the prologue: restage it too
+                const char* s1 = W1 + (size_t)chunk_of(0) * W1_BYTES + lane16;
+                const char* s2 = W2 + (size_t)chunk_of(0) * W2_BYTES + lane16;
+                for (int i = 0; i < W1_FRAGS / NW; ++i) *(uint4*)(smem + (wave + NW * i) * 1024 + lane16) = *(const uint4*)(s1 + (wave + NW * i) * 1024);
+                for (int i = 0; i < W2_FRAGS / NW; ++i) *(uint4*)(smem + W1_BYTES + (wave + NW * i) * 1024 + lane16) = *(const uint4*)(s2 + (wave + NW * i) * 1024);
+            }
+            if (it + 1 < nchunk) {
+                char* dst = smem + ((it + 1) % NBUF) * BUF_BYTES;
+                const char* s1 = W1 + (size_t)chunk_of(it + 1) * W1_BYTES + lane16;
+                const char* s2 = W2 + (size_t)chunk_of(it + 1) * W2_BYTES + lane16;
+                for (int i = 0; i < W1_FRAGS / NW; ++i) *(uint4*)(dst + (wave + NW * i) * 1024 + lane16) = *(const uint4*)(s1 + (wave + NW * i) * 1024);
+                for (int i = 0; i < W2_FRAGS / NW; ++i) *(uint4*)(dst + W1_BYTES + (wave + NW * i) * 1024 + lane16) = *(const uint4*)(s2 + (wave + NW * i) * 1024);
+            }
+            __syncthreads();
+        } else if (it + NBUF - 1 < nchunk && !(p.ablate & 2)) stage(chunk_of(it + NBUF - 1), smem + ((it + NBUF - 1) % NBUF) * BUF_BYTES);
         if (p.ablate & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // debug: synchronous weight DMA
         if constexpr (RB == 1) {
             // The chunk body is written for a wave that is ALONE on its SIMD (small grids: the carrier-token branch, stage 3, the
@@ -218,6 +258,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
 #pragma unroll
                 for (int i = 0; i < FB; ++i) wf[i] = *(const v8*)(buf + (f0 + i) * 1024);   // fragment index = hb * KK + kk
                 __builtin_amdgcn_sched_barrier(0);
+                if (TRACE && dq) {
+                    unsigned h = 0;
+#pragma unroll
+                    for (int i = 0; i < FB; ++i) h = fold8(h, wf[i]);
+                    dq[(size_t)(4 + 5 * it + 0) * 64] = h;
+                }
                 // issue order kk-major inside the batch so that consecutive MFMAs hit different accumulators
 #pragma unroll
                 for (int i = 0; i < FB; ++i) {
@@ -242,12 +288,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
                 f4 h0 = acc1[0][rb][0], h1 = acc1[1][rb][0];
 #pragma unroll
                 for (int ks = 1; ks < KSPLIT; ++ks) { h0 += acc1[0][rb][ks]; h1 += acc1[1][rb][ks]; }
+                if (TRACE && dq) dq[(size_t)(4 + 5 * it + 1) * 64] = fold4(fold4(0u, h0), h1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     pf[rb][r] = (T)gelu_fast(h0[r] + bA[r]);
                     pf[rb][4 + r] = (T)gelu_fast(h1[r] + bB[r]);
                 }
             }
+            if (TRACE && dq) dq[(size_t)(4 + 5 * it + 2) * 64] = fold8(0u, pf[0]);
+            unsigned hw2 = 0;
             // ---- GEMM2: OUT^T[channel][row] += W2[channel][chunk units] . H^T; batch c+1 is requested before the MFMAs of batch c ----
 #pragma unroll
             for (int c0 = 0; c0 < CB; c0 += 2 * HB2) {
@@ -259,6 +308,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
                 for (int i = 0; i < HB2; ++i)
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) acc2[c0 + i][rb] = Op16<T>::mfma(w2a[i], pf[rb], acc2[c0 + i][rb]);
+                if (TRACE && dq) {
+#pragma unroll
+                    for (int i = 0; i < HB2; ++i) hw2 = fold8(hw2, w2a[i]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (c0 + 2 * HB2 < CB) {
 #pragma unroll
@@ -269,6 +322,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
                 for (int i = 0; i < HB2; ++i)
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) acc2[c0 + HB2 + i][rb] = Op16<T>::mfma(w2b[i], pf[rb], acc2[c0 + HB2 + i][rb]);
+                if (TRACE && dq) {
+#pragma unroll
+                    for (int i = 0; i < HB2; ++i) hw2 = fold8(hw2, w2b[i]);
+                }
+            }
+            if (TRACE && dq) {
+                dq[(size_t)(4 + 5 * it + 3) * 64] = hw2;
+                unsigned h = 0;
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) h = fold4(h, acc2[cb][0]);
+                dq[(size_t)(4 + 5 * it + 4) * 64] = h;
             }
         } else {
             // 32 rows per wave (whole-batch launches, two workgroups per CU): 128 accumulator registers leave no room for fragment
@@ -339,6 +403,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
     }
 }
 
+struct MlpDbg {
+    unsigned* buf = nullptr; long long cap = 0, used = 0; int nlaunch = 0; long long off[64]; int rows[64];
+    float* xbuf = nullptr; long long xcap = 0, xused = 0; int nx = 0; long long xoff[64]; int xrows[64];
+};
+MlpDbg g_mdbg;
+
 template <typename T>
 int launch_t(const MlpFusedCall& c, hipStream_t stream) {
     MlpParams p;
@@ -350,6 +420,23 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
     // profiles/r02_repeatability_hunt.log), and it buys no throughput (the chunk loop is not DMA-bound, r02_ring_depth_ab.log)
     p.stagger = tune_get("mlp_stagger", 0);
     p.ablate = tune_get("mlp_ablate", 0);
+    p.dbg = nullptr;
+    p.dbgx = nullptr;
+    if (g_mdbg.xbuf && c.C == 256 && g_mdbg.nx < 64 && g_mdbg.xused + (long long)c.M * c.C <= g_mdbg.xcap) {
+        p.dbgx = g_mdbg.xbuf + g_mdbg.xused;
+        g_mdbg.xoff[g_mdbg.nx] = g_mdbg.xused;
+        g_mdbg.xrows[g_mdbg.nx++] = c.M;
+        g_mdbg.xused += (long long)c.M * c.C;
+    }
+    if (g_mdbg.buf && c.C == 256 && g_mdbg.nlaunch < 64) {
+        const long long need = (long long)((c.M + 63) / 64) * 4 * (4 + 5 * (c.hidden / 32)) * 64;
+        if (g_mdbg.used + need <= g_mdbg.cap) {
+            p.dbg = g_mdbg.buf + g_mdbg.used;
+            g_mdbg.off[g_mdbg.nlaunch] = g_mdbg.used;
+            g_mdbg.rows[g_mdbg.nlaunch++] = c.M;
+            g_mdbg.used += need;
+        }
+    }
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
     ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
@@ -376,7 +463,12 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
             case 3: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2, false>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;
             case 4: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, false>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p); break;
             case 5: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2, true>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;  // spills
-            default: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, true>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p); break;
+            default:
+                if (p.dbg || p.dbgx || (p.ablate & (64 | 128)))   // diagnosis build of the same kernel (fvit_debug_mlp_*)
+                    hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, true, 2, true>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p);
+                else
+                    hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, true>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p);
+                break;
         }
     } else if (c.C == 512) {
         // stage 3 of FasterViT-0: 16 rows per wave, one workgroup (136 KiB of LDS: two 64-KiB weight chunks) per CU; the 128
@@ -405,3 +497,28 @@ int launch_mlp_fused(const MlpFusedCall& c, hipStream_t stream) {
 }
 
 }  // namespace fvit
+
+extern "C" {
+/* diagnosis: while active, every default-variant C = 256 fused-MLP launch writes per-lane hashes of its intermediate state (see dq in the
+ * kernel) to consecutive slices of buf; _end returns the number of traced launches with their slice offsets (words) and row counts */
+int fvit_debug_mlp_trace_begin(void* buf, int64_t capacity_words) {
+    fvit::g_mdbg.buf = (unsigned*)buf; fvit::g_mdbg.cap = capacity_words; fvit::g_mdbg.used = 0; fvit::g_mdbg.nlaunch = 0;
+    return FVIT_OK;
+}
+int fvit_debug_mlp_inputs_begin(void* buf, int64_t capacity_floats) {
+    fvit::g_mdbg.xbuf = (float*)buf; fvit::g_mdbg.xcap = capacity_floats; fvit::g_mdbg.xused = 0; fvit::g_mdbg.nx = 0;
+    return FVIT_OK;
+}
+int fvit_debug_mlp_inputs_end(int64_t* offsets, int32_t* rows, int32_t max_launches) {
+    const int n = fvit::g_mdbg.nx < max_launches ? fvit::g_mdbg.nx : max_launches;
+    for (int i = 0; i < n; ++i) { if (offsets) offsets[i] = fvit::g_mdbg.xoff[i]; if (rows) rows[i] = fvit::g_mdbg.xrows[i]; }
+    fvit::g_mdbg.xbuf = nullptr;
+    return n;
+}
+int fvit_debug_mlp_trace_end(int64_t* offsets, int32_t* rows, int32_t max_launches) {
+    const int n = fvit::g_mdbg.nlaunch < max_launches ? fvit::g_mdbg.nlaunch : max_launches;
+    for (int i = 0; i < n; ++i) { if (offsets) offsets[i] = fvit::g_mdbg.off[i]; if (rows) rows[i] = fvit::g_mdbg.rows[i]; }
+    fvit::g_mdbg.buf = nullptr;
+    return n;
+}
+}

@@ -67,8 +67,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnParams p) {
             v[i] = (f4){0.f, 0.f, 0.f, 0.f};
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = group_sum<64>(sum);
     const float mean = sum / (float)p.C;
     float sq = 0.f;
 #pragma unroll
@@ -79,8 +78,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnParams p) {
             sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    sq = group_sum<64>(sq);
     const float rstd = rsqrtf(sq / (float)p.C + p.eps);
     float* xo = p.x_out ? p.x_out + (size_t)row * p.C : nullptr;
     T* no = (T*)p.n_out + (size_t)row * p.ldn;

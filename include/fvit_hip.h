@@ -336,6 +336,36 @@ int fvit_sgd_momentum(float* param, float* momentum, const float* grad, int64_t 
  * DO produce wrong results.  Guarded by a mutex; launches read the values at launch time. */
 int fvit_tune(const char* key, int32_t value);
 
+/* Diagnosis aid (tests / scripts only): `blocks` workgroups that fill 64 KiB of LDS each with a NaN pattern, spin `spin` iterations and
+ * exit; run beside a forward on another stream, it exposes reads of uninitialised LDS.  sink: >= 4 bytes of device memory. */
+int fvit_debug_lds_poison(void* sink, int32_t blocks, int32_t spin, fvit_stream_t stream);
+/* Diagnosis aid (tests / scripts only): `blocks` single-wave workgroups that each write `pattern` into all 512 vector registers of the
+ * wave and into 40 KiB of LDS, spin and exit (one wave fills a SIMD's register file: >= 1024 blocks cover the chip).  Run BEFORE a kernel
+ * on the same stream it exposes reads of registers / LDS the kernel never wrote (they keep the previous occupant's content). */
+int fvit_debug_regs_poison(void* sink, int32_t blocks, int32_t spin, uint32_t pattern, fvit_stream_t stream);
+/* sink != null: that poison kernel (2048 blocks) is launched in front of EVERY kernel of this library, on the kernel's stream, until the
+ * call is repeated with sink = null.  Results must not depend on it, nor on the pattern. */
+int fvit_debug_poison_launches(void* sink, uint32_t pattern);
+
+/* Diagnosis aid (tests / scripts only): between _begin and _end, fvit_hat_stage_forward appends one 32-bit hash per row of its fp32
+ * streams (window tensor X, carrier stream R) to `buf` after every launch that writes them.  Single host thread only.  _end returns the
+ * number of records and copies up to max_records of them. */
+#define FVIT_DEBUG_MAX_RECORDS 512
+typedef struct { char tag[24]; int64_t offset; int64_t rows; } FvitDebugRowhashRecord;
+int fvit_debug_rowhash_begin(void* buf, int64_t capacity_words);
+int fvit_debug_rowhash_end(FvitDebugRowhashRecord* out, int32_t max_records);
+/* also copy the buffer of record number `record` (in trace order) to dst (device memory); up to 64 records; record < 0 clears the list */
+int fvit_debug_rowhash_dump(int32_t record, void* dst, int64_t capacity_bytes);
+/* Diagnosis aid: while active, every C = 256 fused-MLP launch writes per-lane hashes of its intermediate state (normalised input
+ * fragments; per hidden chunk: the W1 fragments as read from LDS, the pre-GELU accumulators, the GELU output fragment, the W2 fragments as
+ * read, the output accumulators) to consecutive slices of buf: [workgroup * 4 + wave][1 + 5 * hidden / 32][64 lanes] words.  _end returns
+ * the number of traced launches (<= 64) with their slice offsets (words) and row counts.  Single host thread only. */
+int fvit_debug_mlp_trace_begin(void* buf, int64_t capacity_words);
+int fvit_debug_mlp_trace_end(int64_t* offsets, int32_t* rows, int32_t max_launches);
+/* same protocol: every C = 256 fused-MLP launch stores its input rows exactly as its own loads returned them ([M][256] floats per launch) */
+int fvit_debug_mlp_inputs_begin(void* buf, int64_t capacity_floats);
+int fvit_debug_mlp_inputs_end(int64_t* offsets, int32_t* rows, int32_t max_launches);
+
 /* ---- built-in kernel timer (HIP events around every launch, on the launch stream) ---- */
 #define FVIT_PROF_KINDS 11
 /* kind ids */

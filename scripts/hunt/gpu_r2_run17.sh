@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+T=${1:-r3d}
+mkdir -p gpurun_out
+timeout 500 python scripts/race_hunt4.py 12 > gpurun_out/${T}_race_hunt4.log 2>&1
+echo "rc=$?"; grep -v "amdgpu.ids\|UserWarning\|stage_forward(" gpurun_out/${T}_race_hunt4.log | tail -8

@@ -15,8 +15,7 @@ model = fastervit_amd.create_model("faster_vit_0_224").eval().cuda().to(memory_f
 x = torch.randn(256, 3, 224, 224, generator=torch.Generator().manual_seed(1000)).cuda().contiguous(memory_format=torch.channels_last)
 DEF = {"mlp_fused": 1, "attn_fused": 1, "ln_gemm": 0, "mlp_stagger": 0, "pe_preadd": 1, "mlp_variant": -1, "ab_variant": 0, "mlp_ablate": 0,
        "ab_stagger": 0, "gemm_stagger": 0}
-SETS = [{}, {"mlp_stagger": 1}, {"mlp_stagger": 2}, {"mlp_stagger": 0}, {"mlp_stagger": 0, "ln_gemm": 1}, {"mlp_stagger": 2, "mlp_ablate": 16},
-        {"mlp_stagger": 2, "mlp_ablate": 32}, {"mlp_stagger": 2, "mlp_variant": 4}, {"mlp_stagger": 0, "ab_stagger": 1}, {"mlp_stagger": 0, "gemm_stagger": 1}]
+SETS = [{}] * 6
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 for knobs in SETS:
     for k, v in DEF.items():

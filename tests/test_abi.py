@@ -105,6 +105,21 @@ def test_product_does_not_import_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
 
 
+def test_kernels_have_no_lds_pipeline_lane_exchange():
+    """r02 (profiles/r02_repeatability_hunt.log): a __shfl_xor (ds_bpermute_b32, an LDS-pipeline instruction) issued while LDS-DMA of
+    sibling waves was landing returned wrong lane values when kernels of several streams shared a CU.  Lane reductions go through the
+    VALU helpers of fvit_common.h (v_permlane16/32_swap + DPP); only the diagnosis row-hash kernel, which has no LDS-DMA beside it,
+    still shuffles."""
+    csrc = os.path.join(ROOT, "fastervit_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        for ln in open(os.path.join(csrc, f)).read().splitlines():
+            code = ln.split("//")[0]
+            if re.search(r"__shfl|ds_bpermute|ds_permute|ds_swizzle", code):
+                assert f == "fvit_glue.hip" and "h ^=" in code, f"{f}: {ln.strip()}"
+
+
 def test_registry_api():
     import fastervit_amd
     from fastervit_amd.models import registry
