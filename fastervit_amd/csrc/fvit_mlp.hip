@@ -234,15 +234,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
             __syncthreads();
         } else if (it + NBUF - 1 < nchunk && !(p.ablate & 2)) stage(chunk_of(it + NBUF - 1), smem + ((it + NBUF - 1) % NBUF) * BUF_BYTES);
         if (p.ablate & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // debug: synchronous weight DMA
-        if constexpr (RB == 1) {
+        if constexpr (RB == 1 || NW == 2) {   // NW == 2: one wave per SIMD (two 2-wave workgroups per CU), 512-register budget
             // The chunk body is written for a wave that is ALONE on its SIMD (small grids: the carrier-token branch, stage 3, the
             // shard-sized launches of the stream-sharded plan): left to the compiler the loop was "2 ds_read, s_waitcnt lgkmcnt(0),
             // 2 MFMA" sixteen times over plus eight serial GELU chains behind runtime branches -- ~3100 cycles per chunk for 512
             // cycles of MFMA issue (r02 ISA audit).  Here every fragment of a GEMM is requested before its first MFMA (one exposed
             // LDS round trip per GEMM instead of eight), GEMM1 runs KSPLIT independent accumulator chains per (unit block, row
             // block), and GEMM2's fragments are in flight while the VALU does bias + GELU.
-            constexpr int FB = RB == 1 ? 16 : 4;         // fragments requested per batch (64 / 16 VGPRs; RB = 2 already holds 128 accumulators)
-                constexpr int KSPLIT = RB == 1 ? 2 : 1;      // independent accumulator chains per output block in GEMM1
+            constexpr int FB = RB == 1 ? 16 : 8;         // fragments requested per batch (64 / 32 VGPRs)
+            constexpr int KSPLIT = RB == 1 ? 2 : 1;      // independent accumulator chains per output block in GEMM1 (RB = 2: the two row blocks are the two chains)
             constexpr int KH = KK / KSPLIT;
             // ---- GEMM1: H^T[unit][row], 2 unit blocks x RB row blocks; unit = hb*16 + 4g + r ----
             f4 acc1[2][RB][KSPLIT];
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
             }
             // ---- GEMM2's first fragment batch goes in flight now and lands while the VALU runs bias + GELU (pinned: left alone the
             // compiler sinks these reads below the GELU block again to save registers) ----
-            constexpr int HB2 = 8;                   // fragments per GEMM2 batch (32 VGPRs)
+            constexpr int HB2 = RB == 1 ? 8 : 4;     // fragments per GEMM2 batch (32 / 16 VGPRs)
             v8 w2a[HB2], w2b[HB2];
 #pragma unroll
             for (int i = 0; i < HB2; ++i) w2a[i] = *(const v8*)(buf + W1_BYTES + i * 1024);
@@ -414,10 +414,9 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
     MlpParams p;
     p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma;
     p.eps = c.eps; p.M = c.M; p.hidden = c.hidden;
-    // chunk-order stagger is OFF by default: with it, concurrent stream shards are not bit-repeatable run to run (r02 race hunt:
-    // eager or hipGraph, 3 stream shards of batch 256: logits of the side-stream shards differ in the last fp16 bit between
-    // identical calls with stagger 1 / 2, never with 0; the kernel alone on 3 concurrent streams IS repeatable either way --
-    // profiles/r02_repeatability_hunt.log), and it buys no throughput (the chunk loop is not DMA-bound, r02_ring_depth_ab.log)
+    // chunk-order stagger is off by default: it buys no throughput (the chunk loop is not DMA-bound: profiles/r02_ring_depth_ab.log).
+    // (r02 first blamed it for run-to-run differences under concurrent stream shards; the cause was the ds_bpermute lane exchange of the
+    // LayerNorm prologue, see fvit_common.h / profiles/r02_repeatability_hunt.log -- the stagger only moved the timing.)
     p.stagger = tune_get("mlp_stagger", 0);
     p.ablate = tune_get("mlp_ablate", 0);
     p.dbg = nullptr;
@@ -463,6 +462,11 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
             case 3: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2, false>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;
             case 4: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, false>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p); break;
             case 5: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2, true>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;  // spills
+            // 6: 32 rows per wave, TWO waves per workgroup (64 rows, two workgroups per CU = one wave per SIMD with the 512-register budget,
+            // 437 VGPRs, no spills): every weight fragment read from LDS feeds two MFMAs.  With 16 rows per wave the 8 waves of a CU read
+            // 256 KiB of fragments per chunk round = 0.85 us at 128 B/clk of the measured ~1.28 us; halving that did NOT pay: 57.3 vs 49.0 us
+            // at M = 18232, 70.6k vs 74.5k images/s (r02 call r3i) -- one wave per SIMD leaves its barrier / LDS round trips uncovered
+            case 6: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 2, 2, true>), dim3((c.M + 63) / 64), dim3(128), 0, stream, p); break;
             default:
                 if (p.dbg || p.dbgx || (p.ablate & (64 | 128)))   // diagnosis build of the same kernel (fvit_debug_mlp_*)
                     hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, true, 2, true>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p);
