@@ -276,7 +276,18 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         void* RAO = ws + L.off_RAO;
         void* RH = ws + L.off_RH;
         const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
-        if (fused_attn_ok(d, w.hat_attn, L.G, L.Mc)) {
+        bool ct_done = false;
+        if (ctblk_supported(d.C, d.heads, L.G, d.hidden) && d.dpad == 32 && w.hat_attn.w_qkv_frag && w.hat_attn.b_qkv_heads && w.hat_attn.w_proj_frag &&
+            w.hat_attn.bias && w.hat_mlp.w_fc1_frag && w.hat_mlp.w_fc2_frag && tune_get("ct_fused", 1)) {
+            // the whole carrier-token branch (AR:679-683) in one kernel, one workgroup per image
+            CtBlkCall cb = {dt, X, rpi, t.ct_src, (d.square ? w.pe_ct : nullptr), R, d.batch, L.G, d.heads, d.C, d.hidden,
+                            w.hat_attn.ln_w, w.hat_attn.ln_b, w.hat_attn.w_qkv_frag, w.hat_attn.b_qkv_heads, w.hat_attn.w_proj_frag, w.hat_attn.b_proj,
+                            w.hat_attn.gamma, w.hat_attn.bias, scale, w.hat_mlp.ln_w, w.hat_mlp.ln_b, w.hat_mlp.w_fc1_frag, w.hat_mlp.b_fc1,
+                            w.hat_mlp.w_fc2_frag, w.hat_mlp.b_fc2, w.hat_mlp.gamma, 1e-5f};
+            FVIT_TRY(launch_ctblk(cb, st));
+            ct_done = true;
+            dbg_rowhash("ct.block", R, L.Mc, d.C * 4, st);
+        } else if (fused_attn_ok(d, w.hat_attn, L.G, L.Mc)) {
             // ct_dewindow gather (+ hat_pos_embed), LN, qkv, attention over the G carrier tokens, proj, gamma1-residual -> R
             AttnBlkCall ab = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), w.hat_attn.ln_w, w.hat_attn.ln_b,
                               1e-5f, L.G, w.hat_attn.w_qkv_frag, w.hat_attn.b_qkv_heads, w.hat_attn.w_proj_frag, w.hat_attn.b_proj,
@@ -299,7 +310,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
                 FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st));
             }
         }
-        FVIT_TRY(run_mlp(d, L, w.hat_mlp, R, L.Mc, Rn, RH, st));
+        if (!ct_done) FVIT_TRY(run_mlp(d, L, w.hat_mlp, R, L.Mc, Rn, RH, st));
     }
     if (fused_attn_ok(d, w.attn, L.S, L.Mx)) {
         // cat(ct_window(ct), x + pos_embed) gather, LN(norm1), qkv, window attention, proj, gamma3-residual -> X, one kernel
@@ -519,6 +530,18 @@ int fvit_attn_block_fused(int32_t operand_dtype, const float* srcA, int32_t rows
     AttnBlkCall ab = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, ln_w, ln_b, eps, rows_per_image, w_qkv_frag,
                       b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
     return launch_attnblk(ab, (hipStream_t)stream);
+}
+
+int fvit_ct_block_supported(int32_t C, int32_t heads, int32_t G, int32_t hidden) { return ctblk_supported(C, heads, G, hidden) ? 1 : 0; }
+
+int fvit_ct_block_fused(int32_t operand_dtype, const float* X, int32_t rowsA, const int32_t* src_idx, const float* add, float* R,
+                        int32_t batch, int32_t G, int32_t heads, int32_t C, int32_t hidden, const float* ln1_w, const float* ln1_b,
+                        const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag, const float* b_proj, const float* gamma1,
+                        const float* bias, float scale, const float* ln2_w, const float* ln2_b, const void* w_fc1_frag, const float* b_fc1,
+                        const void* w_fc2_frag, const float* b_fc2, const float* gamma2, float eps, fvit_stream_t stream) {
+    CtBlkCall cb = {operand_dtype, X, rowsA, src_idx, add, R, batch, G, heads, C, hidden, ln1_w, ln1_b, w_qkv_frag, b_qkv_heads, w_proj_frag,
+                    b_proj, gamma1, bias, scale, ln2_w, ln2_b, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma2, eps};
+    return launch_ctblk(cb, (hipStream_t)stream);
 }
 
 int fvit_mlp_fused_supported(int32_t C, int32_t hidden) { return mlp_fused_supported(C, hidden) ? 1 : 0; }

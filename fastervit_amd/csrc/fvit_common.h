@@ -261,6 +261,22 @@ struct LnCall {
 int launch_gather_layernorm(const LnCall& c, hipStream_t stream);
 
 // LayerNorm folded into the A-operand staging of the Linear layer that consumes it (fvit_lngemm.hip); ln.n_out / ln.ldn are unused
+// whole carrier-token branch of one HAT block (fvit_ctblk.hip)
+struct CtBlkCall {
+    int dtype;
+    const float* X; int rowsA;        // window tensor, rows per image
+    const int32_t* src_idx;           // [G]
+    const float* add;                 // hat_pos_embed rows [G][C] or null
+    float* R;                         // out [batch * G][C]
+    int batch, G, heads, C, hidden;
+    const float* ln1_w; const float* ln1_b; const void* wqkv_f; const float* bqkv; const void* wproj_f; const float* bproj; const float* gamma1;
+    const float* bias; float scale;
+    const float* ln2_w; const float* ln2_b; const void* w1f; const float* b1; const void* w2f; const float* b2; const float* gamma2;
+    float eps;
+};
+bool ctblk_supported(int C, int heads, int G, int hidden);
+int launch_ctblk(const CtBlkCall& c, hipStream_t stream);
+
 struct LnGemmCall {
     LnCall ln;           // row selection + LayerNorm parameters (x_out optional, must not alias the sources)
     const void* W;       // weights op16 [pad128(N)][ldw]

@@ -1,0 +1,402 @@
+// fvit_ctblk.hip -- the whole carrier-token branch of one HAT block in ONE kernel (C = 256, 8 heads of 32, hidden 1024, <= 16 carrier
+// tokens per image: stage 2 of FasterViT-0), gfx950:
+//
+//   ct  = ct_dewindow(carrier rows of X) (+ hat_pos_embed)                         (AR:679-681)
+//   ct += gamma1 * hat_attn(hat_norm1(ct));  ct += gamma2 * hat_mlp(hat_norm2(ct)) (AR:682-683)   -> R [B * G][C] fp32
+//
+// Unfused this is gather-LayerNorm, qkv GEMM, attention, proj GEMM, LayerNorm, fc1 GEMM, fc2 GEMM on 1360 rows per stream shard: seven
+// launches of 42-176 workgroups that each run a K loop of dependent LDS-DMA round trips (9-19 us each, 61 us per block, 0.04-0.05 of
+// their roof: r02 bench line).  The per-row-block fused kernels (fvit_attnblk / fvit_mlp) lose here as well: a workgroup streams ALL
+// 1.5 MB of weights through LDS in lockstep for 64 rows.
+//
+// Measured (FasterViT-0 stage 2, 86 images): 33 us per launch instead of ~59 us in seven launches; 826 -> 776 us per stage forward,
+// 73.5k -> 76.2k images/s end to end (r02 calls r3l / r3o).
+//
+// Here a workgroup of 4 waves owns ONE image (one 16-token row block) and the waves split the N dimension: wave w computes heads 2w,
+// 2w + 1 of the attention and hidden units 256w .. 256w + 255 of the MLP, so each wave reads only ITS quarter of the weights (384 KiB),
+// straight from L2 into registers in MFMA fragment order (the packed images of fvit_attnblk / fvit_mlp: a fragment = 64 lanes x 16 B,
+// one global_load_dwordx4 per lane), through a 3-deep register ring of 8-fragment steps (24 KiB in flight per wave); every fragment
+// feeds exactly one MFMA, nothing is staged in LDS.  Partial sums over heads (proj) and over hidden units (fc2) are exchanged once each
+// through LDS (fp32, 4 x 16 KiB) and added in a fixed order.  All lane reductions are VALU swaps (fvit_common.h).
+#include "fvit_common.h"
+
+namespace fvit {
+
+namespace {
+
+struct CtBlkParams {
+    const float* X;          // window tensor rows [B * rowsA][C]
+    const int32_t* src_idx;  // [G] row of X (inside the image) of carrier token i in raster order
+    const float* add;        // hat_pos_embed rows [G][C] or null
+    float* R;                // out [B * G][C]
+    int rowsA, B, G;
+    const float* ln1_w; const float* ln1_b;
+    const void* wqkv_f;      // op16 [heads][6][C/32][64][8]
+    const float* bqkv;       // f32  [heads][96]
+    const void* wproj_f;     // op16 [heads][C/16][64][8]
+    const float* bproj; const float* gamma1;
+    const float* bias;       // f32 [heads][16][16] (mask on padded keys)
+    float scale;
+    const float* ln2_w; const float* ln2_b;
+    const void* w1f;         // op16 [hidden/32][2][C/32][64][8]
+    const float* b1;
+    const void* w2f;         // op16 [hidden/32][C/16][64][8]
+    const float* b2; const float* gamma2;
+    float eps;
+    int touch;
+};
+
+// DEPTH: steps of the register ring in flight; MINB: workgroups per CU the register budget is sized for (1: one wave per SIMD, 512
+// registers, the ring and every phase's operands fit without scratch; 2: 256 registers, other kernels' waves can share the SIMD)
+template <typename T, int DEPTH, int MINB>
+__global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
+    typedef typename Op16<T>::v8 v8;
+    typedef typename Op16<T>::v4 v4;
+    constexpr int C = 256, KK = 8, CB = 16, NW = 4, HID = 1024;
+    constexpr int CPW = HID / 32 / NW;        // hidden chunks (of 32 units) per wave
+    constexpr int NSTEP = 16 + 4 * CPW;       // 8-fragment steps of a wave's weight stream: 2 heads x (6 qkv + 2 proj), CPW chunks x (2 fc1 + 2 fc2)
+    // partial accumulators [wave][cb][lane] x 16 B, then the small constants of the inner loops (fc1 bias, qkv bias, attention bias tables):
+    // an ordinary global load inside the loops would queue behind the ring's prefetches in the in-order vmcnt counter, and waiting for it
+    // would drain the ring (first version: 56 us per launch instead of ~20)
+    constexpr int OFF_B1 = NW * CB * 1024, OFF_BQ = OFF_B1 + HID * 4, OFF_BZ = OFF_BQ + 8 * 96 * 4;
+    __shared__ __attribute__((aligned(16))) char smem[OFF_BZ + 8 * 256 * 4];
+    float* b1s = (float*)(smem + OFF_B1);
+    float* bqs = (float*)(smem + OFF_BQ);
+    float* bzs = (float*)(smem + OFF_BZ);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, s = lane & 15;
+    const int lane16 = lane * 16;
+    const int img = blockIdx.x;
+    const int tok = s < p.G ? s : p.G - 1;    // padded tokens recompute the last one; masked as keys by the bias table, never stored
+    const bool row_ok = s < p.G;
+
+    const char* Wq = (const char*)p.wqkv_f + lane16;
+    const char* Wp = (const char*)p.wproj_f + lane16;
+    const char* W1 = (const char*)p.w1f + lane16;
+    const char* W2 = (const char*)p.w2f + lane16;
+    auto step_ptr = [&](int t) -> const char* {
+        if (t < 16) {
+            const int h = 2 * wave + (t >> 3), u = t & 7;
+            return u < 6 ? Wq + ((size_t)h * 48 + u * 8) * 1024 : Wp + ((size_t)h * 16 + (u - 6) * 8) * 1024;
+        }
+        const int m = t - 16, j = CPW * wave + (m >> 2), u = m & 3;
+        return (u < 2 ? W1 : W2) + ((size_t)j * 16 + (u & 1) * 8) * 1024;
+    };
+    v8 ring[DEPTH][8];
+    constexpr bool in_attention = true;   // shadowed in the MLP phase: steps >= 16 are requested only after the exchange
+#define FVIT_CT_LOAD(t)                                                                                  \
+    if ((t) < NSTEP && !(in_attention && (t) >= 16)) {                                                                                   \
+        const char* sp_ = step_ptr(t);                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) ring[(t) % DEPTH][i_] = *(const v8*)(sp_ + i_ * 1024); \
+    }                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // Optional L2 touch (fvit_tune "ct_touch", off): one dword per 128-byte line of the wave's whole stream, all 48 loads in flight at once,
+    // before the ring starts.  The idea: a block's weights are cold (60 MB of weights per model against 4 MiB of L2 per XCD) and the
+    // workgroups of an XCD want the same lines at the same time.  Measured (r02 call r3o): 40.0 vs 33.4 us per launch -- the kernel runs at the
+    // ~40 GB/s a CU pulls from the memory side whatever the ring depth (1.5 MB per workgroup; DEPTH 2 / 3 / 4: 794 / 776 / 786 us per stage),
+    // and the touch pays that rate once more.
+    if (p.touch) {
+        // plain C++ loads folded into a value the compiler cannot discard (an asm load with a dead output would let the register
+        // allocator reuse the destination while the load is still in flight)
+        unsigned sink = 0;
+        const unsigned* tq = (const unsigned*)((const char*)p.wqkv_f + (size_t)(2 * wave) * 48 * 1024 + lane * 128);
+        const unsigned* tp = (const unsigned*)((const char*)p.wproj_f + (size_t)(2 * wave) * 16 * 1024 + lane * 128);
+        const unsigned* t1 = (const unsigned*)((const char*)p.w1f + (size_t)(CPW * wave) * 16 * 1024 + lane * 128);
+        const unsigned* t2 = (const unsigned*)((const char*)p.w2f + (size_t)(CPW * wave) * 16 * 1024 + lane * 128);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) sink ^= tq[i * 2048];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sink ^= tp[i * 2048];
+#pragma unroll
+        for (int i = 0; i < 2 * CPW; ++i) sink ^= t1[i * 2048];
+#pragma unroll
+        for (int i = 0; i < 2 * CPW; ++i) sink ^= t2[i * 2048];
+        if (sink == 0x9E3779B1u && p.touch == 12345) p.R[0] = 0.f;   // never true: keeps the loads
+    }
+    {   // constants first (oldest in the vmcnt queue), then the first DEPTH steps of the weight stream
+        float c1[HID / 256], c2[3], c3[8];
+#pragma unroll
+        for (int i = 0; i < HID / 256; ++i) c1[i] = p.b1[tid + 256 * i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c2[i] = p.bqkv[tid + 256 * i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c3[i] = p.bias[tid + 256 * i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < DEPTH; ++t) { FVIT_CT_LOAD(t) }
+#pragma unroll
+        for (int i = 0; i < HID / 256; ++i) b1s[tid + 256 * i] = c1[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bqs[tid + 256 * i] = c2[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bzs[tid + 256 * i] = c3[i];
+    }
+
+    // ---- gather (+ position embedding) and LayerNorm: lane (g, s) holds token s, channels (cb>>2)*64 + 16g + (cb&3)*4 .. +3 in v[cb] ----
+    const float* src = p.X + ((size_t)img * p.rowsA + p.src_idx[tok]) * C + g * 16;
+    // optional inputs are read through a valid stand-in pointer and masked with a scalar select: a branch per load splits the phase into
+    // basic blocks and the partial sums spill across them
+    const bool has_add = p.add != nullptr, has_g1 = p.gamma1 != nullptr, has_g2 = p.gamma2 != nullptr;
+    const float* addp = has_add ? p.add + (size_t)tok * C + g * 16 : src;
+    auto gather = [&](f4 (&v)[CB]) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) v[cb] = *(const f4*)(src + (cb >> 2) * 64 + (cb & 3) * 4);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const f4 a = *(const f4*)(addp + (cb >> 2) * 64 + (cb & 3) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[cb][r] += has_add ? a[r] : 0.f;
+        }
+    };
+    // v[cb] = channels of GEMM k step kk = cb >> 1, half cb & 1 (kch order): xf[kk] = normalised (v[2kk], v[2kk+1])
+    auto layernorm = [&](const f4 (&v)[CB], const float* lw, const float* lb, v8 (&xf)[KK]) {
+        float sum = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) sum += (v[cb][0] + v[cb][1]) + (v[cb][2] + v[cb][3]);
+        sum = sum_xor32(sum_xor16(sum));
+        const float mean = sum / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const f4 d = v[cb] - mean;
+            sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        sq = sum_xor32(sum_xor16(sq));
+        const float rstd = rsqrtf(sq / (float)C + p.eps);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            v8 o;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int cb = 2 * kk + h2;
+                const int co = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
+                const f4 w = *(const f4*)(lw + co);
+                const f4 b = *(const f4*)(lb + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)((v[cb][r] - mean) * rstd * w[r] + b[r]);
+            }
+            xf[kk] = o;
+        }
+    };
+
+    v8 xf[KK];
+    {
+        f4 v[CB];
+        gather(v);
+        layernorm(v, p.ln1_w, p.ln1_b, xf);
+    }
+
+    __syncthreads();   // constants visible (plain loads in flight survive the barrier)
+    // ---- attention: heads 2 * wave, 2 * wave + 1; out^T partial over these heads in oacc ----
+    f4 oacc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) oacc[cb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int h = 2 * wave + hh;
+        const float* bq = bqs + h * 96;
+        v8 qf, kf, vf[2];
+#pragma unroll
+        for (int ub = 0; ub < 6; ++ub) {
+            const int t = hh * 8 + ub;
+            f4 a = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+                a = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a)     // q0 q1 k0 k1: weights are the A operand -> D[dim][token]
+                           : Op16<T>::mfma(xf[kk], ring[t % DEPTH][kk], a);    // v0 v1: activations are A -> D[token][dim]
+            __builtin_amdgcn_sched_barrier(0);
+            FVIT_CT_LOAD(t + DEPTH)
+            // the accumulator becomes an operand fragment at once (keeps 4 instead of 24 accumulator registers alive)
+            if (ub < 4) {
+                const f4 bb = *(const f4*)(bq + (ub >> 1) * 32 + (ub & 1) * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (ub < 2) qf[(ub & 1) * 4 + r] = (T)(a[r] + bb[r]);
+                    else kf[(ub & 1) * 4 + r] = (T)(a[r] + bb[r]);
+                }
+            } else {
+                const float bv = bq[64 + (ub - 4) * 16 + s];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vf[ub - 4][r] = (T)(a[r] + bv);   // keys 4g + r of the only 16-key block; k slots 4..7 = keys 16.. do not exist
+                    vf[ub - 4][4 + r] = (T)0.f;
+                }
+            }
+        }
+        // scores^T[key][query] = K . Q^T * scale + bias, softmax down the key axis (in-lane over r, lane swaps over g)
+        f4 sc = Op16<T>::mfma(kf, qf, (f4){0.f, 0.f, 0.f, 0.f});
+        const f4 bz = *(const f4*)(bzs + (h * 16 + tok) * 16 + g * 4);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = sc[r] * p.scale + bz[r];
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = max_xor32(max_xor16(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = __expf(sc[r] - mx);
+            sum += sc[r];
+        }
+        sum = sum_xor32(sum_xor16(sum));
+        const float inv = 1.0f / sum;
+        v8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf[r] = (T)sc[r];
+            pf[4 + r] = (T)0.f;
+        }
+        v8 of;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const f4 o = Op16<T>::mfma(vf[db], pf, (f4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) of[db * 4 + r] = (T)(o[r] * inv);
+        }
+        // out^T += Wproj[:, head h] . O^T
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int t = hh * 8 + 6 + half;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) oacc[half * 8 + i] = Op16<T>::mfma(ring[t % DEPTH][i], of, oacc[half * 8 + i]);
+            __builtin_amdgcn_sched_barrier(0);
+            FVIT_CT_LOAD(t + DEPTH)
+        }
+    }
+
+    // ---- exchange 1: sum of the four head-pair partials in a fixed order; ct1 = ct0 + gamma1 * (sum + bproj) ----
+    char* ex = smem + lane16;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) *(f4*)(ex + (wave * CB + cb) * 1024) = oacc[cb];
+    __syncthreads();
+    f4 r1q[4];   // this wave's channel quarter of ct1, kept for the final residual
+    {
+        f4 v[CB];
+        gather(v);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            if ((cb & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // four channel blocks at a time: left alone the compiler requests all 64 partial reads first
+            f4 a = *(const f4*)(ex + (0 * CB + cb) * 1024);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) a += *(const f4*)(ex + (w * CB + cb) * 1024);
+            const int co = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
+            const f4 bv = *(const f4*)(p.bproj + co);
+            const f4 gl = *(const f4*)((has_g1 ? p.gamma1 : p.bproj) + co);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[cb][r] += (has_g1 ? gl[r] : 1.f) * (a[r] + bv[r]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // cb = 4 * wave + q without dynamic register indexing
+            f4 t = v[q];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) t = wave == w ? v[4 * w + q] : t;
+            r1q[q] = t;
+        }
+        layernorm(v, p.ln2_w, p.ln2_b, xf);
+    }
+    __syncthreads();   // every wave has read all partials: the buffer is free for the second exchange
+
+    {
+        constexpr bool in_attention = false;
+#pragma unroll
+        for (int t = 16; t < 16 + DEPTH; ++t) { FVIT_CT_LOAD(t) }
+    }
+    // ---- MLP: hidden units 32 * (CPW * wave + c) .. + 31 per chunk; fc2 partial over this wave's units in acc2 ----
+    f4 acc2[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc2[cb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        constexpr bool in_attention = false;
+        const int j = CPW * wave + c;
+        f4 a1[2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int t = 16 + 4 * c + hb;
+            f4 a = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) a = Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a);
+            a1[hb] = a;
+            __builtin_amdgcn_sched_barrier(0);
+            FVIT_CT_LOAD(t + DEPTH)
+        }
+        const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
+        const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
+        v8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf[r] = (T)gelu_fast(a1[0][r] + bA[r]);
+            pf[4 + r] = (T)gelu_fast(a1[1][r] + bB[r]);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int t = 16 + 4 * c + 2 + half;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc2[half * 8 + i] = Op16<T>::mfma(ring[t % DEPTH][i], pf, acc2[half * 8 + i]);
+            __builtin_amdgcn_sched_barrier(0);
+            FVIT_CT_LOAD(t + DEPTH)
+        }
+    }
+#undef FVIT_CT_LOAD
+
+    // ---- exchange 2: wave w finishes channels 64w .. 64w + 63: ct2 = ct1 + gamma2 * (sum + b2) ----
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) *(f4*)(ex + (wave * CB + cb) * 1024) = acc2[cb];
+    __syncthreads();
+    if (row_ok) {
+        float* pr = p.R + ((size_t)img * p.G + s) * C + wave * 64 + g * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cbo = (4 * wave + q) * 1024;
+            f4 a = *(const f4*)(ex + (0 * CB) * 1024 + cbo);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) a += *(const f4*)(ex + (w * CB) * 1024 + cbo);
+            const int co = wave * 64 + g * 16 + q * 4;
+            const f4 bv = *(const f4*)(p.b2 + co);
+            const f4 gl = *(const f4*)((has_g2 ? p.gamma2 : p.b2) + co);
+            f4 o = r1q[q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] += (has_g2 ? gl[r] : 1.f) * (a[r] + bv[r]);
+            *(f4*)(pr + q * 4) = o;
+        }
+    }
+}
+
+}  // namespace
+
+bool ctblk_supported(int C, int heads, int G, int hidden) { return C == 256 && heads == 8 && hidden == 1024 && G >= 1 && G <= 16; }
+
+int launch_ctblk(const CtBlkCall& c, hipStream_t stream) {
+    if (!ctblk_supported(c.C, c.heads, c.G, c.hidden) || c.batch <= 0 || !c.X || !c.src_idx || !c.R || !c.wqkv_f || !c.wproj_f || !c.w1f || !c.w2f ||
+        !c.bias || !c.bqkv) {
+        set_error("ct_block: unsupported arguments C=%d heads=%d G=%d hidden=%d batch=%d", c.C, c.heads, c.G, c.hidden, c.batch);
+        return FVIT_EINVAL;
+    }
+    CtBlkParams p;
+    p.X = c.X; p.src_idx = c.src_idx; p.add = c.add; p.R = c.R; p.rowsA = c.rowsA; p.B = c.batch; p.G = c.G;
+    p.ln1_w = c.ln1_w; p.ln1_b = c.ln1_b; p.wqkv_f = c.wqkv_f; p.bqkv = c.bqkv; p.wproj_f = c.wproj_f; p.bproj = c.bproj; p.gamma1 = c.gamma1;
+    p.bias = c.bias; p.scale = c.scale;
+    p.ln2_w = c.ln2_w; p.ln2_b = c.ln2_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma2 = c.gamma2; p.eps = c.eps;
+    const double rows = (double)c.batch * c.G;
+    const double flops = rows * (2.0 * c.C * 3 * c.C + 4.0 * c.G * c.C + 2.0 * c.C * c.C + 4.0 * c.C * c.hidden);
+    const double bytes = rows * c.C * 8.0 + 2.0 * (4.0 * c.C * c.C + 2.0 * c.C * c.hidden);
+    ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
+    prof_note("ctblk_kernel<256,G16>", c.batch);
+    p.touch = tune_get("ct_touch", 0);
+    const int variant = tune_get("ct_variant", 0);
+    if (c.dtype == FVIT_F16) {
+        if (variant == 1) hipLaunchKernelGGL((ctblk_kernel<_Float16, 2, 2>), dim3(c.batch), dim3(256), 0, stream, p);
+        else if (variant == 2) hipLaunchKernelGGL((ctblk_kernel<_Float16, 4, 1>), dim3(c.batch), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((ctblk_kernel<_Float16, 3, 1>), dim3(c.batch), dim3(256), 0, stream, p);
+    } else if (c.dtype == FVIT_BF16) {
+        hipLaunchKernelGGL((ctblk_kernel<__bf16, 3, 1>), dim3(c.batch), dim3(256), 0, stream, p);
+    } else { set_error("ct_block: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
+    return check_launch("ctblk_kernel");
+}
+
+}  // namespace fvit

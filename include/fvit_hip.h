@@ -246,6 +246,18 @@ int fvit_ln_gemm(int32_t operand_dtype, const float* srcA, int32_t rowsA, const 
                  int32_t rows_per_image, int32_t C, const void* Wt, int32_t ldw, const float* bias, void* out, int32_t ldo, int32_t N,
                  int32_t act, fvit_stream_t stream);
 
+/* The whole carrier-token branch of one HAT block in one kernel (AR:679-683), one workgroup per image:
+ *   ct[b][i] = X[b * rowsA + src_idx[i]] (+ add[i]);  ct += gamma1 * attn(LayerNorm1(ct));  ct += gamma2 * mlp(LayerNorm2(ct))  -> R [batch * G][C]
+ * attention over the G <= 16 carrier tokens of an image (bias f32 [heads][16][16], mask on padded keys), weights in the fragment-major
+ * packings of fvit_attn_block_fused / fvit_mlp_fused.  Needs C == 256, heads == 8, hidden == 1024 (fvit_ct_block_supported).  gamma1 /
+ * gamma2 / add may be null. */
+int fvit_ct_block_supported(int32_t C, int32_t heads, int32_t G, int32_t hidden);
+int fvit_ct_block_fused(int32_t operand_dtype, const float* X, int32_t rowsA, const int32_t* src_idx, const float* add, float* R,
+                        int32_t batch, int32_t G, int32_t heads, int32_t C, int32_t hidden, const float* ln1_w, const float* ln1_b,
+                        const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag, const float* b_proj, const float* gamma1,
+                        const float* bias, float scale, const float* ln2_w, const float* ln2_b, const void* w_fc1_frag, const float* b_fc1,
+                        const void* w_fc2_frag, const float* b_fc2, const float* gamma2, float eps, fvit_stream_t stream);
+
 /* Fused attention sub-block: x_out[i] = x_in[i] + gamma * proj(softmax(q k^T * scale + bias) v), [q|k|v] = qkv(LayerNorm(x_in)),
  * x_in[i] = gathered source row + optional add row (exactly the row selection of fvit_gather_layernorm), per window of S rows
  * (AR:671-696).  One kernel; needs C == 256, heads == 8 (head_dim 32), S <= 16 or 48 < S <= 64 (fvit_attn_block_supported).
@@ -330,7 +342,7 @@ int fvit_sgd_momentum(float* param, float* momentum, const float* grad, int64_t 
 /* Performance-experiment knobs for A/B runs inside one process; the same keys can be preset through the environment as
  * FVIT_TUNE_<key>=<int> (read once per key).  Kernel-selection knobs never change results beyond fp32 summation order:
  *   "mlp_fused", "attn_fused" 0/1; "mlp_fused_min_rows", "attn_fused_min_rows", "mlp_fused512_min_rows", "attn_fused512_min_rows";
- *   "mlp_variant" (-1 auto), "ab_variant", "ln_gemm" 0/1, "ln_gemm_max_rows", "lngemm_nt", "gemm_ring", "mlp_ring4_max_grid", "gemm_stagger", "ab_stagger", "mlp_stagger" (0 / 1 / 2), "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
+ *   "mlp_variant" (-1 auto), "ab_variant", "ct_fused" 0/1 (carrier branch in one kernel), "ct_variant", "ct_touch", "ln_gemm" 0/1, "ln_gemm_max_rows", "lngemm_nt", "gemm_ring", "mlp_ring4_max_grid", "gemm_stagger", "ab_stagger", "mlp_stagger" (0 / 1 / 2), "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
  *   "conv_halo_grid", "conv64_variant", "conv128_narrow", "stem_fused_grid".
  * The "*_ablate" keys ("mlp_ablate", "ab_ablate", "conv_ablate", "conv_halo_ablate") switch off parts of a kernel for timing and
  * DO produce wrong results.  Guarded by a mutex; launches read the values at launch time. */

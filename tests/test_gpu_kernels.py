@@ -575,6 +575,75 @@ def test_attn_block_fused(opname, dt, code, S, nwin, use_tables, use_gamma, C):
 
 
 @pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("batch,G,use_add,use_gamma", [(86, 16, True, False), (5, 16, False, True), (33, 9, True, True), (2, 1, True, True)])
+def test_ct_block_fused(opname, dt, code, batch, G, use_add, use_gamma):
+    """The carrier-token branch of a HAT block in one kernel (gather + pos-embed, LN, qkv, attention over the image's G carrier tokens,
+    proj, residual, LN, fc1, GELU, fc2, residual; AR:679-683) vs PyTorch fp32 on 16-bit-rounded weights; G < 16 exercises the masked keys
+    and the unwritten padded rows."""
+    lib = _lib.lib()
+    C, heads, d, hid = 256, 8, 32, 1024
+    assert lib.fvit_ct_block_supported(C, heads, G, hid) == 1 and lib.fvit_ct_block_supported(C, heads, 17, hid) == 0 and \
+        lib.fvit_ct_block_supported(512, 16, 16, 2048) == 0
+    g = torch.Generator(device="cpu").manual_seed(batch * 17 + G)
+    rowsA = 4 * 53
+    X = (torch.randn(batch * rowsA, C, generator=g) * 1.3 + 0.2).cuda()
+    src_idx = torch.randperm(rowsA, generator=g)[:G].int().cuda()
+    add = torch.randn(G, C, generator=g).cuda() if use_add else None
+    ln1w, ln2w = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    ln1b, ln2b = (torch.randn(C, generator=g) * 0.2).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    wqkv = (torch.randn(3 * C, C, generator=g) / C ** 0.5).to(dt).cuda()
+    bqkv = (torch.randn(3 * C, generator=g) * 0.3).cuda()
+    wproj = (torch.randn(C, C, generator=g) / C ** 0.5).to(dt).cuda()
+    bproj = (torch.randn(C, generator=g) * 0.3).cuda()
+    w1 = (torch.randn(hid, C, generator=g) / C ** 0.5).to(dt).cuda()
+    b1 = (torch.randn(hid, generator=g) * 0.3).cuda()
+    w2 = (torch.randn(C, hid, generator=g) / hid ** 0.5).to(dt).cuda()
+    b2 = (torch.randn(C, generator=g) * 0.3).cuda()
+    g1 = (torch.rand(C, generator=g) + 0.5).cuda() if use_gamma else None
+    g2 = (torch.rand(C, generator=g) + 0.5).cuda() if use_gamma else None
+    bias = (torch.randn(heads, G, G, generator=g) * 2).cuda()
+    bp = torch.zeros(heads, 16, 16, device="cuda")
+    bp[:, :G, :G] = bias
+    bp[:, :, G:] = _lib.FVIT_MASK_BIAS
+    wqf = hat_runtime.frag_pack_qkv(wqkv.float(), heads).to(dt).contiguous()
+    bqh = bqkv.view(3, heads, 32).permute(1, 0, 2).reshape(heads, 96).contiguous()
+    wpf = hat_runtime.frag_pack_fc2(wproj.float()).to(dt).contiguous()
+    w1f = hat_runtime.frag_pack_fc1(w1.float()).to(dt).contiguous()
+    w2f = hat_runtime.frag_pack_fc2(w2.float()).to(dt).contiguous()
+    out = torch.full((batch * G + 3, C), float("nan"), device="cuda")
+    scale = d ** -0.5
+    p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    for variant in (0, 1, 2):
+        _lib.tune("ct_variant", variant)
+        out.fill_(float("nan"))
+        rc = lib.fvit_ct_block_fused(code, X.data_ptr(), rowsA, src_idx.data_ptr(), p(add), out.data_ptr(), batch, G, heads, C, hid,
+                                     ln1w.data_ptr(), ln1b.data_ptr(), wqf.data_ptr(), bqh.data_ptr(), wpf.data_ptr(), bproj.data_ptr(), p(g1),
+                                     bp.data_ptr(), ctypes.c_float(scale), ln2w.data_ptr(), ln2b.data_ptr(), w1f.data_ptr(), b1.data_ptr(),
+                                     w2f.data_ptr(), b2.data_ptr(), p(g2), ctypes.c_float(1e-5), _stream())
+        _lib.tune("ct_variant", 0)
+        _lib.check(rc, "ct_block_fused")
+        torch.cuda.synchronize()
+        ct = X.view(batch, rowsA, C)[:, src_idx.long()]
+        if use_add:
+            ct = ct + add[None]
+        xn = F.layer_norm(ct, (C,), ln1w, ln1b, 1e-5).to(dt).float()
+        qkv = (xn @ wqkv.float().t() + bqkv).view(batch, G, 3, heads, d).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0].to(dt).float(), qkv[1].to(dt).float(), qkv[2].to(dt).float()
+        att = ((q @ k.transpose(-1, -2)) * scale + bias).softmax(-1)
+        o = (att @ v).transpose(1, 2).reshape(batch, G, C).to(dt).float()
+        y = o @ wproj.float().t() + bproj
+        ct = ct + (g1 * y if use_gamma else y)
+        xn2 = F.layer_norm(ct, (C,), ln2w, ln2b, 1e-5).to(dt).float()
+        h = F.gelu(xn2 @ w1.float().t() + b1).to(dt).float()
+        y2 = h @ w2.float().t() + b2
+        ref = (ct + (g2 * y2 if use_gamma else y2)).reshape(batch * G, C)
+        got = out[:batch * G]
+        assert torch.isfinite(got).all() and torch.isnan(out[batch * G:]).all()
+        tol = (4e-3 if dt == torch.float16 else 3e-2) * ref.abs().max().item()
+        assert (got - ref).abs().max().item() < tol, f"variant {variant}: {(got - ref).abs().max().item()} vs {tol}"
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
 @pytest.mark.parametrize("M,C,N,act,gather", [(1360, 256, 768, 0, True), (1360, 256, 1024, 1, False), (4165, 512, 2048, 1, False),
                                                (4165, 512, 1536, 0, False), (77, 256, 48, 0, True), (300, 512, 272, 1, True)])
 def test_ln_gemm(opname, dt, code, M, C, N, act, gather):
