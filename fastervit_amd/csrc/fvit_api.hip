@@ -279,7 +279,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         bool ct_done = false;
         if (ctblk_supported(d.C, d.heads, L.G, d.hidden) && d.dpad == 32 && w.hat_attn.w_qkv_frag && w.hat_attn.b_qkv_heads && w.hat_attn.w_proj_frag &&
             w.hat_attn.bias && w.hat_mlp.w_fc1_frag && w.hat_mlp.w_fc2_frag && tune_get("ct_fused", 1)) {
-            // the whole carrier-token branch (AR:679-683) in one kernel, one workgroup per image
+            // the whole carrier-token branch (AR:679-686) in one kernel, one workgroup per image
             CtBlkCall cb = {dt, X, rpi, t.ct_src, (d.square ? w.pe_ct : nullptr), R, d.batch, L.G, d.heads, d.C, d.hidden,
                             w.hat_attn.ln_w, w.hat_attn.ln_b, w.hat_attn.w_qkv_frag, w.hat_attn.b_qkv_heads, w.hat_attn.w_proj_frag, w.hat_attn.b_proj,
                             w.hat_attn.gamma, w.hat_attn.bias, scale, w.hat_mlp.ln_w, w.hat_mlp.ln_b, w.hat_mlp.w_fc1_frag, w.hat_mlp.b_fc1,
@@ -299,7 +299,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
             LnCall ln = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), R, Rn, L.ldn,
                          w.hat_attn.ln_w, w.hat_attn.ln_b, 1e-5f, (int)L.Mc, L.G, d.C};
             if (use_ln_gemm(d, L.ldqkv, L.ldn, L.ldqkv, L.Mc)) {
-                // ct_dewindow gather + hat_pos_embed + hat_norm1 + hat_attn.qkv in one kernel (AR:679-683); R (the fp32 carrier stream)
+                // ct_dewindow gather + hat_pos_embed + hat_norm1 + hat_attn.qkv in one kernel (AR:679-686); R (the fp32 carrier stream)
                 // is written by the kernel's first column group
                 LnGemmCall lg = {ln, w.hat_attn.w_qkv, L.ldn, w.hat_attn.b_qkv, RQKV, L.ldqkv, L.ldqkv, 0};
                 FVIT_TRY(launch_ln_gemm(lg, st));

@@ -1,8 +1,8 @@
 // fvit_ctblk.hip -- the whole carrier-token branch of one HAT block in ONE kernel (C = 256, 8 heads of 32, hidden 1024, <= 16 carrier
 // tokens per image: stage 2 of FasterViT-0), gfx950:
 //
-//   ct  = ct_dewindow(carrier rows of X) (+ hat_pos_embed)                         (AR:679-681)
-//   ct += gamma1 * hat_attn(hat_norm1(ct));  ct += gamma2 * hat_mlp(hat_norm2(ct)) (AR:682-683)   -> R [B * G][C] fp32
+//   ct  = ct_dewindow(carrier rows of X) (+ hat_pos_embed)                         (AR:679-682)
+//   ct += gamma1 * hat_attn(hat_norm1(ct));  ct += gamma2 * hat_mlp(hat_norm2(ct)) (AR:685-686)   -> R [B * G][C] fp32
 //
 // Unfused this is gather-LayerNorm, qkv GEMM, attention, proj GEMM, LayerNorm, fc1 GEMM, fc2 GEMM on 1360 rows per stream shard: seven
 // launches of 42-176 workgroups that each run a K loop of dependent LDS-DMA round trips (9-19 us each, 61 us per block, 0.04-0.05 of

@@ -246,7 +246,7 @@ int fvit_ln_gemm(int32_t operand_dtype, const float* srcA, int32_t rowsA, const 
                  int32_t rows_per_image, int32_t C, const void* Wt, int32_t ldw, const float* bias, void* out, int32_t ldo, int32_t N,
                  int32_t act, fvit_stream_t stream);
 
-/* The whole carrier-token branch of one HAT block in one kernel (AR:679-683), one workgroup per image:
+/* The whole carrier-token branch of one HAT block in one kernel (AR:679-686), one workgroup per image:
  *   ct[b][i] = X[b * rowsA + src_idx[i]] (+ add[i]);  ct += gamma1 * attn(LayerNorm1(ct));  ct += gamma2 * mlp(LayerNorm2(ct))  -> R [batch * G][C]
  * attention over the G <= 16 carrier tokens of an image (bias f32 [heads][16][16], mask on padded keys), weights in the fragment-major
  * packings of fvit_attn_block_fused / fvit_mlp_fused.  Needs C == 256, heads == 8, hidden == 1024 (fvit_ct_block_supported).  gamma1 /

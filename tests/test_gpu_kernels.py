@@ -578,7 +578,7 @@ def test_attn_block_fused(opname, dt, code, S, nwin, use_tables, use_gamma, C):
 @pytest.mark.parametrize("batch,G,use_add,use_gamma", [(86, 16, True, False), (5, 16, False, True), (33, 9, True, True), (2, 1, True, True)])
 def test_ct_block_fused(opname, dt, code, batch, G, use_add, use_gamma):
     """The carrier-token branch of a HAT block in one kernel (gather + pos-embed, LN, qkv, attention over the image's G carrier tokens,
-    proj, residual, LN, fc1, GELU, fc2, residual; AR:679-683) vs PyTorch fp32 on 16-bit-rounded weights; G < 16 exercises the masked keys
+    proj, residual, LN, fc1, GELU, fc2, residual; AR:679-686) vs PyTorch fp32 on 16-bit-rounded weights; G < 16 exercises the masked keys
     and the unwritten padded rows."""
     lib = _lib.lib()
     C, heads, d, hid = 256, 8, 32, 1024
