@@ -1,10 +1,11 @@
 """End-to-end parity on an MI355X: HIP HAT path vs the reference's golden vectors and the CPU oracle.
 
-Tolerances (stated per north_star "logits max-abs < 1e-3"):
-  * fp16 MFMA operands, fp32 accumulate / residual / LayerNorm / softmax (the default):
-      logits max-abs error < 1e-3 on the 'init'-family fixtures of the BASELINE configs, with the conv
-      side in fp32, and per-block relative error < 5e-3 on the 'stress' fixtures.
-  * bf16 operands: ~8x looser (8 vs 11 mantissa bits); reported, asserted at 1e-2 / 4e-2.
+Tolerances (stated per north_star "logits max-abs < 1e-3"; r02: tightened to the measured margins):
+  * fp16 MFMA operands, fp32 accumulate / residual / LayerNorm / softmax (the default): logits max-abs error < 1e-3 for FasterViT-0
+    (|logits| <= 1.2) in module mode (conv side fp32), in deploy mode (own fp16 conv kernels), under autocast (automatic plan) and with
+    stream shards; relative error < 1.5e-3 for the variants whose logits reach 5-9 (FasterViT-4, any-res, tiny fixtures); stage maps and
+    the 'stress' fixtures relative < 1e-3 (stages) / 5e-3 (per block, logits).
+  * bf16 operands: 8 mantissa bits per operand, measured 3.3e-3 on FasterViT-0: asserted < 5e-3, does NOT meet the bar.
 """
 import numpy as np
 import pytest
@@ -100,7 +101,8 @@ def test_fvit0_224_channels_last_and_autocast():
         plain = model(x).float().cpu()                                           # plain nn.Module path (MIOpen convs under autocast)
     err, err_plain = max_abs(logits, g["logits"]), max_abs(plain, g["logits"])
     print(f"faster_vit_0_224 autocast-fp16 + channels_last logits max-abs err {err:.3e} (auto deploy plan), {err_plain:.3e} (module path)")
-    assert err < 4e-3 and err_plain < 4e-3
+    # the automatic plan (own fp16 conv kernels) meets the north-star bar; the plain module path's fp16 convolutions are MIOpen's (1.1e-3)
+    assert err < 1e-3 and err_plain < 2e-3
     # outside autocast, with grad enabled, or in train mode nothing is switched automatically
     model.auto_deploy = True
     assert model._autocast_plan(x) is None
@@ -123,7 +125,7 @@ def test_fvit0_224_stage_maps_vs_reference():
             lvl.downsample = ds
             e = rel_err(out, g[f"level{li}_out"])
             print(f"{case} level {li} stage rel err {e:.3e}")
-            assert e < (2e-3 if case == "fvit0_224" else 5e-3)
+            assert e < 1e-3   # measured 2.3e-4 ... 4.9e-4
 
 
 def test_fvit0_224_stress_logits():
@@ -144,7 +146,7 @@ def test_fvit0_224_bf16_operands():
         logits = model(case_input("fvit0_224").cuda()).float().cpu()
     err = max_abs(logits, g["logits"])
     print(f"faster_vit_0_224 bf16-operand logits max-abs err {err:.3e}")
-    assert err < 1e-2
+    assert err < 5e-3   # 8 mantissa bits per operand: does not meet the 1e-3 bar; measured 3.3e-3
 
 
 def test_fvit4_224_logits_vs_reference():
@@ -247,7 +249,7 @@ def test_oracle_on_gpu_box_matches_goldens():
     assert max_abs(logits, g["logits"]) < 2e-4 * np.abs(g["logits"]).max()
 
 
-@pytest.mark.parametrize("name,tol", [("fvit0_224", 4e-3), ("tiny_hier", None), ("tiny_anyres", None), ("tiny_w14", None),
+@pytest.mark.parametrize("name,tol", [("fvit0_224", 1e-3), ("tiny_hier", None), ("tiny_anyres", None), ("tiny_w14", None),
                                       ("tiny_21k_384", None), ("tiny_anyres_w16", None), ("tiny_d80", None), ("fvit4_224", None)])
 def test_deploy_mode_vs_reference(name, tol):
     """switch_to_deploy(): BN folded into the convs, fp16 channels_last conv side, fused glue kernels."""
@@ -258,7 +260,8 @@ def test_deploy_mode_vs_reference(name, tol):
         logits = model(case_input(name).cuda()).float().cpu()
     err, rel = max_abs(logits, g["logits"]), rel_err(logits, g["logits"])
     print(f"{name} deploy-mode (fp16 conv side) logits max-abs err {err:.3e}, relative {rel:.3e}")
-    assert (err < tol) if tol is not None else (rel < 1e-2)
+    # absolute 1e-3 for FasterViT-0 (|logits| <= 1.2); relative 1.5e-3 for the variants whose logits reach 5-9 (measured 5.1e-4 ... 8.2e-4)
+    assert (err < tol) if tol is not None else (rel < 1.5e-3)
     # a weight update is picked up (plan is rebuilt from the new parameter versions)
     with torch.no_grad():
         model.head.bias.add_(1.0)
@@ -285,7 +288,7 @@ def test_deploy_mode_stream_shards(streams):
         y = model(x).float()
         y2 = model(x).float()
     assert max_abs(y.cpu(), ref.cpu()) < 2e-4 and torch.equal(y, y2)
-    assert max_abs(y.cpu(), g["logits"]) < 4e-3
+    assert max_abs(y.cpu(), g["logits"]) < 1e-3
     # capturable: fork / join of the side streams inside one graph
     static_x = x.clone()
     side = torch.cuda.Stream()
