@@ -203,11 +203,15 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
 #pragma unroll
         for (int ub = 0; ub < 6; ++ub) {
             const int t = hh * 8 + ub;
-            f4 a = (f4){0.f, 0.f, 0.f, 0.f};
+            // two independent accumulator chains (even / odd k steps): eight dependent MFMAs would wait 32 cycles each on the previous one
+            f4 a = (f4){0.f, 0.f, 0.f, 0.f}, ao = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
+            for (int kk = 0; kk < KK; kk += 2) {
                 a = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a)     // q0 q1 k0 k1: weights are the A operand -> D[dim][token]
                            : Op16<T>::mfma(xf[kk], ring[t % DEPTH][kk], a);    // v0 v1: activations are A -> D[token][dim]
+                ao = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[kk + 1], ao) : Op16<T>::mfma(xf[kk + 1], ring[t % DEPTH][kk + 1], ao);
+            }
+            a += ao;
             __builtin_amdgcn_sched_barrier(0);
             FVIT_CT_LOAD(t + DEPTH)
             // the accumulator becomes an operand fragment at once (keeps 4 instead of 24 accumulator registers alive)
@@ -318,10 +322,13 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             const int t = 16 + 4 * c + hb;
-            f4 a = (f4){0.f, 0.f, 0.f, 0.f};
+            f4 a = (f4){0.f, 0.f, 0.f, 0.f}, ao = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) a = Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a);
-            a1[hb] = a;
+            for (int kk = 0; kk < KK; kk += 2) {
+                a = Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a);
+                ao = Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[kk + 1], ao);
+            }
+            a1[hb] = a + ao;
             __builtin_amdgcn_sched_barrier(0);
             FVIT_CT_LOAD(t + DEPTH)
         }
