@@ -255,8 +255,13 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
 // Local-only stages (no carrier tokens: stage 3 of FasterViT-0) with the LayerNorm-in-GEMM kernels: the in-place `x = x + pos_embed`
 // of block i + 1 (AR:671) is applied by block i's fc2 epilogue, so block i + 1's norm1 is a plain LayerNorm of X and folds into its
 // qkv GEMM.  Same two fp32 additions in the same order as the separate kernel (bitwise the same residual stream).
+// C = 512 (stage 3 of FasterViT-0): the attention sub-block with the waves of a window splitting heads / output channels (fvit_winblk.hip)
+static bool win_fused_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S) {
+    return winblk_supported(d.C, d.heads, S) && d.dpad == 32 && w.w_qkv_frag && w.b_qkv_heads && w.w_proj_frag && w.bias && tune_get("win_fused", 1);
+}
+
 static bool pe_preadd_chain(const FvitStageDesc& d, const StageLayout& L, const FvitBlockWeights& w) {
-    return !d.hier && use_ln_gemm(d, L.ldqkv, L.ldn, L.ldqkv, L.Mx) && !fused_attn_ok(d, w.attn, L.S, L.Mx) && !mlp_takes_fused_kernel(d, w.mlp, L.Mx) &&
+    return !d.hier && !win_fused_ok(d, w.attn, L.S) && use_ln_gemm(d, L.ldqkv, L.ldn, L.ldqkv, L.Mx) && !fused_attn_ok(d, w.attn, L.S, L.Mx) && !mlp_takes_fused_kernel(d, w.mlp, L.Mx) &&
            tune_get("pe_preadd", 1);
 }
 
@@ -312,7 +317,15 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         }
         if (!ct_done) FVIT_TRY(run_mlp(d, L, w.hat_mlp, R, L.Mc, Rn, RH, st));
     }
-    if (fused_attn_ok(d, w.attn, L.S, L.Mx)) {
+    if (win_fused_ok(d, w.attn, L.S)) {
+        // C = 512 (stage 3 of FasterViT-0): the same sub-block with the waves of a window splitting heads / output channels
+        const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
+        AttnBlkCall ab = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, w.attn.ln_w, w.attn.ln_b, 1e-5f, rpi,
+                          w.attn.w_qkv_frag, w.attn.b_qkv_heads, w.attn.w_proj_frag, w.attn.b_proj, w.attn.gamma, w.attn.bias, X,
+                          d.batch * L.nW, L.S, d.heads, d.C, scale};
+        FVIT_TRY(launch_winblk(ab, st));
+        dbg_rowhash("win.winblk", X, L.Mx, d.C * 4, st);
+    } else if (fused_attn_ok(d, w.attn, L.S, L.Mx)) {
         // cat(ct_window(ct), x + pos_embed) gather, LN(norm1), qkv, window attention, proj, gamma3-residual -> X, one kernel
         const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
         AttnBlkCall ab = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, w.attn.ln_w, w.attn.ln_b, 1e-5f, rpi,
@@ -530,6 +543,18 @@ int fvit_attn_block_fused(int32_t operand_dtype, const float* srcA, int32_t rows
     AttnBlkCall ab = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, ln_w, ln_b, eps, rows_per_image, w_qkv_frag,
                       b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
     return launch_attnblk(ab, (hipStream_t)stream);
+}
+
+int fvit_win_block_supported(int32_t C, int32_t heads, int32_t S) { return winblk_supported(C, heads, S) ? 1 : 0; }
+
+int fvit_win_block_fused(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                         const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
+                         int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
+                         const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
+                         int32_t heads, int32_t C, float scale, fvit_stream_t stream) {
+    AttnBlkCall ab = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, ln_w, ln_b, eps, rows_per_image, w_qkv_frag,
+                      b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
+    return launch_winblk(ab, (hipStream_t)stream);
 }
 
 int fvit_ct_block_supported(int32_t C, int32_t heads, int32_t G, int32_t hidden) { return ctblk_supported(C, heads, G, hidden) ? 1 : 0; }

@@ -222,6 +222,9 @@ struct AttnBlkCall {
 };
 bool attnblk_supported(int C, int heads, int S);
 int launch_attnblk(const AttnBlkCall& c, hipStream_t stream);
+// same contract for C = 512 / 16 heads, one 49..64-token window per workgroup, waves split heads / output channels (fvit_winblk.hip)
+bool winblk_supported(int C, int heads, int S);
+int launch_winblk(const AttnBlkCall& c, hipStream_t stream);
 
 struct AttnCall {
     int dtype;

@@ -16,7 +16,7 @@ bs = int(sys.argv[2]) if len(sys.argv) > 2 else 86
 torch.manual_seed(0)
 model = fastervit_amd.create_model("faster_vit_0_224").eval().cuda()
 g = torch.Generator(device="cpu").manual_seed(5)
-for li, R, C in ((2, 14, 256),):
+for li, R, C in ((2, 14, 256), (3, 7, 512)):
     lvl = model.levels[li]
     x = torch.randn(bs, C, R, R, generator=g).cuda().half().contiguous(memory_format=torch.channels_last)
     ref = None

@@ -548,13 +548,19 @@ def test_attn_block_fused(opname, dt, code, S, nwin, use_tables, use_gamma, C):
     wpf = hat_runtime.frag_pack_fc2(wproj.float()).to(dt).contiguous()
     out = torch.full((rows, C), float("nan"), device="cuda")
     scale = d ** -0.5
-    rc = lib.fvit_attn_block_fused(code, X.data_ptr(), rpi, R.data_ptr(), 7, src_idx.data_ptr() if use_tables else None,
-                                   add_idx.data_ptr() if use_tables else None, add.data_ptr() if use_tables else None, lnw.data_ptr(),
-                                   lnb.data_ptr(), ctypes.c_float(1e-5), rpi, wqf.data_ptr(), bqh.data_ptr(), wpf.data_ptr(), bproj.data_ptr(),
-                                   gamma.data_ptr() if use_gamma else None, bp.data_ptr(), out.data_ptr(), nwin, S, heads, C,
-                                   ctypes.c_float(scale), _stream())
+    args = (code, X.data_ptr(), rpi, R.data_ptr(), 7, src_idx.data_ptr() if use_tables else None,
+            add_idx.data_ptr() if use_tables else None, add.data_ptr() if use_tables else None, lnw.data_ptr(),
+            lnb.data_ptr(), ctypes.c_float(1e-5), rpi, wqf.data_ptr(), bqh.data_ptr(), wpf.data_ptr(), bproj.data_ptr(),
+            gamma.data_ptr() if use_gamma else None, bp.data_ptr())
+    rc = lib.fvit_attn_block_fused(*args, out.data_ptr(), nwin, S, heads, C, ctypes.c_float(scale), _stream())
     _lib.check(rc, "attn_block_fused")
     torch.cuda.synchronize()
+    out_win = None
+    assert lib.fvit_win_block_supported(C, heads, S) == (1 if C == 512 else 0)
+    if C == 512:   # the same contract with the N-split work split (fvit_winblk.hip)
+        out_win = torch.full((rows, C), float("nan"), device="cuda")
+        _lib.check(lib.fvit_win_block_fused(*args, out_win.data_ptr(), nwin, S, heads, C, ctypes.c_float(scale), _stream()), "win_block_fused")
+        torch.cuda.synchronize()
     # reference
     xin = X.view(nimg, rpi, C).clone()
     if use_tables:
@@ -572,6 +578,9 @@ def test_attn_block_fused(opname, dt, code, S, nwin, use_tables, use_gamma, C):
     assert torch.isfinite(out).all()
     tol = (4e-3 if dt == torch.float16 else 3e-2) * ref.abs().max().item()
     assert (out - ref).abs().max().item() < tol
+    if out_win is not None:
+        assert torch.isfinite(out_win).all()
+        assert (out_win - ref).abs().max().item() < tol, f"win_block: {(out_win - ref).abs().max().item()} vs {tol}"
 
 
 @pytest.mark.parametrize("opname,dt,code", OPS)
