@@ -214,6 +214,10 @@ struct NextPe {   // position-embedding rows of the NEXT block, applied in this 
     int rows_per_image = 1;
 };
 
+static bool win_mlp_ok(const FvitStageDesc& d, const FvitMlpWeights& w) {
+    return winmlp_supported(d.C, d.hidden) && w.w_fc1_frag && w.w_fc2_frag && tune_get("win_mlp", 1);
+}
+
 static bool mlp_takes_fused_kernel(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t rows) {
     const int64_t fused_min = d.C == 256 ? tune_get("mlp_fused_min_rows", 16384) : tune_get("mlp_fused512_min_rows", 1 << 30);
     return w.w_fc1_frag && w.w_fc2_frag && mlp_fused_supported(d.C, d.hidden) && rows >= fused_min && tune_get("mlp_fused", 1);
@@ -226,6 +230,14 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
     // (>= ~16k rows; 104 vs 137 us at 54k rows) and loses on the latency-bound carrier branch (4k rows: 83 vs 31 us)
     // C = 512 (stage 3): the fused instance is correct but slower than LN + 2 GEMMs at these row counts (65-196 workgroups, each
     // streaming 4 MiB of weights: 65.8k vs 71.0k images/s end to end, r01 sweep r31) => opt-in
+    if (win_mlp_ok(d, w)) {
+        // C = 512 (stage 3 of FasterViT-0): 64-row workgroups whose waves split hidden units / output channels (fvit_winmlp.hip)
+        if (next_pe && next_pe->add) { set_error("internal: position-embedding pre-add requested on the fused MLP path"); return FVIT_EINVAL; }
+        MlpFusedCall mc = {dt, x, (int)rows, d.C, d.hidden, w.ln_w, w.ln_b, 1e-5f, w.w_fc1_frag, w.b_fc1, w.w_fc2_frag, w.b_fc2, w.gamma};
+        FVIT_TRY(launch_winmlp(mc, st));
+        dbg_rowhash("winmlp.out", x, rows, d.C * 4, st);
+        return FVIT_OK;
+    }
     if (mlp_takes_fused_kernel(d, w, rows)) {
         if (next_pe && next_pe->add) { set_error("internal: position-embedding pre-add requested on the fused MLP path"); return FVIT_EINVAL; }
         MlpFusedCall mc = {dt, x, (int)rows, d.C, d.hidden, w.ln_w, w.ln_b, 1e-5f, w.w_fc1_frag, w.b_fc1, w.w_fc2_frag, w.b_fc2, w.gamma};
@@ -261,7 +273,7 @@ static bool win_fused_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S
 }
 
 static bool pe_preadd_chain(const FvitStageDesc& d, const StageLayout& L, const FvitBlockWeights& w) {
-    return !d.hier && !win_fused_ok(d, w.attn, L.S) && use_ln_gemm(d, L.ldqkv, L.ldn, L.ldqkv, L.Mx) && !fused_attn_ok(d, w.attn, L.S, L.Mx) && !mlp_takes_fused_kernel(d, w.mlp, L.Mx) &&
+    return !d.hier && !win_fused_ok(d, w.attn, L.S) && !win_mlp_ok(d, w.mlp) && use_ln_gemm(d, L.ldqkv, L.ldn, L.ldqkv, L.Mx) && !fused_attn_ok(d, w.attn, L.S, L.Mx) && !mlp_takes_fused_kernel(d, w.mlp, L.Mx) &&
            tune_get("pe_preadd", 1);
 }
 
@@ -543,6 +555,15 @@ int fvit_attn_block_fused(int32_t operand_dtype, const float* srcA, int32_t rows
     AttnBlkCall ab = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, ln_w, ln_b, eps, rows_per_image, w_qkv_frag,
                       b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
     return launch_attnblk(ab, (hipStream_t)stream);
+}
+
+int fvit_win_mlp_supported(int32_t C, int32_t hidden) { return winmlp_supported(C, hidden) ? 1 : 0; }
+
+int fvit_win_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,
+                       float eps, const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2,
+                       const float* gamma, fvit_stream_t stream) {
+    MlpFusedCall mc = {operand_dtype, x, M, C, hidden, ln_w, ln_b, eps, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma};
+    return launch_winmlp(mc, (hipStream_t)stream);
 }
 
 int fvit_win_block_supported(int32_t C, int32_t heads, int32_t S) { return winblk_supported(C, heads, S) ? 1 : 0; }

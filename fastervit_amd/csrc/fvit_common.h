@@ -194,6 +194,9 @@ struct MlpFusedCall {
 };
 bool mlp_fused_supported(int C, int hidden);
 int launch_mlp_fused(const MlpFusedCall& c, hipStream_t stream);
+// same contract for C = 512 / hidden 2048: 64-row workgroups whose 8 waves split hidden units / output channels (fvit_winmlp.hip)
+bool winmlp_supported(int C, int hidden);
+int launch_winmlp(const MlpFusedCall& c, hipStream_t stream);
 
 struct AttnBlkCall {
     int dtype;

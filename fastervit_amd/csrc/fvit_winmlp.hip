@@ -1,0 +1,236 @@
+// fvit_winmlp.hip -- MLP sub-block of a HAT block for C = 512, hidden 2048 (stage 3 of FasterViT-0) with the waves of a 64-row workgroup
+// splitting the N dimension (gfx950):
+//
+//   x += gamma * fc2( GELU( fc1( LayerNorm(x) ) ) )                                   (AR:697 with AR:398-407)
+//
+// Same contract as fvit_mlp_fused.  The per-row-block form of that kernel (fvit_mlp.hip: every wave 16 rows, ALL 4 MiB of weights through
+// LDS per 64 rows in lockstep) loses at this shape; unfused it is LayerNorm + fc1 GEMM + fc2 GEMM, three chip-wide launches per block and
+// stream shard.  Here (the work split of fvit_ctblk.hip / fvit_winblk.hip): a workgroup of 8 waves owns 64 rows = 4 row blocks.
+//   A  LayerNorm of the 64 rows into MFMA B-operand fragments in LDS (XN[rb][kk], 64 KiB).
+//   per super-chunk of 256 hidden units (8 of them):
+//   B  wave w computes the 32 units of chunk 8 sc + w for ALL four row blocks (W1 slice straight from L2 through a register ring),
+//      applies bias + GELU and publishes the four H^T fragments in LDS (H[buf][w][rb], double-buffered: one barrier per super-chunk);
+//   C  wave w accumulates output channels 64w .. 64w + 63 for all rows over the 8 chunks of the super-chunk (its W2 slice through the ring,
+//      the H^T fragments of all waves from LDS).
+// Every weight fragment is read from L2 exactly once per workgroup and feeds four MFMAs; the hidden activation never leaves the CU.
+//
+// Measured (FasterViT-0 stage 3, 4 214 rows = 66 workgroups, r02 call r4a): the stage-3 forward ALONE gets slower (547 -> 622 us: 4 MiB of
+// cold weights per workgroup at the ~65 GB/s a CU pulls from the memory side), but the step gets faster: 71.9k -> 76.3k images/s (+6.1 %).
+// 66 CUs for ~75 us instead of the whole chip for LayerNorm + two GEMMs leave the other two stream shards the rest of the GPU.
+// On by default (fvit_tune "win_mlp").
+#include "fvit_common.h"
+
+namespace fvit {
+
+namespace {
+
+struct WinMlpParams {
+    float* x;            // [M][C] fp32 residual stream, updated in place
+    const float* ln_w;
+    const float* ln_b;
+    const void* w1f;     // op16 [hidden/32][2][C/32][64][8]
+    const float* b1;
+    const void* w2f;     // op16 [hidden/32][C/16][64][8]
+    const float* b2;
+    const float* gamma;  // [C] or null
+    float eps;
+    int M;
+};
+
+template <typename T, int DEPTH>
+__global__ __launch_bounds__(512, 1) void winmlp_kernel(WinMlpParams p) {
+    typedef typename Op16<T>::v8 v8;
+    constexpr int C = 512, KK = 16, CB = 32, HID = 2048, NW = 8, NRB = 4;
+    constexpr int NSC = HID / 32 / NW;             // super-chunks: 8 chunks of 32 units each, one chunk per wave
+    static_assert(8 % DEPTH == 0, "ring slots must be static inside the super-chunk loop");   // per super-chunk 4 fc1 + 4 fc2 steps of 8 fragments
+    constexpr int OFF_H = NRB * KK * 1024;         // XN: 64 KiB; H: 2 x 32 KiB; fc1 bias: 8 KiB
+    constexpr int OFF_B1 = OFF_H + 2 * NW * NRB * 1024;
+    __shared__ __attribute__((aligned(16))) char smem[OFF_B1 + HID * 4];
+    float* b1s = (float*)(smem + OFF_B1);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, s = lane & 15;
+    const int lane16 = lane * 16;
+    const int row0 = blockIdx.x * 64;
+
+    const char* W1 = (const char*)p.w1f + lane16;
+    const char* W2 = (const char*)p.w2f + lane16;
+    v8 ring[DEPTH][8];
+    // step (sc, u) into ring slot `slot`; u and slot are compile-time at every call site (the super-chunk loop is not unrolled, a
+    // super-chunk is 8 steps and DEPTH divides 8, so the slot of step 8 sc + u is u % DEPTH)
+    auto issue = [&](int sc, int u, int slot) {
+        if (sc < NSC) {
+            if (u < 4) {      // fc1: chunk 8 sc + wave, k steps 4u .. 4u + 3, slot (kk - 4u) * 2 + hb
+                const char* b = W1 + (size_t)(sc * NW + wave) * 2 * KK * 1024;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ring[slot][i] = *(const v8*)(b + ((i & 1) * KK + 4 * u + (i >> 1)) * 1024);
+            } else {          // fc2: chunks 8 sc + 2 (u - 4) + {0, 1}, channel blocks 4 wave + q, slot c * 4 + q
+                const char* b = W2 + ((size_t)(sc * NW + 2 * (u - 4)) * CB + 4 * wave) * 1024;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ring[slot][i] = *(const v8*)(b + ((i >> 2) * CB + (i & 3)) * 1024);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    {   // fc1 bias to LDS (an ordinary load inside the loops would queue behind the ring's prefetches and drain it), then the first steps
+        float c1[HID / 512];
+#pragma unroll
+        for (int i = 0; i < HID / 512; ++i) c1[i] = p.b1[tid + 512 * i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < DEPTH; ++t) issue(0, t, t);
+#pragma unroll
+        for (int i = 0; i < HID / 512; ++i) b1s[tid + 512 * i] = c1[i];
+    }
+
+    // ---- phase A: LayerNorm; this wave writes k steps [8 * half, 8 * half + 8) of row block rb (both waves of a row block read the full rows) ----
+    {
+        const int rb = wave >> 1, half = wave & 1;
+        const int row = min(row0 + rb * 16 + s, p.M - 1);
+        const float* src = p.x + (size_t)row * C;
+        f4 v[2 * KK];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2 * KK; ++i) {
+            v[i] = *(const f4*)(src + (i >> 2) * 64 + g * 16 + (i & 3) * 4);   // i = 2 * kk + h2
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        sum = sum_xor32(sum_xor16(sum));
+        const float mean = sum / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2 * KK; ++i) {
+            const f4 d = v[i] - mean;
+            sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        sq = sum_xor32(sum_xor16(sq));
+        const float rstd = rsqrtf(sq / (float)C + p.eps);
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            v8 o;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f4 x0 = v[2 * k8 + h2], x1 = v[2 * (k8 + 8) + h2];
+                const int co = ((k8 + 8 * half) >> 1) * 64 + g * 16 + ((k8 + 8 * half) & 1) * 8 + h2 * 4;
+                const f4 w = *(const f4*)(p.ln_w + co);
+                const f4 bb = *(const f4*)(p.ln_b + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)(((half ? x1[r] : x0[r]) - mean) * rstd * w[r] + bb[r]);
+            }
+            *(v8*)(smem + ((rb * KK + k8 + 8 * half) * 1024) + lane16) = o;
+        }
+    }
+    __syncthreads();
+
+    const char* xn = smem + lane16;
+    f4 acc2[4][NRB];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc2[q][rb] = (f4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int sc = 0; sc < NSC; ++sc) {
+        // ---- B: H^T of chunk 8 sc + wave: [32 units][64 rows] ----
+        f4 acc1[2][NRB];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc1[hb][rb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                v8 xb[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) xb[rb] = *(const v8*)(xn + (rb * KK + 4 * u + k4) * 1024);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) acc1[hb][rb] = Op16<T>::mfma(ring[u % DEPTH][k4 * 2 + hb], xb[rb], acc1[hb][rb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue(u + DEPTH < 8 ? sc : sc + 1, (u + DEPTH) & 7, u % DEPTH);
+        }
+        const int j = sc * NW + wave;
+        const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
+        const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
+        char* hw = smem + OFF_H + ((sc & 1) * NW + wave) * NRB * 1024 + lane16;
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            v8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (T)gelu_fast(acc1[0][rb][r] + bA[r]);
+                pf[4 + r] = (T)gelu_fast(acc1[1][rb][r] + bB[r]);
+            }
+            *(v8*)(hw + rb * 1024) = pf;
+        }
+        __syncthreads();   // H of this super-chunk visible; the other buffer's last readers are past their fc2 of super-chunk sc - 1
+        // ---- C: out^T[channels 64w ..][rows] += W2[:, chunk] . H^T over the 8 chunks ----
+        const char* hr = smem + OFF_H + (sc & 1) * NW * NRB * 1024 + lane16;
+#pragma unroll
+        for (int u = 4; u < 8; ++u) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                v8 hb4[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) hb4[rb] = *(const v8*)(hr + ((2 * (u - 4) + c) * NRB + rb) * 1024);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) acc2[q][rb] = Op16<T>::mfma(ring[u % DEPTH][c * 4 + q], hb4[rb], acc2[q][rb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue(u + DEPTH < 8 ? sc : sc + 1, (u + DEPTH) & 7, u % DEPTH);
+        }
+    }
+
+    // ---- epilogue: x[row][c] += gamma * (out + b2); fragment (4w + q), slot 4g + r <-> channel 64w + 16g + 4q + r, row rb * 16 + s ----
+    const bool has_g = p.gamma != nullptr;
+    const int c0 = wave * 64 + g * 16;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+        const int row = row0 + rb * 16 + s;
+        if (row < p.M) {
+            float* px = p.x + (size_t)row * C + c0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f4 xv = *(const f4*)(px + q * 4);
+                const f4 bv = *(const f4*)(p.b2 + c0 + q * 4);
+                const f4 gl = *(const f4*)((has_g ? p.gamma : p.b2) + c0 + q * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xv[r] += (has_g ? gl[r] : 1.f) * (acc2[q][rb][r] + bv[r]);
+                *(f4*)(px + q * 4) = xv;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool winmlp_supported(int C, int hidden) { return C == 512 && hidden == 2048; }
+
+int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
+    if (!winmlp_supported(c.C, c.hidden) || c.M <= 0 || !c.x || !c.w1f || !c.w2f) {
+        set_error("win_mlp: unsupported arguments C=%d hidden=%d M=%d", c.C, c.hidden, c.M);
+        return FVIT_EINVAL;
+    }
+    WinMlpParams p;
+    p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma; p.eps = c.eps; p.M = c.M;
+    const double flops = 4.0 * c.M * (double)c.C * c.hidden;
+    const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
+    ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
+    const int grid = (c.M + 63) / 64;
+    prof_note("winmlp_kernel<512>", grid);
+    // ring depth 2: every slot index t % 2 is static inside the (not unrolled) super-chunk loop because a super-chunk is 8 steps
+    if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 2>), dim3(grid), dim3(512), 0, stream, p);
+    else if (c.dtype == FVIT_BF16) hipLaunchKernelGGL((winmlp_kernel<__bf16, 2>), dim3(grid), dim3(512), 0, stream, p);
+    else { set_error("win_mlp: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
+    return check_launch("winmlp_kernel");
+}
+
+}  // namespace fvit

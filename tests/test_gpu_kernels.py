@@ -322,6 +322,15 @@ def test_mlp_fused(opname, dt, code, M, use_gamma, C):
     tol = (3e-3 if dt == torch.float16 else 2e-2) * ref.abs().max().item()
     assert torch.isfinite(x).all()
     assert (x - ref).abs().max().item() < tol
+    assert lib.fvit_win_mlp_supported(C, hid) == (1 if C == 512 else 0)
+    if C == 512:   # the same contract with the N-split work split (fvit_winmlp.hip)
+        xw = torch.cat([x0, torch.full((5, C), float("nan"), device="cuda")])   # rows beyond M stay untouched
+        _lib.check(lib.fvit_win_mlp_fused(code, xw.data_ptr(), M, C, hid, lnw.data_ptr(), lnb.data_ptr(), ctypes.c_float(1e-5), w1p.data_ptr(),
+                                          b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(), gamma.data_ptr() if use_gamma else None, _stream()),
+                   "win_mlp_fused")
+        torch.cuda.synchronize()
+        assert torch.isfinite(xw[:M]).all() and torch.isnan(xw[M:]).all()
+        assert (xw[:M] - ref).abs().max().item() < tol, f"win_mlp: {(xw[:M] - ref).abs().max().item()} vs {tol}"
 
 
 @pytest.mark.parametrize("C,Cv", [(256, 196), (448, 392), (64, 16), (128, 80)])
