@@ -214,8 +214,10 @@ struct NextPe {   // position-embedding rows of the NEXT block, applied in this 
     int rows_per_image = 1;
 };
 
-static bool win_mlp_ok(const FvitStageDesc& d, const FvitMlpWeights& w) {
-    return winmlp_supported(d.C, d.hidden) && w.w_fc1_frag && w.w_fc2_frag && tune_get("win_mlp", 1);
+static bool win_mlp_ok(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t rows) {
+    if (!winmlp_supported(d.C, d.hidden) || !w.w_fc1_frag || !w.w_fc2_frag) return false;
+    if (d.C == 512) return tune_get("win_mlp", 1) != 0;
+    return rows >= tune_get("mlp_fused_min_rows", 16384) && tune_get("win_mlp256", 0) != 0;   // C = 256: 128-row workgroups
 }
 
 static bool mlp_takes_fused_kernel(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t rows) {
@@ -230,7 +232,7 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
     // (>= ~16k rows; 104 vs 137 us at 54k rows) and loses on the latency-bound carrier branch (4k rows: 83 vs 31 us)
     // C = 512 (stage 3): the fused instance is correct but slower than LN + 2 GEMMs at these row counts (65-196 workgroups, each
     // streaming 4 MiB of weights: 65.8k vs 71.0k images/s end to end, r01 sweep r31) => opt-in
-    if (win_mlp_ok(d, w)) {
+    if (win_mlp_ok(d, w, rows)) {
         // C = 512 (stage 3 of FasterViT-0): 64-row workgroups whose waves split hidden units / output channels (fvit_winmlp.hip)
         if (next_pe && next_pe->add) { set_error("internal: position-embedding pre-add requested on the fused MLP path"); return FVIT_EINVAL; }
         MlpFusedCall mc = {dt, x, (int)rows, d.C, d.hidden, w.ln_w, w.ln_b, 1e-5f, w.w_fc1_frag, w.b_fc1, w.w_fc2_frag, w.b_fc2, w.gamma};
@@ -273,7 +275,7 @@ static bool win_fused_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S
 }
 
 static bool pe_preadd_chain(const FvitStageDesc& d, const StageLayout& L, const FvitBlockWeights& w) {
-    return !d.hier && !win_fused_ok(d, w.attn, L.S) && !win_mlp_ok(d, w.mlp) && use_ln_gemm(d, L.ldqkv, L.ldn, L.ldqkv, L.Mx) && !fused_attn_ok(d, w.attn, L.S, L.Mx) && !mlp_takes_fused_kernel(d, w.mlp, L.Mx) &&
+    return !d.hier && !win_fused_ok(d, w.attn, L.S) && !win_mlp_ok(d, w.mlp, L.Mx) && use_ln_gemm(d, L.ldqkv, L.ldn, L.ldqkv, L.Mx) && !fused_attn_ok(d, w.attn, L.S, L.Mx) && !mlp_takes_fused_kernel(d, w.mlp, L.Mx) &&
            tune_get("pe_preadd", 1);
 }
 

@@ -18,6 +18,9 @@
 // cold weights per workgroup at the ~65 GB/s a CU pulls from the memory side), but the step gets faster: 71.9k -> 76.3k images/s (+6.1 %).
 // 66 CUs for ~75 us instead of the whole chip for LayerNorm + two GEMMs leave the other two stream shards the rest of the GPU.
 // On by default (fvit_tune "win_mlp").
+// The C = 256 / hidden 1024 instance (128-row workgroups, stage 2: 143 workgroups per shard instead of the 285 of mlp_fused_kernel) is
+// correct and tested but buys nothing there (774 vs 773 us per stage-2 forward, 78.7k vs 79.9k images/s, call r4c): 143 workgroups are not
+// narrow, and the 64-row kernel it would replace is not weight-bound.  Opt-in (fvit_tune "win_mlp256").
 #include "fvit_common.h"
 
 namespace fvit {
@@ -37,14 +40,22 @@ struct WinMlpParams {
     int M;
 };
 
-template <typename T, int DEPTH>
+// CC / HID: channels / hidden units; NRB: row blocks of 16 per workgroup (4: 64 rows, C = 512; 8: 128 rows, C = 256)
+template <typename T, int CC, int HID, int NRB, int DEPTH>
 __global__ __launch_bounds__(512, 1) void winmlp_kernel(WinMlpParams p) {
     typedef typename Op16<T>::v8 v8;
-    constexpr int C = 512, KK = 16, CB = 32, HID = 2048, NW = 8, NRB = 4;
+    constexpr int C = CC, KK = C / 32, CB = C / 16, NW = 8;
+    constexpr int CBW = CB / NW;                   // output channel blocks per wave (4 / 2)
     constexpr int NSC = HID / 32 / NW;             // super-chunks: 8 chunks of 32 units each, one chunk per wave
-    static_assert(8 % DEPTH == 0, "ring slots must be static inside the super-chunk loop");   // per super-chunk 4 fc1 + 4 fc2 steps of 8 fragments
-    constexpr int OFF_H = NRB * KK * 1024;         // XN: 64 KiB; H: 2 x 32 KiB; fc1 bias: 8 KiB
-    constexpr int OFF_B1 = OFF_H + 2 * NW * NRB * 1024;
+    constexpr int F1S = 2 * KK / 8;                // fc1 steps of 8 fragments per chunk: 4 k steps x 2 unit blocks each
+    constexpr int CPS = 8 / CBW;                   // chunks per fc2 step of 8 fragments
+    constexpr int F2S = NW / CPS;                  // fc2 steps per super-chunk
+    constexpr int SPS = F1S + F2S;                 // steps per super-chunk (8 / 4)
+    static_assert(SPS % DEPTH == 0, "ring slots must be static inside the super-chunk loop");
+    constexpr int WPR = NW / NRB;                  // waves sharing a row block in the LayerNorm phase (2 / 1)
+    constexpr int HBUF = (NRB * KK + 2 * NW * NRB) * 1024 + HID * 4 <= 150 * 1024 ? 2 : 1;   // H double-buffered when it fits
+    constexpr int OFF_H = NRB * KK * 1024;         // XN: 64 KiB; H: HBUF x NW x NRB KiB; fc1 bias
+    constexpr int OFF_B1 = OFF_H + HBUF * NW * NRB * 1024;
     __shared__ __attribute__((aligned(16))) char smem[OFF_B1 + HID * 4];
     float* b1s = (float*)(smem + OFF_B1);
 
@@ -53,23 +64,23 @@ __global__ __launch_bounds__(512, 1) void winmlp_kernel(WinMlpParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, s = lane & 15;
     const int lane16 = lane * 16;
-    const int row0 = blockIdx.x * 64;
+    const int row0 = blockIdx.x * (16 * NRB);
 
     const char* W1 = (const char*)p.w1f + lane16;
     const char* W2 = (const char*)p.w2f + lane16;
     v8 ring[DEPTH][8];
     // step (sc, u) into ring slot `slot`; u and slot are compile-time at every call site (the super-chunk loop is not unrolled, a
-    // super-chunk is 8 steps and DEPTH divides 8, so the slot of step 8 sc + u is u % DEPTH)
+    // super-chunk is SPS steps and DEPTH divides SPS, so the slot of step SPS sc + u is u % DEPTH)
     auto issue = [&](int sc, int u, int slot) {
         if (sc < NSC) {
-            if (u < 4) {      // fc1: chunk 8 sc + wave, k steps 4u .. 4u + 3, slot (kk - 4u) * 2 + hb
+            if (u < F1S) {    // fc1: chunk 8 sc + wave, k steps 4u .. 4u + 3, slot (kk - 4u) * 2 + hb
                 const char* b = W1 + (size_t)(sc * NW + wave) * 2 * KK * 1024;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ring[slot][i] = *(const v8*)(b + ((i & 1) * KK + 4 * u + (i >> 1)) * 1024);
-            } else {          // fc2: chunks 8 sc + 2 (u - 4) + {0, 1}, channel blocks 4 wave + q, slot c * 4 + q
-                const char* b = W2 + ((size_t)(sc * NW + 2 * (u - 4)) * CB + 4 * wave) * 1024;
+            } else {          // fc2: chunks 8 sc + CPS (u - F1S) + c, channel blocks CBW wave + q, slot c * CBW + q
+                const char* b = W2 + ((size_t)(sc * NW + CPS * (u - F1S)) * CB + CBW * wave) * 1024;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ring[slot][i] = *(const v8*)(b + ((i >> 2) * CB + (i & 3)) * 1024);
+                for (int i = 0; i < 8; ++i) ring[slot][i] = *(const v8*)(b + ((i / CBW) * CB + (i % CBW)) * 1024);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -86,9 +97,10 @@ __global__ __launch_bounds__(512, 1) void winmlp_kernel(WinMlpParams p) {
         for (int i = 0; i < HID / 512; ++i) b1s[tid + 512 * i] = c1[i];
     }
 
-    // ---- phase A: LayerNorm; this wave writes k steps [8 * half, 8 * half + 8) of row block rb (both waves of a row block read the full rows) ----
+    // ---- phase A: LayerNorm; WPR waves share a row block: each reads the full rows and writes KK / WPR of the k steps ----
     {
-        const int rb = wave >> 1, half = wave & 1;
+        constexpr int KP = KK / WPR;
+        const int rb = wave / WPR, part = wave % WPR;
         const int row = min(row0 + rb * 16 + s, p.M - 1);
         const float* src = p.x + (size_t)row * C;
         f4 v[2 * KK];
@@ -109,39 +121,43 @@ __global__ __launch_bounds__(512, 1) void winmlp_kernel(WinMlpParams p) {
         sq = sum_xor32(sum_xor16(sq));
         const float rstd = rsqrtf(sq / (float)C + p.eps);
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
+        for (int k8 = 0; k8 < KP; ++k8) {
             v8 o;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                const f4 x0 = v[2 * k8 + h2], x1 = v[2 * (k8 + 8) + h2];
-                const int co = ((k8 + 8 * half) >> 1) * 64 + g * 16 + ((k8 + 8 * half) & 1) * 8 + h2 * 4;
+                // wave-uniform choice of the part without dynamic register indexing
+                f4 xs = v[2 * k8 + h2];
+#pragma unroll
+                for (int pp = 1; pp < WPR; ++pp) xs = part == pp ? v[2 * (k8 + pp * KP) + h2] : xs;
+                const int kk = k8 + part * KP;
+                const int co = (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 + h2 * 4;
                 const f4 w = *(const f4*)(p.ln_w + co);
                 const f4 bb = *(const f4*)(p.ln_b + co);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)(((half ? x1[r] : x0[r]) - mean) * rstd * w[r] + bb[r]);
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)((xs[r] - mean) * rstd * w[r] + bb[r]);
             }
-            *(v8*)(smem + ((rb * KK + k8 + 8 * half) * 1024) + lane16) = o;
+            *(v8*)(smem + ((rb * KK + k8 + part * KP) * 1024) + lane16) = o;
         }
     }
     __syncthreads();
 
     const char* xn = smem + lane16;
-    f4 acc2[4][NRB];
+    f4 acc2[CBW][NRB];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < CBW; ++q)
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc2[q][rb] = (f4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
     for (int sc = 0; sc < NSC; ++sc) {
-        // ---- B: H^T of chunk 8 sc + wave: [32 units][64 rows] ----
+        // ---- B: H^T of chunk 8 sc + wave: [32 units][16 NRB rows] ----
         f4 acc1[2][NRB];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) acc1[hb][rb] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < F1S; ++u) {
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
                 v8 xb[NRB];
@@ -153,12 +169,13 @@ __global__ __launch_bounds__(512, 1) void winmlp_kernel(WinMlpParams p) {
                     for (int rb = 0; rb < NRB; ++rb) acc1[hb][rb] = Op16<T>::mfma(ring[u % DEPTH][k4 * 2 + hb], xb[rb], acc1[hb][rb]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            issue(u + DEPTH < 8 ? sc : sc + 1, (u + DEPTH) & 7, u % DEPTH);
+            issue(u + DEPTH < SPS ? sc : sc + 1, (u + DEPTH) % SPS, u % DEPTH);
         }
         const int j = sc * NW + wave;
         const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
         const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
-        char* hw = smem + OFF_H + ((sc & 1) * NW + wave) * NRB * 1024 + lane16;
+        const int hbuf = HBUF == 2 ? (sc & 1) : 0;
+        char* hw = smem + OFF_H + (hbuf * NW + wave) * NRB * 1024 + lane16;
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
             v8 pf;
@@ -169,42 +186,44 @@ __global__ __launch_bounds__(512, 1) void winmlp_kernel(WinMlpParams p) {
             }
             *(v8*)(hw + rb * 1024) = pf;
         }
-        __syncthreads();   // H of this super-chunk visible; the other buffer's last readers are past their fc2 of super-chunk sc - 1
-        // ---- C: out^T[channels 64w ..][rows] += W2[:, chunk] . H^T over the 8 chunks ----
-        const char* hr = smem + OFF_H + (sc & 1) * NW * NRB * 1024 + lane16;
+        __syncthreads();   // H of this super-chunk visible (HBUF = 2: the other buffer's last readers are past their fc2 of super-chunk sc - 1)
+        // ---- C: out^T[this wave's channels][rows] += W2[:, chunk] . H^T over the 8 chunks ----
+        const char* hr = smem + OFF_H + hbuf * NW * NRB * 1024 + lane16;
 #pragma unroll
-        for (int u = 4; u < 8; ++u) {
+        for (int u = F1S; u < SPS; ++u) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < CPS; ++c) {
                 v8 hb4[NRB];
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) hb4[rb] = *(const v8*)(hr + ((2 * (u - 4) + c) * NRB + rb) * 1024);
+                for (int rb = 0; rb < NRB; ++rb) hb4[rb] = *(const v8*)(hr + ((CPS * (u - F1S) + c) * NRB + rb) * 1024);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < CBW; ++q)
 #pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) acc2[q][rb] = Op16<T>::mfma(ring[u % DEPTH][c * 4 + q], hb4[rb], acc2[q][rb]);
+                    for (int rb = 0; rb < NRB; ++rb) acc2[q][rb] = Op16<T>::mfma(ring[u % DEPTH][c * CBW + q], hb4[rb], acc2[q][rb]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            issue(u + DEPTH < 8 ? sc : sc + 1, (u + DEPTH) & 7, u % DEPTH);
+            issue(u + DEPTH < SPS ? sc : sc + 1, (u + DEPTH) % SPS, u % DEPTH);
         }
+        if (HBUF == 1) __syncthreads();   // single H buffer: every wave is done reading it before the next super-chunk overwrites it
     }
 
-    // ---- epilogue: x[row][c] += gamma * (out + b2); fragment (4w + q), slot 4g + r <-> channel 64w + 16g + 4q + r, row rb * 16 + s ----
+    // ---- epilogue: x[row][c] += gamma * (out + b2); fragment cb = CBW w + q, slot 4g + r <-> channel (cb>>2)*64 + 16g + (cb&3)*4 + r, row rb * 16 + s ----
     const bool has_g = p.gamma != nullptr;
-    const int c0 = wave * 64 + g * 16;
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
         const int row = row0 + rb * 16 + s;
         if (row < p.M) {
-            float* px = p.x + (size_t)row * C + c0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f4 xv = *(const f4*)(px + q * 4);
-                const f4 bv = *(const f4*)(p.b2 + c0 + q * 4);
-                const f4 gl = *(const f4*)((has_g ? p.gamma : p.b2) + c0 + q * 4);
+            for (int q = 0; q < CBW; ++q) {
+                const int cb = CBW * wave + q;
+                const int c0 = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
+                float* px = p.x + (size_t)row * C + c0;
+                f4 xv = *(const f4*)px;
+                const f4 bv = *(const f4*)(p.b2 + c0);
+                const f4 gl = *(const f4*)((has_g ? p.gamma : p.b2) + c0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xv[r] += (has_g ? gl[r] : 1.f) * (acc2[q][rb][r] + bv[r]);
-                *(f4*)(px + q * 4) = xv;
+                *(f4*)px = xv;
             }
         }
     }
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void winmlp_kernel(WinMlpParams p) {
 
 }  // namespace
 
-bool winmlp_supported(int C, int hidden) { return C == 512 && hidden == 2048; }
+bool winmlp_supported(int C, int hidden) { return (C == 512 && hidden == 2048) || (C == 256 && hidden == 1024); }
 
 int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     if (!winmlp_supported(c.C, c.hidden) || c.M <= 0 || !c.x || !c.w1f || !c.w2f) {
@@ -224,12 +243,17 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
     ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
-    const int grid = (c.M + 63) / 64;
-    prof_note("winmlp_kernel<512>", grid);
-    // ring depth 2: every slot index t % 2 is static inside the (not unrolled) super-chunk loop because a super-chunk is 8 steps
-    if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 2>), dim3(grid), dim3(512), 0, stream, p);
-    else if (c.dtype == FVIT_BF16) hipLaunchKernelGGL((winmlp_kernel<__bf16, 2>), dim3(grid), dim3(512), 0, stream, p);
-    else { set_error("win_mlp: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
+    const int rows_per_wg = c.C == 512 ? 64 : 128;
+    const int grid = (c.M + rows_per_wg - 1) / rows_per_wg;
+    prof_note(c.C == 512 ? "winmlp_kernel<512>" : "winmlp_kernel<256>", grid);
+    if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_mlp: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
+    if (c.C == 512) {
+        if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 512, 2048, 4, 2>), dim3(grid), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((winmlp_kernel<__bf16, 512, 2048, 4, 2>), dim3(grid), dim3(512), 0, stream, p);
+    } else {
+        if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 256, 1024, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((winmlp_kernel<__bf16, 256, 1024, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
+    }
     return check_launch("winmlp_kernel");
 }
 

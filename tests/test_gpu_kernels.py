@@ -322,8 +322,8 @@ def test_mlp_fused(opname, dt, code, M, use_gamma, C):
     tol = (3e-3 if dt == torch.float16 else 2e-2) * ref.abs().max().item()
     assert torch.isfinite(x).all()
     assert (x - ref).abs().max().item() < tol
-    assert lib.fvit_win_mlp_supported(C, hid) == (1 if C == 512 else 0)
-    if C == 512:   # the same contract with the N-split work split (fvit_winmlp.hip)
+    assert lib.fvit_win_mlp_supported(C, hid) == 1 and lib.fvit_win_mlp_supported(784, 3136) == 0
+    if True:   # the same contract with the N-split work split (fvit_winmlp.hip: 64-row workgroups for C = 512, 128-row for C = 256)
         xw = torch.cat([x0, torch.full((5, C), float("nan"), device="cuda")])   # rows beyond M stay untouched
         _lib.check(lib.fvit_win_mlp_fused(code, xw.data_ptr(), M, C, hid, lnw.data_ptr(), lnb.data_ptr(), ctypes.c_float(1e-5), w1p.data_ptr(),
                                           b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(), gamma.data_ptr() if use_gamma else None, _stream()),
