@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md
+N_CU = 256                 # compute units of an MI355X (8 XCDs x 32)
 HBM_PEAK_GBS = 8000.0
 RIDGE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
 PMC_FILE = os.path.join("profiles", "r02_pmc_hbm_traffic_by_kernel.json")   # scripts/gpu_pmc_traffic.sh -> scripts/pmc_traffic_summary.py
@@ -245,7 +246,8 @@ def roofline_entry(row, operand):
          "flop_per_byte": row["flop_per_byte"], "tflops": row["tflops"], "gbs": row["gbs"], "launches_per_step": row["launches_per_step"],
          "avg_launch_us": row["avg_launch_us"], "ms_per_step": row["ms_per_step"],
          "algorithmic_mflop_per_launch": row["algorithmic_mflop_per_launch"], "algorithmic_mbyte_per_launch": row["algorithmic_mbyte_per_launch"],
-         "selection": "the (kernel, launch shape) with the largest summed time per step among the launches of the timed configuration"}
+         "selection": ("the HAT (kernel, launch shape) with the largest GPU share per step among the launches of the timed configuration: "
+                       "summed time x min(workgroups, 256) / 256 CUs (roofline_shapes lists every shape with both figures)")}
     pm = pmc_row(row["kernel"], row["workgroups"])
     if pm is not None:
         e["traffic"] = int(pm["hbm_traffic_mb"] * 1e6)
@@ -397,7 +399,13 @@ def main():
     out["step_ms"] = step_dispersion(cfg, min(max(args.steps, 5), 30))
     shapes = profile_shapes(cfg, args.prof_steps)
     hat = [r for r in shapes if r["kind"] not in ("other", "conv3x3")]
-    dom = max((r for r in shapes if r["algorithmic_mflop_per_launch"] > 0 and r["kind"] != "conv3x3"), key=lambda r: r["ms_per_step"], default=None)
+    # dominant = the HAT (kernel, launch shape) that consumes the most GPU: summed time per step x the share of the 256 CUs its launch
+    # occupies.  The per-image / per-window kernels of r02 (86 or 66 workgroups of 4-8 waves, one per CU) hold a third or a quarter of the
+    # chip while the other stream shards use the rest; by time alone they would head the list although they leave most of the GPU free.
+    for r in shapes:
+        r["cu_share"] = round(min(r["workgroups"], N_CU) / N_CU, 3)
+        r["gpu_ms_per_step"] = round(r["ms_per_step"] * r["cu_share"], 4)
+    dom = max((r for r in shapes if r["algorithmic_mflop_per_launch"] > 0 and r["kind"] != "conv3x3"), key=lambda r: r["gpu_ms_per_step"], default=None)
     out["roofline"] = roofline_entry(dom, args.operand)
     out["roofline_shapes"] = shapes[:24]
     out["hat_ms_per_step"] = round(sum(r["ms_per_step"] for r in hat), 4)
