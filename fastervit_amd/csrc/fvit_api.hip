@@ -217,7 +217,7 @@ struct NextPe {   // position-embedding rows of the NEXT block, applied in this 
 static bool win_mlp_ok(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t rows) {
     if (!winmlp_supported(d.C, d.hidden) || !w.w_fc1_frag || !w.w_fc2_frag) return false;
     if (d.C == 512) return tune_get("win_mlp", 1) != 0;
-    return rows >= tune_get("mlp_fused_min_rows", 16384) && tune_get("win_mlp256", 0) != 0;   // C = 256: 128-row workgroups
+    return rows >= tune_get("mlp_fused_min_rows", 16384) && tune_get("win_mlp256", 2) != 0;   // C = 256: 2 = 4-wave 64-row workgroups, two per CU (default); 1 = 8-wave 128-row
 }
 
 static bool mlp_takes_fused_kernel(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t rows) {

@@ -20,7 +20,10 @@
 // On by default (fvit_tune "win_mlp").
 // The C = 256 / hidden 1024 instance (128-row workgroups, stage 2: 143 workgroups per shard instead of the 285 of mlp_fused_kernel) is
 // correct and tested but buys nothing there (774 vs 773 us per stage-2 forward, 78.7k vs 79.9k images/s, call r4c): 143 workgroups are not
-// narrow, and the 64-row kernel it would replace is not weight-bound.  Opt-in (fvit_tune "win_mlp256").
+// narrow, and the 64-row kernel it would replace is not weight-bound (fvit_tune "win_mlp256" = 1).  What does pay in stage 2 is the
+// 4-wave form ("win_mlp256" = 2, the default): 64-row workgroups of 4 waves, 210 registers and 68 KiB of LDS, so TWO workgroups share a
+// CU and their LayerNorm / fc1 / exchange / fc2 phases interleave instead of running in lockstep: 47 vs 50 us per launch against
+// mlp_fused_kernel<256> (LDS reads per MFMA a quarter of that kernel's), 774 -> 756 us per stage-2 forward, 79.8k -> 80.8k images/s (call r4h).
 #include "fvit_common.h"
 
 namespace fvit {
@@ -41,19 +44,20 @@ struct WinMlpParams {
 };
 
 // CC / HID: channels / hidden units; NRB: row blocks of 16 per workgroup (4: 64 rows, C = 512; 8: 128 rows, C = 256)
-template <typename T, int CC, int HID, int NRB, int DEPTH>
-__global__ __launch_bounds__(512, 1) void winmlp_kernel(WinMlpParams p) {
+// NWV: waves per workgroup (8: one workgroup per CU; 4: 256 registers per wave and <= 70 KiB of LDS, two workgroups per CU whose phases interleave)
+template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinMlpParams p) {
     typedef typename Op16<T>::v8 v8;
-    constexpr int C = CC, KK = C / 32, CB = C / 16, NW = 8;
+    constexpr int C = CC, KK = C / 32, CB = C / 16, NW = NWV;
     constexpr int CBW = CB / NW;                   // output channel blocks per wave (4 / 2)
-    constexpr int NSC = HID / 32 / NW;             // super-chunks: 8 chunks of 32 units each, one chunk per wave
+    constexpr int NSC = HID / 32 / NW;             // super-chunks: NW chunks of 32 units each, one chunk per wave
     constexpr int F1S = 2 * KK / 8;                // fc1 steps of 8 fragments per chunk: 4 k steps x 2 unit blocks each
     constexpr int CPS = 8 / CBW;                   // chunks per fc2 step of 8 fragments
     constexpr int F2S = NW / CPS;                  // fc2 steps per super-chunk
     constexpr int SPS = F1S + F2S;                 // steps per super-chunk (8 / 4)
     static_assert(SPS % DEPTH == 0, "ring slots must be static inside the super-chunk loop");
     constexpr int WPR = NW / NRB;                  // waves sharing a row block in the LayerNorm phase (2 / 1)
-    constexpr int HBUF = (NRB * KK + 2 * NW * NRB) * 1024 + HID * 4 <= 150 * 1024 ? 2 : 1;   // H double-buffered when it fits
+    constexpr int HBUF = (NRB * KK + 2 * NW * NRB) * 1024 + HID * 4 <= (NW == 8 ? 150 : 72) * 1024 ? 2 : 1;   // H double-buffered when it fits
     constexpr int OFF_H = NRB * KK * 1024;         // XN: 64 KiB; H: HBUF x NW x NRB KiB; fc1 bias
     constexpr int OFF_B1 = OFF_H + HBUF * NW * NRB * 1024;
     __shared__ __attribute__((aligned(16))) char smem[OFF_B1 + HID * 4];
@@ -87,14 +91,15 @@ __global__ __launch_bounds__(512, 1) void winmlp_kernel(WinMlpParams p) {
     };
 
     {   // fc1 bias to LDS (an ordinary load inside the loops would queue behind the ring's prefetches and drain it), then the first steps
-        float c1[HID / 512];
+        constexpr int NT = 64 * NW;
+        float c1[HID / NT];
 #pragma unroll
-        for (int i = 0; i < HID / 512; ++i) c1[i] = p.b1[tid + 512 * i];
+        for (int i = 0; i < HID / NT; ++i) c1[i] = p.b1[tid + NT * i];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < DEPTH; ++t) issue(0, t, t);
 #pragma unroll
-        for (int i = 0; i < HID / 512; ++i) b1s[tid + 512 * i] = c1[i];
+        for (int i = 0; i < HID / NT; ++i) b1s[tid + NT * i] = c1[i];
     }
 
     // ---- phase A: LayerNorm; WPR waves share a row block: each reads the full rows and writes KK / WPR of the k steps ----
@@ -243,7 +248,8 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
     ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
-    const int rows_per_wg = c.C == 512 ? 64 : 128;
+    const int small = c.C == 256 && tune_get("win_mlp256", 2) == 2;   // 4-wave, 64-row workgroups, two per CU
+    const int rows_per_wg = c.C == 512 || small ? 64 : 128;
     const int grid = (c.M + rows_per_wg - 1) / rows_per_wg;
     prof_note(c.C == 512 ? "winmlp_kernel<512>" : "winmlp_kernel<256>", grid);
     if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_mlp: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
@@ -251,7 +257,10 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
         if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 512, 2048, 4, 2>), dim3(grid), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((winmlp_kernel<__bf16, 512, 2048, 4, 2>), dim3(grid), dim3(512), 0, stream, p);
     } else {
-        if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 256, 1024, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
+        if (small) {
+            if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 256, 1024, 4, 2, 4>), dim3(grid), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((winmlp_kernel<__bf16, 256, 1024, 4, 2, 4>), dim3(grid), dim3(256), 0, stream, p);
+        } else if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 256, 1024, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((winmlp_kernel<__bf16, 256, 1024, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
     }
     return check_launch("winmlp_kernel");
