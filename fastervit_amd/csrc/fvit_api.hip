@@ -271,7 +271,8 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
 // qkv GEMM.  Same two fp32 additions in the same order as the separate kernel (bitwise the same residual stream).
 // C = 512 (stage 3 of FasterViT-0): the attention sub-block with the waves of a window splitting heads / output channels (fvit_winblk.hip)
 static bool win_fused_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S) {
-    return winblk_supported(d.C, d.heads, S) && d.dpad == 32 && w.w_qkv_frag && w.b_qkv_heads && w.w_proj_frag && w.bias && tune_get("win_fused", 1);
+    if (!winblk_supported(d.C, d.heads, S) || d.dpad != 32 || !w.w_qkv_frag || !w.b_qkv_heads || !w.w_proj_frag || !w.bias) return false;
+    return d.C == 512 ? tune_get("win_fused", 1) != 0 : tune_get("win_fused256", 0) != 0;   // C = 256: the 4-wave form, two workgroups per CU
 }
 
 static bool pe_preadd_chain(const FvitStageDesc& d, const StageLayout& L, const FvitBlockWeights& w) {

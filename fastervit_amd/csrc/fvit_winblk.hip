@@ -21,6 +21,9 @@
 // the memory side (scripts/probes/regstream_probe.hip), 2.3 MB per workgroup.  But it occupies 86 CUs instead of the whole chip four times,
 // and with three stream shards sharing the GPU that is what counts: +0.7 % / +1.9 % images/s end to end on two boxes.  On by default
 // (fvit_tune "win_fused").
+// The C = 256 / 8-head instance for stage 2 (4 waves, two workgroups per CU; fvit_tune "win_fused256", off) is bitwise the same result as
+// attnblk_kernel<256> (same summation orders) and loses to it: 767-772 vs 755-774 us per stage-2 forward, 77.4k-78.0k vs 79.2k images/s
+// (call r4l): 344 window workgroups are a chip-wide launch either way, and attnblk's per-row-block waves need no O^T exchange.
 #include "fvit_common.h"
 
 namespace fvit {
@@ -48,10 +51,14 @@ struct WinBlkParams {
     float scale;
 };
 
-template <typename T>
-__global__ __launch_bounds__(512, 1) void winblk_kernel(WinBlkParams p) {
+// CC = 512: 8 waves, one workgroup per CU.  CC = 256 (stage 2, 8 heads): 4 waves (two heads and four channel blocks each, like the 8-wave
+// form), <= 256 registers and 67 KiB of LDS, so two workgroups share a CU and their phases interleave.
+template <typename T, int CC, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinBlkParams p) {
     typedef typename Op16<T>::v8 v8;
-    constexpr int C = 512, KK = 16, CB = 32, HEADS = 16, NW = 8, NRB = 4, SP = 64;
+    constexpr int C = CC, KK = C / 32, CB = C / 16, HEADS = C / 32, NW = NWV, NRB = 4, SP = 64;
+    static_assert(HEADS == 2 * NW && CB == 4 * NW, "two heads and four output channel blocks per wave");
+    constexpr int SPH = KK + 4;                    // steps per head: KK qkv steps + 4 bias-tile steps
     constexpr int DEPTH = 2;                       // ring slots of 6 fragments (6 KiB) per wave (3 slots spill at the 256-register budget of 8 waves)
     constexpr int OFF_O = NRB * KK * 1024;         // XN: 64 KiB, then O: 64 KiB (a separate region: each head's O^T fragments leave the
     constexpr int OFF_BQ = OFF_O + NRB * HEADS * 1024;   // registers at once -- held across the next head they spilled, and a scratch reload
@@ -85,14 +92,14 @@ __global__ __launch_bounds__(512, 1) void winblk_kernel(WinBlkParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) ring[slot][q] = *(const v8*)(Wp + ((size_t)h * CB + 4 * wave + q) * 1024);
     };
-    // per head 16 + 4 = 20 steps; two heads = 40; proj 16: 56 steps.  issue(t) requests step t into slot t % DEPTH.
+    // per head KK + 4 steps; two heads; then one proj step per head of the layer.  issue(t) requests step t into slot t % DEPTH.
     auto issue = [&](int t) {
-        if (t < 40) {
-            const int hh = t / 20, u = t - hh * 20, h = 2 * wave + hh;
-            if (u < 16) load_qkv(t % DEPTH, h, u);
-            else load_bias(t % DEPTH, h, u - 16);
-        } else if (t < 56) {
-            load_proj(t % DEPTH, t - 40);
+        if (t < 2 * SPH) {
+            const int hh = t / SPH, u = t - hh * SPH, h = 2 * wave + hh;
+            if (u < KK) load_qkv(t % DEPTH, h, u);
+            else load_bias(t % DEPTH, h, u - KK);
+        } else if (t < 2 * SPH + HEADS) {
+            load_proj(t % DEPTH, t - 2 * SPH);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -102,9 +109,10 @@ __global__ __launch_bounds__(512, 1) void winblk_kernel(WinBlkParams p) {
 #pragma unroll
     for (int t = 0; t < DEPTH; ++t) issue(t);
 
-    // ---- phase A: gather (+ add) and LayerNorm; this wave writes k steps [8 * half, 8 * half + 8) of row block rb ----
+    // ---- phase A: gather (+ add) and LayerNorm; WPR waves share a row block: each reads the full rows and writes KK / WPR of the k steps ----
     {
-        const int rb = wave >> 1, half = wave & 1;
+        constexpr int WPR = NW / NRB, KP = KK / WPR;
+        const int rb = wave / WPR, part = wave % WPR;
         const int tok = rb * 16 + s;
         const int64_t row = (int64_t)win * p.S + (tok < p.S ? tok : p.S - 1);   // clamped: always a real row
         const int b = (int)(row / p.rows_per_image), pr = (int)(row - (int64_t)b * p.rows_per_image);
@@ -141,19 +149,22 @@ __global__ __launch_bounds__(512, 1) void winblk_kernel(WinBlkParams p) {
         sq = sum_xor32(sum_xor16(sq));
         const float rstd = rsqrtf(sq / (float)C + p.eps);
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
+        for (int k8 = 0; k8 < KP; ++k8) {
             v8 o;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                // dynamic (wave-uniform) choice of the half without dynamic register indexing
-                const f4 x0 = v[2 * k8 + h2], x1 = v[2 * (k8 + 8) + h2];
-                const int co = ((k8 + 8 * half) >> 1) * 64 + g * 16 + ((k8 + 8 * half) & 1) * 8 + h2 * 4;
+                // wave-uniform choice of the part without dynamic register indexing
+                f4 xs = v[2 * k8 + h2];
+#pragma unroll
+                for (int pp = 1; pp < WPR; ++pp) xs = part == pp ? v[2 * (k8 + pp * KP) + h2] : xs;
+                const int kk = k8 + part * KP;
+                const int co = (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 + h2 * 4;
                 const f4 w = *(const f4*)(p.ln_w + co);
                 const f4 bb = *(const f4*)(p.ln_b + co);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)(((half ? x1[r] : x0[r]) - mean) * rstd * w[r] + bb[r]);
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)((xs[r] - mean) * rstd * w[r] + bb[r]);
             }
-            *(v8*)(smem + ((rb * KK + k8 + 8 * half) * 1024) + lane16) = o;
+            *(v8*)(smem + ((rb * KK + k8 + part * KP) * 1024) + lane16) = o;
         }
     }
     __syncthreads();
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(512, 1) void winblk_kernel(WinBlkParams p) {
             for (int rb = 0; rb < NRB; ++rb) acc[ub][rb] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            const int t = hh * 20 + kk;
+            const int t = hh * SPH + kk;
             v8 xb[NRB];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) xb[rb] = *(const v8*)(xn + (rb * KK + kk) * 1024);
@@ -209,10 +220,10 @@ __global__ __launch_bounds__(512, 1) void winblk_kernel(WinBlkParams p) {
                     vf[db][k32][4 + r] = (T)(acc[4 + db][2 * k32 + 1][r] + bv);  // keys 32 k32 + 16 + 4g + r
                 }
         }
-        // scores^T, softmax over keys, O^T, per query row block; the bias tiles of (h, qb) are step hh * 20 + 16 + qb
+        // scores^T, softmax over keys, O^T, per query row block; the bias tiles of (h, qb) are step hh * SPH + KK + qb
 #pragma unroll
         for (int qb = 0; qb < NRB; ++qb) {
-            const int t = hh * 20 + 16 + qb;
+            const int t = hh * SPH + KK + qb;
             f4 sc[NRB];
             float mx = -3.0e38f;
 #pragma unroll
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void winblk_kernel(WinBlkParams p) {
         for (int rb = 0; rb < NRB; ++rb) oacc[q][rb] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) {
-        const int t = 40 + h;
+        const int t = 2 * SPH + h;
         v8 ob[NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) ob[rb] = *(const v8*)(xn + OFF_O + (rb * HEADS + h) * 1024);
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void winblk_kernel(WinBlkParams p) {
 
 }  // namespace
 
-bool winblk_supported(int C, int heads, int S) { return C == 512 && heads == 16 && S > 48 && S <= 64; }
+bool winblk_supported(int C, int heads, int S) { return ((C == 512 && heads == 16) || (C == 256 && heads == 8)) && S > 48 && S <= 64; }
 
 int launch_winblk(const AttnBlkCall& c, hipStream_t stream) {
     if (!winblk_supported(c.C, c.heads, c.S) || c.nwin <= 0 || !c.wqkv_f || !c.wproj_f || !c.x_out || !c.bias || !c.bqkv) {
@@ -333,10 +344,15 @@ int launch_winblk(const AttnBlkCall& c, hipStream_t stream) {
     const double flops = rows * (2.0 * c.C * 3 * c.C + 4.0 * c.S * c.C + 2.0 * c.C * c.C);
     const double bytes = rows * c.C * 8.0 + 2.0 * 4.0 * c.C * c.C;
     ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
-    prof_note("winblk_kernel<512,S64>", c.nwin);
-    if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winblk_kernel<_Float16>), dim3(c.nwin), dim3(512), 0, stream, p);
-    else if (c.dtype == FVIT_BF16) hipLaunchKernelGGL((winblk_kernel<__bf16>), dim3(c.nwin), dim3(512), 0, stream, p);
-    else { set_error("win_block: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
+    prof_note(c.C == 512 ? "winblk_kernel<512,S64>" : "winblk_kernel<256,S64>", c.nwin);
+    if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_block: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
+    if (c.C == 512) {
+        if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winblk_kernel<_Float16, 512, 8>), dim3(c.nwin), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((winblk_kernel<__bf16, 512, 8>), dim3(c.nwin), dim3(512), 0, stream, p);
+    } else {
+        if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winblk_kernel<_Float16, 256, 4>), dim3(c.nwin), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((winblk_kernel<__bf16, 256, 4>), dim3(c.nwin), dim3(256), 0, stream, p);
+    }
     return check_launch("winblk_kernel");
 }
 

@@ -255,7 +255,8 @@ int fvit_win_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, in
                        const float* gamma, fvit_stream_t stream);
 
 /* fvit_attn_block_fused's contract for C == 512, heads == 16, 48 < S <= 64 (stage 3 of FasterViT-0) with a different work split: one
- * workgroup per window, its 8 waves split heads / output channels and stream their weight slices from L2 into registers (fvit_winblk.hip). */
+ * workgroup per window, its 8 waves split heads / output channels and stream their weight slices from L2 into registers (fvit_winblk.hip);
+ * also C == 256, heads == 8 with 4 waves. */
 int fvit_win_block_supported(int32_t C, int32_t heads, int32_t S);
 int fvit_win_block_fused(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB,
                          const int32_t* src_idx, const int32_t* add_idx, const float* add, const float* ln_w,
@@ -360,7 +361,7 @@ int fvit_sgd_momentum(float* param, float* momentum, const float* grad, int64_t 
 /* Performance-experiment knobs for A/B runs inside one process; the same keys can be preset through the environment as
  * FVIT_TUNE_<key>=<int> (read once per key).  Kernel-selection knobs never change results beyond fp32 summation order:
  *   "mlp_fused", "attn_fused" 0/1; "mlp_fused_min_rows", "attn_fused_min_rows", "mlp_fused512_min_rows", "attn_fused512_min_rows";
- *   "mlp_variant" (-1 auto), "ab_variant", "ct_fused" 0/1 (carrier branch in one kernel), "win_fused" 0/1 (stage-3 attention sub-block in one kernel), "win_mlp" 0/1 (stage-3 MLP sub-block in one kernel), "win_mlp256" 0/1/2 (its C = 256 instances for stage 2: 2 = 4-wave 64-row workgroups (default), 1 = 8-wave 128-row, 0 = fvit_mlp_fused's kernel), "ct_variant", "ct_touch", "ln_gemm" 0/1, "ln_gemm_max_rows", "lngemm_nt", "gemm_ring", "mlp_ring4_max_grid", "gemm_stagger", "ab_stagger", "mlp_stagger" (0 / 1 / 2), "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
+ *   "mlp_variant" (-1 auto), "ab_variant", "ct_fused" 0/1 (carrier branch in one kernel), "win_fused" 0/1 (stage-3 attention sub-block in one kernel), "win_fused256" 0/1 (its 4-wave C = 256 instance for stage 2, off), "win_mlp" 0/1 (stage-3 MLP sub-block in one kernel), "win_mlp256" 0/1/2 (its C = 256 instances for stage 2: 2 = 4-wave 64-row workgroups (default), 1 = 8-wave 128-row, 0 = fvit_mlp_fused's kernel), "ct_variant", "ct_touch", "ln_gemm" 0/1, "ln_gemm_max_rows", "lngemm_nt", "gemm_ring", "mlp_ring4_max_grid", "gemm_stagger", "ab_stagger", "mlp_stagger" (0 / 1 / 2), "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
  *   "conv_halo_grid", "conv64_variant", "conv128_narrow", "stem_fused_grid".
  * The "*_ablate" keys ("mlp_ablate", "ab_ablate", "conv_ablate", "conv_halo_ablate") switch off parts of a kernel for timing and
  * DO produce wrong results.  Guarded by a mutex; launches read the values at launch time. */
