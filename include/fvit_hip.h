@@ -269,7 +269,7 @@ int fvit_win_block_fused(int32_t operand_dtype, const float* srcA, int32_t rowsA
  *   ct[b][i] = X[b * rowsA + src_idx[i]] (+ add[i]);  ct += gamma1 * attn(LayerNorm1(ct));  ct += gamma2 * mlp(LayerNorm2(ct))  -> R [batch * G][C]
  * attention over the G <= 16 carrier tokens of an image (bias f32 [heads][16][16], mask on padded keys), weights in the fragment-major
  * packings of fvit_attn_block_fused / fvit_mlp_fused.  Needs C == 256, heads == 8, hidden == 1024 (fvit_ct_block_supported).  gamma1 /
- * gamma2 / add may be null. */
+ * gamma2 / add may be null; every src_idx entry must be >= 0 (carrier tokens are rows of X; there is no second source here). */
 int fvit_ct_block_supported(int32_t C, int32_t heads, int32_t G, int32_t hidden);
 int fvit_ct_block_fused(int32_t operand_dtype, const float* X, int32_t rowsA, const int32_t* src_idx, const float* add, float* R,
                         int32_t batch, int32_t G, int32_t heads, int32_t C, int32_t hidden, const float* ln1_w, const float* ln1_b,
