@@ -146,3 +146,19 @@ def test_checkpoint_roundtrip(tmp_path):
     m3 = fastervit_amd.create_model("faster_vit_0_224", **kw)
     m3._load_state_dict(path, strict=True)
     assert torch.equal(m3.head.weight, m.head.weight)
+
+
+def test_committed_pmc_traffic_file_covers_the_default_kernels():
+    """bench.py fills roofline.traffic from the committed PMC passes (it cannot sample counters on itself); the file must have been
+    produced by the CURRENT default path: a row for every HAT kernel family the FasterViT-0 deploy plan launches (r01: it went stale
+    silently after a kernel was replaced)."""
+    import json
+    import bench
+    path = os.path.join(ROOT, bench.PMC_FILE)
+    assert os.path.exists(path), path
+    rows = json.load(open(path))["kernels"]
+    fams = {r["kernel"].split("<")[0] for r in rows}
+    for fam in ("winmlp_kernel", "attnblk_kernel", "ctblk_kernel", "winblk_kernel", "conv3x3_kernel", "conv3x3_c64_halo_kernel", "stem_fused_kernel"):
+        assert fam in fams, f"{bench.PMC_FILE} has no row of {fam}: re-run scripts/gpu_r2_evidence.sh and copy the new file"
+    dom = [r for r in rows if r["kernel"].startswith("winmlp_kernel<f16,256") and r["workgroups"] == 285]
+    assert dom and dom[0]["hbm_traffic_mb"] > 0
