@@ -1,0 +1,51 @@
+"""CPU checks of the MFMA fragment-order weight packers (hat_runtime.frag_pack_*): every fused kernel (attention block, fused / N-split MLP,
+carrier-branch and window kernels) reads these images linearly, so the documented element mapping of include/fvit_hip.h is pinned here
+against a plain index formula on random weights."""
+import pytest
+import torch
+
+from fastervit_amd import hat_runtime as hr
+
+
+def kch(kk, g, e):
+    return (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 + e
+
+
+@pytest.mark.parametrize("C", [256, 512])
+def test_kslot_channels_is_a_permutation_with_the_documented_formula(C):
+    k = hr.kslot_channels(C)
+    assert sorted(k.tolist()) == list(range(C))
+    for slot in (0, 7, 8, 31, 32, 33, 95, C - 1):
+        kk, g, e = slot >> 5, (slot >> 3) & 3, slot & 7
+        assert int(k[slot]) == kch(kk, g, e)
+
+
+@pytest.mark.parametrize("C,hid", [(256, 1024), (512, 2048)])
+def test_frag_pack_fc1_and_fc2(C, hid):
+    g_ = torch.Generator().manual_seed(C)
+    w1 = torch.randn(hid, C, generator=g_)
+    w2 = torch.randn(C, hid, generator=g_)
+    p1 = hr.frag_pack_fc1(w1).reshape(hid // 32, 2, C // 32, 64, 8)     # lane = 16 g + s
+    p2 = hr.frag_pack_fc2(w2).reshape(hid // 32, C // 16, 64, 8)
+    assert p1.shape == (hid // 32, 2, C // 32, 64, 8) and p2.shape == (hid // 32, C // 16, 64, 8)
+    for (j, hb, kk, g, s, e) in [(0, 0, 0, 0, 0, 0), (3, 1, 5, 2, 9, 7), (hid // 32 - 1, 1, C // 32 - 1, 3, 15, 7), (7, 0, 1, 1, 4, 3)]:
+        assert p1[j, hb, kk, 16 * g + s, e] == w1[j * 32 + hb * 16 + s, kch(kk, g, e)]
+    for (j, cb, g, s, e) in [(0, 0, 0, 0, 0), (5, 9, 2, 11, 6), (hid // 32 - 1, C // 16 - 1, 3, 15, 7), (2, 3, 1, 7, 4)]:
+        ch = (cb >> 2) * 64 + (s >> 2) * 16 + (cb & 3) * 4 + (s & 3)
+        col = j * 32 + (e >> 2) * 16 + 4 * g + (e & 3)
+        assert p2[j, cb, 16 * g + s, e] == w2[ch, col]
+    # the packings are bijections of the weight elements
+    assert torch.equal(p1.flatten().sort().values, w1.flatten().sort().values)
+    assert torch.equal(p2.flatten().sort().values, w2.flatten().sort().values)
+
+
+@pytest.mark.parametrize("C,heads", [(256, 8), (512, 16)])
+def test_frag_pack_qkv(C, heads):
+    g_ = torch.Generator().manual_seed(heads)
+    w = torch.randn(3 * C, C, generator=g_)
+    p = hr.frag_pack_qkv(w, heads).reshape(heads, 6, C // 32, 64, 8)
+    assert p.shape == (heads, 6, C // 32, 64, 8)
+    for (h, ub, kk, g, s, e) in [(0, 0, 0, 0, 0, 0), (heads - 1, 5, C // 32 - 1, 3, 15, 7), (3, 2, 4, 1, 6, 5), (5, 4, 7, 2, 13, 1)]:
+        row = (ub >> 1) * C + h * 32 + (ub & 1) * 16 + s
+        assert p[h, ub, kk, 16 * g + s, e] == w[row, kch(kk, g, e)]
+    assert torch.equal(p.flatten().sort().values, w.flatten().sort().values)
