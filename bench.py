@@ -12,15 +12,20 @@ timings into one whole-job figure.  Rank 0 prints ONE JSON line:
 
   value / ms_per_step     W untimed + exactly K timed hipGraph replays, barrier + synchronize on both sides, MAX over ranks
   step_ms                 min / median / max of individually event-timed steps (a separate pass; dispersion of the number above)
-  roofline                ONE (kernel, launch shape) row: the shape with the largest summed time in the timed configuration; live
-                          HIP-event duration per launch (library kernel timer, on the launch stream), algorithmic bytes / FLOPs of
-                          THAT shape, PMC traffic of THAT (kernel, grid) from the committed rocprofv3 passes (null when the
-                          committed file has no such row)
+  roofline                the DOMINANT KERNEL BY TIME: launches of the timed configuration are summed per kernel name (the key of a
+                          rocprofv3 --kernel-trace --stats row, conv kernels included, no weighting); the kernel with the largest
+                          summed time per step is reported through its heaviest launch shape: live HIP-event duration per launch
+                          (library kernel timer, on the launch stream), algorithmic bytes / FLOPs of THAT shape, PMC traffic of THAT
+                          (kernel, grid) from the committed rocprofv3 passes (null when the committed file has no such row).
+                          cu_share / frac_of_occupied_cus are extra fields (a 66-workgroup launch holds a quarter of the chip)
   roofline_shapes         every (kernel, launch shape) of the step with the same columns (what DESIGN.md §4 quotes)
-  parity / parity_bf16    logits max-abs error vs the fp32 CPU oracle, 8 images from EACH stream shard (fp16 operands = the timed
-                          configuration; bf16 operands reported beside it)
+  parity / parity_<op>    logits max-abs error vs the fp32 CPU oracle, 8 images from EACH stream shard, on synthetic weights of the
+                          'init' family of tests/synth.py (reference init + gamma ~ U(0.5, 1.5), BN statistics, biases: with the
+                          reference's plain init FasterViT-4's layer-scale gamma = 1e-5 would hide the HAT stages).  The timed
+                          operand type first; every other operand mode (bf16, and the split-operand bf16x2 / bf16x3 routes) is
+                          reported beside it with its own error AND its own images/s
   secondary               BASELINE configs 3 and 5 (faster_vit_4_224 bs 128; faster_vit_4_any_res 576x960 bs 8): a few timed steps
-                          each + parity on 2 images (N = 1 only)
+                          each + parity on 2 images, same synthetic weights (N = 1 only)
   cpu_baseline            the CPU oracle (a port of the reference's fp32 PyTorch path) on the host cores, batch 8 and batch 64
 """
 import argparse
@@ -41,7 +46,10 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROAR
 N_CU = 256                 # compute units of an MI355X (8 XCDs x 32)
 HBM_PEAK_GBS = 8000.0
 RIDGE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-PMC_FILE = os.path.join("profiles", "r02_pmc_hbm_traffic_by_kernel.json")   # scripts/gpu_pmc_traffic.sh -> scripts/pmc_traffic_summary.py
+WEIGHT_SEED = 1234          # tests/cases.py SEED: the weights of the committed golden fixtures
+# scripts/gpu_pmc_traffic.sh -> scripts/pmc_traffic_summary.py; the newest committed round wins
+PMC_FILE = next((f for f in (os.path.join("profiles", f"r0{r}_pmc_hbm_traffic_by_kernel.json") for r in (3, 2))
+                 if os.path.exists(os.path.join(ROOT, f))), os.path.join("profiles", "r02_pmc_hbm_traffic_by_kernel.json"))
 
 
 def parse():
@@ -68,6 +76,8 @@ def parse():
     ap.add_argument("--prof-steps", type=int, default=3, help="eager HIP-event passes for the roofline rows (0: skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 3 and 5")
     ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="exercise ONLY the rank launch / barrier / reduction path on CPU (gloo), no model: prints n_gpus = ranks that ran")
     return ap.parse_args()
 
 
@@ -78,8 +88,13 @@ class Config:
     def __init__(self, args, dev, rank, model_name, batch, hw=None, model_kwargs=None, streams=3):
         import fastervit_amd
         self.args, self.dev, self.name, self.batch = args, dev, model_name, batch
-        torch.manual_seed(0)  # same random-init weights on every rank
+        torch.manual_seed(0)
         self.model = fastervit_amd.create_model(model_name, **(model_kwargs or {})).eval()
+        # synthetic weights keyed by state_dict name, identical on every rank: the reference's init plus seeded gamma ~ U(0.5, 1.5),
+        # BN running statistics and biases (tests/synth.py 'init' family, SURVEY.md §4 trap / §8d) -- with the plain init the
+        # layer-scale gammas of FasterViT-4 are 1e-5 and a parity check would see the conv side only
+        from tests.synth import synth_state_dict
+        self.model.load_state_dict(synth_state_dict(self.model.state_dict(), seed=WEIGHT_SEED, family="init"))
         self.sd_cpu = {k: v.clone() for k, v in self.model.state_dict().items()}
         self.model = self.model.to(dev).to(memory_format=torch.channels_last)
         self.model.set_hat_operand_dtype(args.operand)
@@ -218,6 +233,13 @@ def profile_shapes(cfg, prof_steps, serialize=True):
     return out
 
 
+def shapes_cu(shapes):
+    for r in shapes:
+        r["cu_share"] = round(min(r["workgroups"], N_CU) / N_CU, 3)
+        r["gpu_ms_per_step"] = round(r["ms_per_step"] * r["cu_share"], 4)
+    return shapes
+
+
 def pmc_row(kernel, workgroups):
     """HBM bytes per launch of (kernel family, workgroups) from the committed rocprofv3 PMC passes of THIS command in eager mode
     (bench.py cannot sample PMCs on itself); None when the committed file has no row of that launch shape."""
@@ -237,7 +259,21 @@ def pmc_row(kernel, workgroups):
     return best
 
 
-def roofline_entry(row, operand):
+def dominant_by_time(shapes):
+    """The dominant kernel BY TIME: launches summed per kernel name -- the key of a rocprofv3 --kernel-trace --stats row; every kernel
+    with algorithmic work counts, conv kernels included, no weighting -- and, inside that kernel, its heaviest launch shape."""
+    fam = {}
+    for r in shapes:
+        if r["algorithmic_mflop_per_launch"] > 0 or r["algorithmic_mbyte_per_launch"] > 0:
+            if r["kind"] != "other":
+                fam.setdefault(r["kernel"], []).append(r)
+    if not fam:
+        return None, 0.0
+    name = max(fam, key=lambda k: sum(r["ms_per_step"] for r in fam[k]))
+    return max(fam[name], key=lambda r: r["ms_per_step"]), round(sum(r["ms_per_step"] for r in fam[name]), 4)
+
+
+def roofline_entry(row, operand, family_ms=None):
     if row is None:
         return None
     e = {"kernel": f"{row['kernel']} <{operand}> x {row['workgroups']} workgroups", "bound": row["bound"],
@@ -246,8 +282,12 @@ def roofline_entry(row, operand):
          "flop_per_byte": row["flop_per_byte"], "tflops": row["tflops"], "gbs": row["gbs"], "launches_per_step": row["launches_per_step"],
          "avg_launch_us": row["avg_launch_us"], "ms_per_step": row["ms_per_step"],
          "algorithmic_mflop_per_launch": row["algorithmic_mflop_per_launch"], "algorithmic_mbyte_per_launch": row["algorithmic_mbyte_per_launch"],
-         "selection": ("the HAT (kernel, launch shape) with the largest GPU share per step among the launches of the timed configuration: "
-                       "summed time x min(workgroups, 256) / 256 CUs (roofline_shapes lists every shape with both figures)")}
+         "kernel_ms_per_step_all_shapes": family_ms,
+         "cu_share": row.get("cu_share"),
+         "frac_of_occupied_cus": round(row["frac"] / max(row.get("cu_share") or 1.0, 1e-9), 4),
+         "selection": ("dominant kernel by time: launches of the timed configuration summed per kernel name (as a rocprofv3 --stats row), "
+                       "conv kernels included, no weighting; reported through that kernel's heaviest launch shape.  cu_share = "
+                       "min(workgroups, 256) / 256 and frac_of_occupied_cus = frac / cu_share are extra fields")}
     pm = pmc_row(row["kernel"], row["workgroups"])
     if pm is not None:
         e["traffic"] = int(pm["hbm_traffic_mb"] * 1e6)
@@ -337,9 +377,13 @@ def run_secondary(args, dev):
                 idx = [0, batch - 1]
                 par, _ = parity_vs_oracle(cfg, logits, arch, idx, f"CPU oracle fp32, images {idx} of the batch")
             shapes = profile_shapes(cfg, 1) if args.prof_steps > 0 else []
-            res.append({"workload": f"{name} inference, {cfg.H}x{cfg.W}, batch {batch}, random-init weights", "value": round(batch * args.secondary_steps / elapsed, 1),
+            sec_roof = None
+            if shapes:
+                dom, fam_ms = dominant_by_time(shapes_cu(shapes))
+                sec_roof = roofline_entry(dom, args.operand, fam_ms)
+            res.append({"workload": f"{name} inference, {cfg.H}x{cfg.W}, batch {batch}, synthetic weights (tests/synth.py init family)", "value": round(batch * args.secondary_steps / elapsed, 1),
                         "unit": "images/s", "steps": args.secondary_steps, "ms_per_step": round(elapsed / args.secondary_steps * 1e3, 4),
-                        "launch": cfg.launch_desc(), "parity": par, "roofline": roofline_entry(shapes[0] if shapes else None, args.operand),
+                        "launch": cfg.launch_desc(), "parity": par, "roofline": sec_roof,
                         "wall_s": round(time.perf_counter() - t0, 1)})
             del cfg
         except Exception as e:  # a secondary config must never take the headline line down with it
@@ -348,12 +392,42 @@ def run_secondary(args, dev):
     return res
 
 
+def launch_selftest(args, dp, rank, world):
+    """The N-rank plumbing of this file without a GPU: gloo group, W + K trivial steps through dp.timed_steps, MAX / SUM
+    reductions, ONE JSON line from rank 0 (tests/test_bench_launch.py)."""
+    dist = dp.init_process_group("gloo")
+    elapsed = dp.timed_steps(lambda: time.sleep(0.002), args.steps, args.warmup, lambda: None, dist, None)
+    value = dp.whole_job_rate(args.batch * args.steps, elapsed, dist, None)
+    ran = dp.ranks_that_ran(dist, None)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "launch selftest (no model, CPU, gloo)", "value": round(value, 1), "unit": "items/s", "n_gpus": ran,
+                          "group_world_size": world, "steps": args.steps, "warmup": args.warmup}))
+
+
 def main():
     args = parse()
     from fastervit_amd import dp
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: spawn the N ranks here (one process per GPU under torch.distributed.run)
+        # instead of silently measuring one GPU
+        if not args.launch_selftest and torch.cuda.device_count() < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} requested but this node exposes {torch.cuda.device_count()} HIP device(s); "
+                  "refusing to run fewer ranks than asked for", file=sys.stderr)
+            sys.exit(2)
+        sys.exit(dp.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank, local_rank, world = dp.env_world()
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)", file=sys.stderr)
+        sys.exit(2)
+    if args.launch_selftest:
+        return launch_selftest(args, dp, rank, world)
     dist = dp.init_process_group("nccl")  # RCCL on ROCm; None when WORLD_SIZE == 1
-    assert args.gpus == world or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if dist is not None and dist.get_world_size() != args.gpus:
+        print(f"bench.py: RCCL group has {dist.get_world_size()} ranks, expected {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -365,6 +439,7 @@ def main():
     # W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks
     elapsed = dp.timed_steps(cfg.step, args.steps, args.warmup, torch.cuda.synchronize, dist, dev)
     value = dp.whole_job_rate(args.batch * args.steps, elapsed, dist, dev)
+    n_ran = dp.ranks_that_ran(dist, dev)   # ranks that actually ran the timed region (== RCCL's group size)
     logits_gpu = cfg.logits()
 
     def finish():
@@ -380,11 +455,12 @@ def main():
     out = {
         "metric": ("images/sec FasterViT-0 224x224 inference, bs=256/GPU" if headline
                    else f"images/sec {args.model} {H}x{W} inference, bs={args.batch}/GPU (secondary config)"),
-        "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 1), "unit": "images/s", "n_gpus": n_ran, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.operand,
         "data": "synthetic",
-        "config": {"workload": f"{args.model} inference, {H}x{W}, batch {args.batch}/GPU, random-init weights",
+        "config": {"workload": f"{args.model} inference, {H}x{W}, batch {args.batch}/GPU, synthetic weights (tests/synth.py init family)",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent shards, no data-path collective)",
+                   "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
                    "hat_operands": args.operand,
                    "conv_side": (f"deploy plan: BN folded, {args.conv_dtype} channels_last, HIP conv3x3 (halo-tiled / implicit-GEMM) + fused stem + LayerNorm2d kernels"
                                  if cfg.deploy else (f"model(x) under autocast {args.conv_dtype}: automatic deploy plan" if args.mode == "auto"
@@ -399,14 +475,11 @@ def main():
     out["step_ms"] = step_dispersion(cfg, min(max(args.steps, 5), 30))
     shapes = profile_shapes(cfg, args.prof_steps)
     hat = [r for r in shapes if r["kind"] not in ("other", "conv3x3")]
-    # dominant = the HAT (kernel, launch shape) that consumes the most GPU: summed time per step x the share of the 256 CUs its launch
-    # occupies.  The per-image / per-window kernels of r02 (86 or 66 workgroups of 4-8 waves, one per CU) hold a third or a quarter of the
-    # chip while the other stream shards use the rest; by time alone they would head the list although they leave most of the GPU free.
     for r in shapes:
         r["cu_share"] = round(min(r["workgroups"], N_CU) / N_CU, 3)
         r["gpu_ms_per_step"] = round(r["ms_per_step"] * r["cu_share"], 4)
-    dom = max((r for r in shapes if r["algorithmic_mflop_per_launch"] > 0 and r["kind"] != "conv3x3"), key=lambda r: r["gpu_ms_per_step"], default=None)
-    out["roofline"] = roofline_entry(dom, args.operand)
+    dom, fam_ms = dominant_by_time(shapes)
+    out["roofline"] = roofline_entry(dom, args.operand, fam_ms)
     out["roofline_shapes"] = shapes[:24]
     out["hat_ms_per_step"] = round(sum(r["ms_per_step"] for r in hat), 4)
     out["kernel_ms_per_step_serialized"] = round(sum(r["ms_per_step"] for r in shapes), 4)
@@ -426,7 +499,7 @@ def main():
         starts = [sum(sizes[:i]) for i in range(len(sizes))]
         idx = [s + j for s, n in zip(starts, sizes) for j in range(min(8, n))]
         parity, _ = parity_vs_oracle(cfg, logits_gpu, arch, idx, f"CPU oracle fp32; 8 images from each of the {len(sizes)} stream shards (shard starts {starts})")
-        parity["weights"] = "random init (seed 0)"
+        parity["weights"] = f"tests/synth.py family 'init', seed {WEIGHT_SEED} (reference init + gamma ~ U(0.5,1.5), BN statistics, biases)"
         parity["tolerance"] = "north_star: logits max-abs < 1e-3"
         # the other 16-bit operand type on the same images (eager, same plan): reported, not timed
         other = "bf16" if args.operand == "f16" else "f16"

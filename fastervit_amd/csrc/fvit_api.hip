@@ -73,11 +73,17 @@ struct ProfRec {
     int grid;
     char name[40];
 };
+std::recursive_mutex& diag_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+typedef std::lock_guard<std::recursive_mutex> DiagLock;
 static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_events;  // 2 per record
 static std::vector<ProfRec> g_recs;
 
 ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t stream) : slot_(-1), stream_(stream) {
+    DiagLock lock(diag_mutex());
     dbg_poison_before_launch(stream);   // no-op unless fvit_debug_poison_launches(sink != null) is active
     if (!g_prof_on) return;
     slot_ = (int)g_recs.size();
@@ -91,10 +97,12 @@ ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t stream) :
 }
 
 ProfScope::~ProfScope() {
-    if (slot_ >= 0) hipEventRecord(g_events[2 * slot_ + 1], stream_);
+    DiagLock lock(diag_mutex());
+    if (slot_ >= 0 && 2 * slot_ + 1 < (int)g_events.size()) hipEventRecord(g_events[2 * slot_ + 1], stream_);
 }
 
 void prof_note(const char* kernel, int grid) {
+    DiagLock lock(diag_mutex());
     if (!g_prof_on || g_recs.empty()) return;
     ProfRec& r = g_recs.back();
     r.grid = grid;
@@ -117,9 +125,9 @@ struct StageLayout {
 static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
     if (d.batch <= 0 || d.C <= 0 || d.heads <= 0 || d.C % d.heads || d.ws <= 0 || d.Hp % d.ws || d.Wp % d.ws ||
         (d.dpad != 32 && d.dpad != 64 && d.dpad != 96) || d.dpad < d.C / d.heads || d.hidden <= 0 || (d.C % 16) || (d.hidden % 16) ||
-        (d.operand_dtype != FVIT_F16 && d.operand_dtype != FVIT_BF16) || (d.hier && d.cw <= 0)) {
-        set_error("stage descriptor rejected: batch=%d C=%d heads=%d dpad=%d ws=%d Hp=%d Wp=%d hidden=%d hier=%d cw=%d dtype=%d",
-                  d.batch, d.C, d.heads, d.dpad, d.ws, d.Hp, d.Wp, d.hidden, d.hier, d.cw, d.operand_dtype);
+        (d.operand_dtype != FVIT_F16 && d.operand_dtype != FVIT_BF16) || (d.hier && d.cw <= 0) || (d.weight_terms != 1 && d.weight_terms != 2)) {
+        set_error("stage descriptor rejected: batch=%d C=%d heads=%d dpad=%d ws=%d Hp=%d Wp=%d hidden=%d hier=%d cw=%d dtype=%d weight_terms=%d",
+                  d.batch, d.C, d.heads, d.dpad, d.ws, d.Hp, d.Wp, d.hidden, d.hier, d.cw, d.operand_dtype, d.weight_terms);
         return false;
     }
     L.nW = (d.Hp / d.ws) * (d.Wp / d.ws);
@@ -171,20 +179,22 @@ static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
 // resident operand panel needs 96-128 KiB of LDS per workgroup, so no other stream shard's kernel can share the CU with it -- and
 // that co-residency is what the stream shards' gain comes from (profiles/r02_ln_gemm_ab.log)
 static bool use_ln_gemm(const FvitStageDesc& d, int N, int ldw, int ldo, int64_t rows) {
-    return ln_gemm_supported(d.C, N, ldw, ldo) && tune_get("ln_gemm", 0) && rows <= tune_get("ln_gemm_max_rows", 16384);
+    return d.weight_terms == 1 && ln_gemm_supported(d.C, N, ldw, ldo) && tune_get("ln_gemm", 0) && rows <= tune_get("ln_gemm_max_rows", 16384);
 }
 
 // LN -> qkv -> attention -> proj + gamma-residual, on `rows` rows of the f32 stream `x`
 static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttnWeights& w, float* x, int64_t rows, void* xn,
                     void* qkv, void* ao, int nwin, int S, bool ln_done, hipStream_t st, bool qkv_done = false) {
     const int dt = d.operand_dtype;
+    const int T = d.weight_terms;   // K-concatenated weight terms: the GEMMs run K = T x ld against the same activation columns
     if (!ln_done && !qkv_done) {
         LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
         FVIT_TRY(launch_gather_layernorm(ln, st));
     }
     dbg_rowhash("attn.xn", xn, rows, L.ldn * 2, st);
     if (!qkv_done) {
-        GemmCall g1 = {dt, xn, L.ldn, w.w_qkv, L.ldn, w.b_qkv, nullptr, qkv, L.ldqkv, (int)rows, L.ldqkv, L.ldn, 0};
+        GemmCall g1 = {dt, xn, L.ldn, w.w_qkv, T * L.ldn, w.b_qkv, nullptr, qkv, L.ldqkv, (int)rows, L.ldqkv, T * L.ldn, 0};
+        g1.ka = L.ldn;
         FVIT_TRY(launch_gemm(g1, st));
     }
     dbg_rowhash("attn.qkv", qkv, rows, L.ldqkv * 2, st);
@@ -192,7 +202,8 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
     AttnCall at = {dt, qkv, L.ldqkv, ao, L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale, w.rel_table, w.rel_w, w.rel_ng, d.C / d.heads};
     FVIT_TRY(launch_attention(at, st));
     dbg_rowhash("attn.ao", ao, rows, L.ldao * 2, st);
-    GemmCall g2 = {dt, ao, L.ldao, w.w_proj, L.ldao, w.b_proj, w.gamma, x, d.C, (int)rows, d.C, L.ldao, 2};
+    GemmCall g2 = {dt, ao, L.ldao, w.w_proj, T * L.ldao, w.b_proj, w.gamma, x, d.C, (int)rows, d.C, T * L.ldao, 2};
+    g2.ka = L.ldao;
     FVIT_TRY(launch_gemm(g2, st));
     dbg_rowhash("attn.out", x, rows, d.C * 4, st);
     return FVIT_OK;
@@ -203,7 +214,7 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
 // C = 512 / 16 heads (stage 3): the fused instance is correct but loses end to end (66.0k vs 71.9k images/s, r01 sweep r41): one
 // workgroup per 49-token window streams 2 MiB of weights for 49 rows => opt-in (attn_fused512_min_rows)
 static bool fused_attn_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S, int64_t rows) {
-    return w.w_qkv_frag && w.b_qkv_heads && w.w_proj_frag && d.dpad == 32 && d.C / d.heads == 32 && attnblk_supported(d.C, d.heads, S) &&
+    return d.weight_terms == 1 && w.w_qkv_frag && w.b_qkv_heads && w.w_proj_frag && d.dpad == 32 && d.C / d.heads == 32 && attnblk_supported(d.C, d.heads, S) &&
            rows >= (d.C == 256 ? tune_get("attn_fused_min_rows", 16384) : tune_get("attn_fused512_min_rows", 1 << 30)) && tune_get("attn_fused", 1);
 }
 
@@ -221,6 +232,7 @@ static bool win_mlp_ok(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t 
 }
 
 static bool mlp_takes_fused_kernel(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t rows) {
+    if (d.weight_terms != 1) return false;
     const int64_t fused_min = d.C == 256 ? tune_get("mlp_fused_min_rows", 16384) : tune_get("mlp_fused512_min_rows", 1 << 30);
     return w.w_fc1_frag && w.w_fc2_frag && mlp_fused_supported(d.C, d.hidden) && rows >= fused_min && tune_get("mlp_fused", 1);
 }
@@ -228,6 +240,7 @@ static bool mlp_takes_fused_kernel(const FvitStageDesc& d, const FvitMlpWeights&
 static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWeights& w, float* x, int64_t rows, void* xn, void* h,
                    hipStream_t st, const NextPe* next_pe = nullptr) {
     const int dt = d.operand_dtype;
+    const int T = d.weight_terms;
     // the fused kernel streams all MLP weights per 128-row workgroup: it wins once the launch fills the chip
     // (>= ~16k rows; 104 vs 137 us at 54k rows) and loses on the latency-bound carrier branch (4k rows: 83 vs 31 us)
     // C = 512 (stage 3): the fused instance is correct but slower than LN + 2 GEMMs at these row counts (65-196 workgroups, each
@@ -235,7 +248,7 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
     if (win_mlp_ok(d, w, rows)) {
         // C = 512 (stage 3 of FasterViT-0): 64-row workgroups whose waves split hidden units / output channels (fvit_winmlp.hip)
         if (next_pe && next_pe->add) { set_error("internal: position-embedding pre-add requested on the fused MLP path"); return FVIT_EINVAL; }
-        MlpFusedCall mc = {dt, x, (int)rows, d.C, d.hidden, w.ln_w, w.ln_b, 1e-5f, w.w_fc1_frag, w.b_fc1, w.w_fc2_frag, w.b_fc2, w.gamma};
+        MlpFusedCall mc = {dt, x, (int)rows, d.C, d.hidden, w.ln_w, w.ln_b, 1e-5f, w.w_fc1_frag, w.b_fc1, w.w_fc2_frag, w.b_fc2, w.gamma, T};
         FVIT_TRY(launch_winmlp(mc, st));
         dbg_rowhash("winmlp.out", x, rows, d.C * 4, st);
         return FVIT_OK;
@@ -255,11 +268,13 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
         FVIT_TRY(launch_ln_gemm(lg, st));
     } else {
         FVIT_TRY(launch_gather_layernorm(ln, st));
-        GemmCall g1 = {dt, xn, L.ldn, w.w_fc1, L.ldn, w.b_fc1, nullptr, h, L.ldh, (int)rows, d.hidden, L.ldn, 1};
+        GemmCall g1 = {dt, xn, L.ldn, w.w_fc1, T * L.ldn, w.b_fc1, nullptr, h, L.ldh, (int)rows, d.hidden, T * L.ldn, 1};
+        g1.ka = L.ldn;
         FVIT_TRY(launch_gemm(g1, st));
     }
     dbg_rowhash("mlp.h", h, rows, L.ldh * 2, st);
-    GemmCall g2 = {dt, h, L.ldh, w.w_fc2, L.ldh, w.b_fc2, w.gamma, x, d.C, (int)rows, d.C, L.ldh, 2};
+    GemmCall g2 = {dt, h, L.ldh, w.w_fc2, T * L.ldh, w.b_fc2, w.gamma, x, d.C, (int)rows, d.C, T * L.ldh, 2};
+    g2.ka = L.ldh;
     if (next_pe && next_pe->add) { g2.add = next_pe->add; g2.add_idx = next_pe->add_idx; g2.rows_per_image = next_pe->rows_per_image; }
     FVIT_TRY(launch_gemm(g2, st));
     dbg_rowhash("mlp.out", x, rows, d.C * 4, st);
@@ -271,7 +286,7 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
 // qkv GEMM.  Same two fp32 additions in the same order as the separate kernel (bitwise the same residual stream).
 // C = 512 (stage 3 of FasterViT-0): the attention sub-block with the waves of a window splitting heads / output channels (fvit_winblk.hip)
 static bool win_fused_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S) {
-    if (!winblk_supported(d.C, d.heads, S) || d.dpad != 32 || !w.w_qkv_frag || !w.b_qkv_heads || !w.w_proj_frag || !w.bias) return false;
+    if (d.weight_terms != 1 || !winblk_supported(d.C, d.heads, S) || d.dpad != 32 || !w.w_qkv_frag || !w.b_qkv_heads || !w.w_proj_frag || !w.bias) return false;
     return d.C == 512 ? tune_get("win_fused", 1) != 0 : tune_get("win_fused256", 0) != 0;   // C = 256: the 4-wave form, two workgroups per CU
 }
 
@@ -297,7 +312,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         void* RH = ws + L.off_RH;
         const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
         bool ct_done = false;
-        if (ctblk_supported(d.C, d.heads, L.G, d.hidden) && d.dpad == 32 && w.hat_attn.w_qkv_frag && w.hat_attn.b_qkv_heads && w.hat_attn.w_proj_frag &&
+        if (d.weight_terms == 1 && ctblk_supported(d.C, d.heads, L.G, d.hidden) && d.dpad == 32 && w.hat_attn.w_qkv_frag && w.hat_attn.b_qkv_heads && w.hat_attn.w_proj_frag &&
             w.hat_attn.bias && w.hat_mlp.w_fc1_frag && w.hat_mlp.w_fc2_frag && tune_get("ct_fused", 1)) {
             // the whole carrier-token branch (AR:679-686) in one kernel, one workgroup per image
             CtBlkCall cb = {dt, X, rpi, t.ct_src, (d.square ? w.pe_ct : nullptr), R, d.batch, L.G, d.heads, d.C, d.hidden,
@@ -511,6 +526,14 @@ int fvit_gemm_residual(int32_t operand_dtype, const void* A, int32_t lda, const 
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+int fvit_gemm_terms(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias, const float* gamma,
+                    void* out, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t ka, int32_t epilogue, fvit_stream_t stream) {
+    if (epilogue < 0 || epilogue > 2) { set_error("gemm_terms: epilogue %d", epilogue); return FVIT_EINVAL; }
+    GemmCall g = {operand_dtype, A, lda, Wt, ldw, bias, epilogue == 2 ? gamma : nullptr, out, ldo, M, N, K, epilogue};
+    g.ka = ka;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
 int fvit_window_attention(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, const float* bias,
                           int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale, fvit_stream_t stream) {
     if (!attention_dense(S, dpad)) {
@@ -569,6 +592,13 @@ int fvit_win_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, in
     return launch_winmlp(mc, (hipStream_t)stream);
 }
 
+int fvit_win_mlp_fused_terms(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,
+                             float eps, const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2,
+                             const float* gamma, int32_t terms, fvit_stream_t stream) {
+    MlpFusedCall mc = {operand_dtype, x, M, C, hidden, ln_w, ln_b, eps, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma, terms};
+    return launch_winmlp(mc, (hipStream_t)stream);
+}
+
 int fvit_win_block_supported(int32_t C, int32_t heads, int32_t S) { return winblk_supported(C, heads, S) ? 1 : 0; }
 
 int fvit_win_block_fused(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
@@ -610,6 +640,7 @@ int fvit_tune(const char* key, int32_t value) {
 }
 
 int fvit_prof_enable(int on) {
+    DiagLock lock(diag_mutex());
     g_prof_on = on != 0;
     if (g_prof_on) g_recs.clear();
     return FVIT_OK;
@@ -617,6 +648,7 @@ int fvit_prof_enable(int on) {
 
 int fvit_prof_collect(FvitProfEntry* out) {
     if (!out) return FVIT_EINVAL;
+    DiagLock lock(diag_mutex());
     memset(out, 0, sizeof(FvitProfEntry) * FVIT_PROF_KINDS);
     for (size_t i = 0; i < g_recs.size(); ++i) {
         float ms = 0.f;
@@ -638,6 +670,7 @@ int fvit_prof_collect(FvitProfEntry* out) {
 
 int fvit_prof_records(FvitProfRecord* out, int32_t max_records) {
     if (!out || max_records < 0) return FVIT_EINVAL;
+    DiagLock lock(diag_mutex());
     int n = 0;
     for (size_t i = 0; i < g_recs.size() && n < max_records; ++i, ++n) {
         float ms = 0.f;

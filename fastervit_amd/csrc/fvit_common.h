@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <mutex>
 #include <stdio.h>
 
 #include "../../include/fvit_hip.h"
@@ -144,6 +145,11 @@ int check_launch(const char* what);
 // ---- tuning knobs (A/B experiments inside one process; see fvit_tune in fvit_hip.h) ----
 int tune_get(const char* key, int dflt);
 
+// ---- diagnostics state (kernel timer records, row-hash / MLP traces, poison sink) is process-global: every access -- including
+// the ones inside ProfScope, i.e. on every launch -- takes this mutex, so that host threads driving different devices / streams
+// (nn.DataParallel replicas) may launch while a profile or a trace is being recorded.  Uncontended cost: one atomic per launch.
+std::recursive_mutex& diag_mutex();
+
 // ---- built-in kernel timer ----
 struct ProfScope {
     ProfScope(int kind, double flops, double bytes, hipStream_t stream);
@@ -176,6 +182,9 @@ struct GemmCall {
     const float* add = nullptr;
     const int32_t* add_idx = nullptr;
     int rows_per_image = 1;
+    // K-concatenated weight terms (FvitStageDesc.weight_terms): the weight rows hold K columns = terms x ka, the activation rows ka
+    // columns that are re-used for every term (column k of the contraction reads A column k mod ka).  0 = K.
+    int ka = 0;
 };
 int launch_gemm(const GemmCall& c, hipStream_t stream);
 
@@ -191,6 +200,7 @@ struct MlpFusedCall {
     const void* w2f;  // fragment-major fc2 weight
     const float* b2;
     const float* gamma;
+    int terms = 1;    // weight terms (1, or 2 = [hi image | lo image]); fvit_winmlp.hip only
 };
 bool mlp_fused_supported(int C, int hidden);
 int launch_mlp_fused(const MlpFusedCall& c, hipStream_t stream);

@@ -37,6 +37,7 @@ struct GemmParams {
     void* out;
     int lda, ldw, ldo;
     int M, N, K;
+    int ka;       // activation columns; the contraction index k reads A column k mod ka (K = terms x ka, see GemmCall)
     int tiles_m, tiles_n;
     int stagger;  // 1: workgroup (tm, tn) walks the K tiles starting at a tile-dependent offset (see gemm_kernel)
     const float* add;        // residual epilogue: optional row table added after the update (see GemmCall)
@@ -125,12 +126,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
         rot = (tn * per + tm) % nk;
     }
     auto ktile = [&](int kt) { const int k = kt + rot; return k >= nk ? k - nk : k; };
+    auto acol = [&](int kt) { const int k = ktile(kt) * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1 or 2 x ka
     char* const xring = smem;
     char* const wring = smem + NSTAGE * XT_BYTES;
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st) {
         if (st < nk) {
-            stage_tile<T, false, BMT, NW>(A, p.lda, m0, ktile(st) * BK, xring + st * XT_BYTES, wave, lane);
+            stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(st), xring + st * XT_BYTES, wave, lane);
             stage_tile<T, true, 128, NW>(W, p.ldw, n0, ktile(st) * BK, wring + st * TILE_BYTES, wave, lane);
         }
     }
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             int slot = cur + NSTAGE - 1;
             if (slot >= NSTAGE) slot -= NSTAGE;
             if (nxt < nk) {
-                stage_tile<T, false, BMT, NW>(A, p.lda, m0, ktile(nxt) * BK, xring + slot * XT_BYTES, wave, lane);
+                stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(nxt), xring + slot * XT_BYTES, wave, lane);
                 stage_tile<T, true, 128, NW>(W, p.ldw, n0, ktile(nxt) * BK, wring + slot * TILE_BYTES, wave, lane);
             }
         }
@@ -262,6 +264,7 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.A = c.A; p.W = c.W; p.bias = c.bias; p.gamma = c.gamma; p.out = c.out;
     p.lda = c.lda; p.ldw = c.ldw; p.ldo = c.ldo;
     p.M = c.M; p.N = c.N; p.K = c.K;
+    p.ka = c.ka > 0 ? c.ka : c.K;
     p.tiles_n = (c.N + BN - 1) / BN;
     p.stagger = tune_get("gemm_stagger", 0);
     p.add = c.epilogue == 2 ? c.add : nullptr;
@@ -276,8 +279,8 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     const bool small = grid128 <= bm64_max;   // 64-row tiles
     p.tiles_m = small ? (c.M + 63) / 64 : (c.M + 127) / 128;
     const int grid = p.tiles_m * p.tiles_n;
-    const double flops = 2.0 * c.M * (double)c.N * c.K;
-    double bytes = 2.0 * c.M * (double)c.K + 2.0 * c.N * (double)c.K;  // operands once
+    const double flops = 2.0 * c.M * (double)c.N * p.ka;   // algorithmic: the extra weight terms are a precision cost, not work
+    double bytes = 2.0 * c.M * (double)p.ka + 2.0 * c.N * (double)c.K;  // operands once
     int kind;
     if (c.epilogue == 2) {
         bytes += 8.0 * c.M * (double)c.N;  // fp32 residual read + write
@@ -313,7 +316,8 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
 
 int launch_gemm(const GemmCall& c, hipStream_t stream) {
     if (c.M <= 0 || c.N <= 0 || c.K <= 0 || (c.K % BK) != 0 || (c.N % 16) != 0 || (c.lda % 8) != 0 ||
-        (c.ldw % 8) != 0 || (c.ldo % (c.epilogue == 2 ? 4 : 8)) != 0 || c.lda < c.K || c.ldw < c.K) {
+        (c.ldw % 8) != 0 || (c.ldo % (c.epilogue == 2 ? 4 : 8)) != 0 || c.ldw < c.K ||
+        (c.ka > 0 ? (c.ka % BK != 0 || (c.K != c.ka && c.K != 2 * c.ka) || c.lda < c.ka) : c.lda < c.K)) {
         set_error("gemm: unsupported shape M=%d N=%d K=%d lda=%d ldw=%d ldo=%d (need K%%64==0, N%%16==0)", c.M, c.N,
                   c.K, c.lda, c.ldw, c.ldo);
         return FVIT_EINVAL;

@@ -263,6 +263,7 @@ namespace fvit {
 struct DbgTrace { unsigned* buf = nullptr; long long cap = 0, used = 0; int nrec = 0; int ndump = 0; int dump_rec[64]; void* dump_dst[64]; long long dump_cap[64]; FvitDebugRowhashRecord rec[FVIT_DEBUG_MAX_RECORDS]; };
 static DbgTrace g_dbg;
 void dbg_rowhash(const char* tag, const void* ptr, long long rows, int row_bytes, hipStream_t st) {
+    std::lock_guard<std::recursive_mutex> lock(diag_mutex());
     if (!g_dbg.buf || !ptr || rows <= 0) return;
     if (g_dbg.nrec >= FVIT_DEBUG_MAX_RECORDS || g_dbg.used + rows > g_dbg.cap) return;
     FvitDebugRowhashRecord& r = g_dbg.rec[g_dbg.nrec++];
@@ -280,6 +281,7 @@ namespace fvit {
 static unsigned* g_poison_sink = nullptr;
 static unsigned g_poison_pattern = 0;
 void dbg_poison_before_launch(hipStream_t st) {
+    std::lock_guard<std::recursive_mutex> lock(diag_mutex());
     if (!g_poison_sink) return;
     hipLaunchKernelGGL(regs_poison_kernel, dim3(2048), dim3(64), 40 * 1024, st, g_poison_sink, 64, g_poison_pattern);
 }
@@ -287,14 +289,17 @@ void dbg_poison_before_launch(hipStream_t st) {
 
 extern "C" {
 int fvit_debug_poison_launches(void* sink, uint32_t pattern) {
+    std::lock_guard<std::recursive_mutex> lock(fvit::diag_mutex());
     fvit::g_poison_sink = (unsigned*)sink; fvit::g_poison_pattern = pattern;
     return FVIT_OK;
 }
 int fvit_debug_rowhash_begin(void* buf, int64_t capacity_words) {
+    std::lock_guard<std::recursive_mutex> lock(fvit::diag_mutex());
     fvit::g_dbg.buf = (unsigned*)buf; fvit::g_dbg.cap = capacity_words; fvit::g_dbg.used = 0; fvit::g_dbg.nrec = 0;
     return FVIT_OK;
 }
 int fvit_debug_rowhash_dump(int32_t record, void* dst, int64_t capacity_bytes) {
+    std::lock_guard<std::recursive_mutex> lock(fvit::diag_mutex());
     if (record < 0) { fvit::g_dbg.ndump = 0; return FVIT_OK; }
     if (fvit::g_dbg.ndump >= 64) { set_error("debug_rowhash_dump: at most 64 records"); return FVIT_EINVAL; }
     const int i = fvit::g_dbg.ndump++;
@@ -302,6 +307,7 @@ int fvit_debug_rowhash_dump(int32_t record, void* dst, int64_t capacity_bytes) {
     return FVIT_OK;
 }
 int fvit_debug_rowhash_end(FvitDebugRowhashRecord* out, int32_t max_records) {
+    std::lock_guard<std::recursive_mutex> lock(fvit::diag_mutex());
     int n = fvit::g_dbg.nrec < max_records ? fvit::g_dbg.nrec : max_records;
     for (int i = 0; i < n && out; ++i) out[i] = fvit::g_dbg.rec[i];
     fvit::g_dbg.buf = nullptr;

@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256) void head_xent_loss_kernel(const float* __rest
     if (lane == 0) {
         const float lse = m + __logf(se);
         const int64_t t = target[b];
-        const float nll = lse - x[t];                 // -log p_t
+        // a label outside [0, N) (torch's cross_entropy asserts on it): no out-of-bounds read, and the row's loss -- hence the
+        // step's loss and the whole [dW | db | loss] buffer's last entry -- becomes NaN instead of a silently wrong number
+        const bool t_ok = t >= 0 && t < (int64_t)N;
+        const float nll = t_ok ? lse - x[t] : __builtin_nanf("");   // -log p_t
         const float smooth = lse - sx / (float)N;     // mean_n(-log p_n)
         loss_rows[b] = (1.0f - smoothing) * nll + smoothing * smooth;
         row_stats[2 * b] = m;

@@ -421,6 +421,7 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
     p.ablate = tune_get("mlp_ablate", 0);
     p.dbg = nullptr;
     p.dbgx = nullptr;
+    std::lock_guard<std::recursive_mutex> dlock(diag_mutex());   // trace bookkeeping + the timer record of this launch
     if (g_mdbg.xbuf && c.C == 256 && g_mdbg.nx < 64 && g_mdbg.xused + (long long)c.M * c.C <= g_mdbg.xcap) {
         p.dbgx = g_mdbg.xbuf + g_mdbg.xused;
         g_mdbg.xoff[g_mdbg.nx] = g_mdbg.xused;
@@ -506,20 +507,24 @@ extern "C" {
 /* diagnosis: while active, every default-variant C = 256 fused-MLP launch writes per-lane hashes of its intermediate state (see dq in the
  * kernel) to consecutive slices of buf; _end returns the number of traced launches with their slice offsets (words) and row counts */
 int fvit_debug_mlp_trace_begin(void* buf, int64_t capacity_words) {
+    std::lock_guard<std::recursive_mutex> lock(fvit::diag_mutex());
     fvit::g_mdbg.buf = (unsigned*)buf; fvit::g_mdbg.cap = capacity_words; fvit::g_mdbg.used = 0; fvit::g_mdbg.nlaunch = 0;
     return FVIT_OK;
 }
 int fvit_debug_mlp_inputs_begin(void* buf, int64_t capacity_floats) {
+    std::lock_guard<std::recursive_mutex> lock(fvit::diag_mutex());
     fvit::g_mdbg.xbuf = (float*)buf; fvit::g_mdbg.xcap = capacity_floats; fvit::g_mdbg.xused = 0; fvit::g_mdbg.nx = 0;
     return FVIT_OK;
 }
 int fvit_debug_mlp_inputs_end(int64_t* offsets, int32_t* rows, int32_t max_launches) {
+    std::lock_guard<std::recursive_mutex> lock(fvit::diag_mutex());
     const int n = fvit::g_mdbg.nx < max_launches ? fvit::g_mdbg.nx : max_launches;
     for (int i = 0; i < n; ++i) { if (offsets) offsets[i] = fvit::g_mdbg.xoff[i]; if (rows) rows[i] = fvit::g_mdbg.xrows[i]; }
     fvit::g_mdbg.xbuf = nullptr;
     return n;
 }
 int fvit_debug_mlp_trace_end(int64_t* offsets, int32_t* rows, int32_t max_launches) {
+    std::lock_guard<std::recursive_mutex> lock(fvit::diag_mutex());
     const int n = fvit::g_mdbg.nlaunch < max_launches ? fvit::g_mdbg.nlaunch : max_launches;
     for (int i = 0; i < n; ++i) { if (offsets) offsets[i] = fvit::g_mdbg.off[i]; if (rows) rows[i] = fvit::g_mdbg.rows[i]; }
     fvit::g_mdbg.buf = nullptr;

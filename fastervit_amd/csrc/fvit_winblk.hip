@@ -337,7 +337,7 @@ int launch_winblk(const AttnBlkCall& c, hipStream_t stream) {
     }
     WinBlkParams p;
     p.srcA = c.srcA; p.srcB = c.srcB; p.src_idx = c.src_idx; p.add_idx = c.add_idx; p.add = c.add; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.eps = c.eps;
-    p.rowsA = c.rowsA; p.rowsB = c.rowsB; p.rows_per_image = c.rows_per_image;
+    p.rowsA = c.rowsA; p.rowsB = c.rowsB; p.rows_per_image = c.rows_per_image > 0 ? c.rows_per_image : 1;
     p.wqkv_f = c.wqkv_f; p.bqkv = c.bqkv; p.wproj_f = c.wproj_f; p.bproj = c.bproj; p.gamma = c.gamma; p.bias = c.bias; p.x_out = c.x_out;
     p.nwin = c.nwin; p.S = c.S; p.scale = c.scale;
     const double rows = (double)c.nwin * c.S;

@@ -45,7 +45,10 @@ struct WinMlpParams {
 
 // CC / HID: channels / hidden units; NRB: row blocks of 16 per workgroup (4: 64 rows, C = 512; 8: 128 rows, C = 256)
 // NWV: waves per workgroup (8: one workgroup per CU; 4: 256 registers per wave and <= 70 KiB of LDS, two workgroups per CU whose phases interleave)
-template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8>
+// SP: weight terms (FvitStageDesc.weight_terms).  SP = 2: w1f / w2f are two images back to back (hi, lo); every weight step runs once
+// per term against the SAME activation fragments (hi steps first, then lo), so the hidden activation and the output accumulate
+// X . (W_hi + W_lo) with X rounded once -- twice the weight stream and twice the MFMAs, nothing else changes.
+template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinMlpParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int C = CC, KK = C / 32, CB = C / 16, NW = NWV;
@@ -54,7 +57,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
     constexpr int F1S = 2 * KK / 8;                // fc1 steps of 8 fragments per chunk: 4 k steps x 2 unit blocks each
     constexpr int CPS = 8 / CBW;                   // chunks per fc2 step of 8 fragments
     constexpr int F2S = NW / CPS;                  // fc2 steps per super-chunk
-    constexpr int SPS = F1S + F2S;                 // steps per super-chunk (8 / 4)
+    constexpr int F1T = SP * F1S, F2T = SP * F2S;  // ... times the weight terms
+    constexpr int SPS = F1T + F2T;                 // steps per super-chunk (8 / 4 per term)
+    constexpr size_t WBYTES = (size_t)HID * C * 2; // one fragment-order image of fc1 (= of fc2)
     static_assert(SPS % DEPTH == 0, "ring slots must be static inside the super-chunk loop");
     constexpr int WPR = NW / NRB;                  // waves sharing a row block in the LayerNorm phase (2 / 1)
     constexpr int HBUF = (NRB * KK + 2 * NW * NRB) * 1024 + HID * 4 <= (NW == 8 ? 150 : 72) * 1024 ? 2 : 1;   // H double-buffered when it fits
@@ -77,12 +82,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
     // super-chunk is SPS steps and DEPTH divides SPS, so the slot of step SPS sc + u is u % DEPTH)
     auto issue = [&](int sc, int u, int slot) {
         if (sc < NSC) {
-            if (u < F1S) {    // fc1: chunk 8 sc + wave, k steps 4u .. 4u + 3, slot (kk - 4u) * 2 + hb
-                const char* b = W1 + (size_t)(sc * NW + wave) * 2 * KK * 1024;
+            if (u < F1T) {    // fc1, term u / F1S: chunk 8 sc + wave, k steps 4uu .. 4uu + 3 (uu = u % F1S), slot (kk - 4uu) * 2 + hb
+                const int uu = u % F1S;
+                const char* b = W1 + (size_t)(u / F1S) * WBYTES + (size_t)(sc * NW + wave) * 2 * KK * 1024;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ring[slot][i] = *(const v8*)(b + ((i & 1) * KK + 4 * u + (i >> 1)) * 1024);
-            } else {          // fc2: chunks 8 sc + CPS (u - F1S) + c, channel blocks CBW wave + q, slot c * CBW + q
-                const char* b = W2 + ((size_t)(sc * NW + CPS * (u - F1S)) * CB + CBW * wave) * 1024;
+                for (int i = 0; i < 8; ++i) ring[slot][i] = *(const v8*)(b + ((i & 1) * KK + 4 * uu + (i >> 1)) * 1024);
+            } else {          // fc2, term (u - F1T) / F2S: chunks 8 sc + CPS vv + c (vv = (u - F1T) % F2S), channel blocks CBW wave + q, slot c * CBW + q
+                const int vv = (u - F1T) % F2S;
+                const char* b = W2 + (size_t)((u - F1T) / F2S) * WBYTES + ((size_t)(sc * NW + CPS * vv) * CB + CBW * wave) * 1024;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ring[slot][i] = *(const v8*)(b + ((i / CBW) * CB + (i % CBW)) * 1024);
             }
@@ -162,12 +169,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) acc1[hb][rb] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < F1S; ++u) {
+        for (int u = 0; u < F1T; ++u) {
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
                 v8 xb[NRB];
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) xb[rb] = *(const v8*)(xn + (rb * KK + 4 * u + k4) * 1024);
+                for (int rb = 0; rb < NRB; ++rb) xb[rb] = *(const v8*)(xn + (rb * KK + 4 * (u % F1S) + k4) * 1024);
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -195,12 +202,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
         // ---- C: out^T[this wave's channels][rows] += W2[:, chunk] . H^T over the 8 chunks ----
         const char* hr = smem + OFF_H + hbuf * NW * NRB * 1024 + lane16;
 #pragma unroll
-        for (int u = F1S; u < SPS; ++u) {
+        for (int u = F1T; u < SPS; ++u) {
 #pragma unroll
             for (int c = 0; c < CPS; ++c) {
                 v8 hb4[NRB];
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) hb4[rb] = *(const v8*)(hr + ((CPS * (u - F1S) + c) * NRB + rb) * 1024);
+                for (int rb = 0; rb < NRB; ++rb) hb4[rb] = *(const v8*)(hr + ((CPS * ((u - F1T) % F2S) + c) * NRB + rb) * 1024);
 #pragma unroll
                 for (int q = 0; q < CBW; ++q)
 #pragma unroll
@@ -253,16 +260,19 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     const int grid = (c.M + rows_per_wg - 1) / rows_per_wg;
     prof_note(c.C == 512 ? "winmlp_kernel<512>" : "winmlp_kernel<256>", grid);
     if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_mlp: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
-    if (c.C == 512) {
-        if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 512, 2048, 4, 2>), dim3(grid), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((winmlp_kernel<__bf16, 512, 2048, 4, 2>), dim3(grid), dim3(512), 0, stream, p);
-    } else {
-        if (small) {
-            if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 256, 1024, 4, 2, 4>), dim3(grid), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((winmlp_kernel<__bf16, 256, 1024, 4, 2, 4>), dim3(grid), dim3(256), 0, stream, p);
-        } else if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winmlp_kernel<_Float16, 256, 1024, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((winmlp_kernel<__bf16, 256, 1024, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
-    }
+    if (c.terms != 1 && c.terms != 2) { set_error("win_mlp: weight terms %d not supported", c.terms); return FVIT_EINVAL; }
+#define FVIT_WINMLP(T, CC_, HID_, NRB_, NWV_, SP_) \
+    hipLaunchKernelGGL((winmlp_kernel<T, CC_, HID_, NRB_, 2, NWV_, SP_>), dim3(grid), dim3(64 * NWV_), 0, stream, p)
+#define FVIT_WINMLP_T(CC_, HID_, NRB_, NWV_)                                                     \
+    do {                                                                                         \
+        if (c.dtype == FVIT_F16) { if (c.terms == 2) FVIT_WINMLP(_Float16, CC_, HID_, NRB_, NWV_, 2); else FVIT_WINMLP(_Float16, CC_, HID_, NRB_, NWV_, 1); } \
+        else { if (c.terms == 2) FVIT_WINMLP(__bf16, CC_, HID_, NRB_, NWV_, 2); else FVIT_WINMLP(__bf16, CC_, HID_, NRB_, NWV_, 1); } \
+    } while (0)
+    if (c.C == 512) FVIT_WINMLP_T(512, 2048, 4, 8);
+    else if (small) FVIT_WINMLP_T(256, 1024, 4, 4);
+    else FVIT_WINMLP_T(256, 1024, 8, 8);
+#undef FVIT_WINMLP_T
+#undef FVIT_WINMLP
     return check_launch("winmlp_kernel");
 }
 

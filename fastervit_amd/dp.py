@@ -28,6 +28,38 @@ def init_process_group(backend: str = "nccl"):
     return dist
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(script: str, argv, nproc: int, env: Optional[dict] = None) -> int:
+    """Re-execute ``script argv`` as ``nproc`` ranks of ONE node under ``torch.distributed.run`` (rendezvous on 127.0.0.1, a free
+    port), one process per GPU; returns the launcher's exit code.  Used by ``bench.py --gpus N`` when it is started as a plain
+    ``python bench.py`` (no WORLD_SIZE in the environment): the ranks are spawned here instead of silently running one."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(argv)
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL / cross-process tensor sharing)
+    e.setdefault("OMP_NUM_THREADS", "8")
+    e.update(env or {})
+    return subprocess.call(cmd, env=e)
+
+
+def ranks_that_ran(dist=None, device=None) -> int:
+    """Number of ranks that reached this point (SUM of ones over the process group; 1 without a group)."""
+    if dist is None:
+        return 1
+    import torch
+    t = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(t.item()))
+
+
 def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous, balanced split of ``n_items`` (strong-scaling use: one global batch over N GPUs)."""
     base, rem = divmod(n_items, world)

@@ -31,7 +31,11 @@ from ._lib import (FVIT_BF16, FVIT_F16, FVIT_F32, FVIT_MASK_BIAS, FVIT_TILE_K, F
                    FvitBlockWeights, FvitMapView, FvitMlpWeights, FvitStageDesc, FvitStageTables)
 
 _DT = {torch.float32: FVIT_F32, torch.float16: FVIT_F16, torch.bfloat16: FVIT_BF16}
-_OP = {"f16": (FVIT_F16, torch.float16), "bf16": (FVIT_BF16, torch.bfloat16)}
+# operand modes: (MFMA operand code, torch dtype, weight terms).  "x2" = every Linear weight packed as TWO 16-bit terms
+# (hi = round(w), lo = round(w - hi); FvitStageDesc.weight_terms): the route to logits max-abs < 1e-3 with bf16 operands.
+_OP = {"f16": (FVIT_F16, torch.float16, 1), "bf16": (FVIT_BF16, torch.bfloat16, 1),
+       "f16x2": (FVIT_F16, torch.float16, 2), "bf16x2": (FVIT_BF16, torch.bfloat16, 2)}
+OPERAND_MODES = tuple(_OP)
 
 
 def _rup(x: int, m: int) -> int:
@@ -113,9 +117,23 @@ class _Keep:
     """Holds packed device tensors alive and hands out their pointers (dtype / layout checked:
     the kernels reinterpret raw pointers, a silently down-cast table would be read out of bounds)."""
 
-    def __init__(self, op_dtype=None):
+    def __init__(self, op_dtype=None, terms: int = 1):
         self.tensors = []
         self.op_dtype = op_dtype
+        self.terms = terms
+
+    def op16(self, w: torch.Tensor, dim: int = -1) -> torch.Tensor:
+        """fp32 packed weight -> operand type; with 2 weight terms the hi and lo parts are concatenated along ``dim`` (the K
+        columns of a row-major array, or dim 0 of a flattened fragment-order image)."""
+        hi = w.to(self.op_dtype)
+        if self.terms == 1:
+            return hi.contiguous()
+        lo = (w - hi.float()).to(self.op_dtype)
+        return torch.cat([hi, lo], dim=dim).contiguous()
+
+    def frag16(self, w: torch.Tensor) -> torch.Tensor:
+        """fragment-order image(s): [hi image | lo image] back to back."""
+        return self.op16(w.reshape(1, -1), dim=0).reshape(-1)
 
     def ptr(self, t: Optional[torch.Tensor], op16: bool = False) -> Optional[int]:
         if t is None:
@@ -163,10 +181,10 @@ def pack_attention(attn, norm, gamma, S: int, dpad: int, op_dtype, keep: _Keep) 
     if d == 32 and lib.fvit_attn_block_supported(C_, h, S):
         wqkv32 = _f32(attn.qkv.weight)
         bqkv32 = _f32(attn.qkv.bias) if attn.qkv.bias is not None else torch.zeros(3 * C_, device=dev)
-        wqf = frag_pack_qkv(wqkv32, h).to(op_dtype)
+        wqf = keep.frag16(frag_pack_qkv(wqkv32, h))
         bqh = bqkv32.view(3, h, 32).permute(1, 0, 2).reshape(h, 96).contiguous()
-        wpf = frag_pack_fc2(_f32(attn.proj.weight)).to(op_dtype)   # chunks of 32 input columns = heads
-    return FvitAttnWeights(keep.ptr(wq.to(op_dtype), True), keep.ptr(bq), keep.ptr(wp.to(op_dtype), True), keep.ptr(_f32(attn.proj.bias)),
+        wpf = keep.frag16(frag_pack_fc2(_f32(attn.proj.weight)))   # chunks of 32 input columns = heads
+    return FvitAttnWeights(keep.ptr(keep.op16(wq), True), keep.ptr(bq), keep.ptr(keep.op16(wp), True), keep.ptr(_f32(attn.proj.bias)),
                            keep.ptr(bias), keep.ptr(_f32(norm.weight)), keep.ptr(_f32(norm.bias)), keep.ptr(_gamma(gamma)),
                            keep.ptr(wqf, True), keep.ptr(bqh), keep.ptr(wpf, True), keep.ptr(rel), rel_w, rel_ng)
 
@@ -192,9 +210,9 @@ def pack_mlp(mlp, norm, gamma, op_dtype, keep: _Keep) -> FvitMlpWeights:
     w2[:C_, :hid] = _f32(mlp.fc2.weight)
     w1f = w2f = None
     if _lib.lib().fvit_mlp_fused_supported(C_, hid):
-        w1f = frag_pack_fc1(_f32(mlp.fc1.weight)).to(op_dtype)
-        w2f = frag_pack_fc2(_f32(mlp.fc2.weight)).to(op_dtype)
-    return FvitMlpWeights(keep.ptr(w1.to(op_dtype), True), keep.ptr(_f32(mlp.fc1.bias)), keep.ptr(w2.to(op_dtype), True),
+        w1f = keep.frag16(frag_pack_fc1(_f32(mlp.fc1.weight)))
+        w2f = keep.frag16(frag_pack_fc2(_f32(mlp.fc2.weight)))
+    return FvitMlpWeights(keep.ptr(keep.op16(w1), True), keep.ptr(_f32(mlp.fc1.bias)), keep.ptr(keep.op16(w2), True),
                           keep.ptr(_f32(mlp.fc2.bias)), keep.ptr(_f32(norm.weight)), keep.ptr(_f32(norm.bias)),
                           keep.ptr(_gamma(gamma)), keep.ptr(w1f, True), keep.ptr(w2f, True))
 
@@ -321,7 +339,9 @@ def _geometry(layer, Hp: int, Wp: int):
 def _prepare(layer, x_dev, Hp: int, Wp: int):
     st = _state(layer, x_dev)
     op_name = getattr(layer, "hat_operand_dtype", "f16")
-    op_code, op_dtype = _OP[op_name]
+    if op_name not in _OP:
+        raise ValueError(f"unknown HAT operand mode {op_name!r}; choose from {OPERAND_MODES}")
+    op_code, op_dtype, terms = _OP[op_name]
     ws, hier, sr0, sr1 = _geometry(layer, Hp, Wp)
     blk0 = layer.blocks[0]
     cw = blk0.cr_window
@@ -341,7 +361,7 @@ def _prepare(layer, x_dev, Hp: int, Wp: int):
     tb, _, ctables = st.tables[tkey]
     sig = _signature(layer.blocks, x_dev, op_name, bool(getattr(layer, "_is_replica", False))) + (tb["S"], tb["G"])
     if st.sig != sig:
-        keep = _Keep(op_dtype)
+        keep = _Keep(op_dtype, terms)
         arr = (FvitBlockWeights * len(layer.blocks))()
         # constant folding must not run under the caller's autocast: the tables are fp32 by contract
         with torch.autocast(device_type="cuda", enabled=False):
@@ -353,7 +373,7 @@ def _prepare(layer, x_dev, Hp: int, Wp: int):
                        square=int(hier and hasattr(blk0, "hat_pos_embed")), hidden=blk0.mlp.fc1.out_features,
                        depth=len(layer.blocks), do_propagation=int(bool(blk0.do_propagation)), operand_dtype=op_code,
                        spad=lib.fvit_attention_spad(tb["S"]), gpad=lib.fvit_attention_spad(tb["G"]) if hier else 0,
-                       qk_scale=float(blk0.attn.scale))
+                       qk_scale=float(blk0.attn.scale), weight_terms=terms)
     return st, tb, ctables, desc_common
 
 
@@ -382,6 +402,7 @@ def workspace_slot(slot: int):
 
 
 def _workspace(st: StageState, desc_common: dict, B: int, H: int, W: int, device) -> _Workspace:
+    # (the workspace layout does not depend on the weight terms: activations are single-rounded in every mode)
     key = (B, desc_common["Hp"], desc_common["Wp"], H, W, desc_common["operand_dtype"], _slot())
     hit = st.workspaces.get(key)
     if hit is not None:
@@ -457,15 +478,19 @@ _WARNED = set()
 
 def _check_mode(layer, x: torch.Tensor, what: str):
     """The HIP path has forward kernels only and implements eval semantics (DropPath / Dropout identity, AR:636-637, 657-658).
-      * train mode                      -> RuntimeError (stochastic depth / dropout would silently be skipped);
-      * grad enabled + x.requires_grad  -> RuntimeError (the caller is differentiating through the stage: outputs are detached);
-      * grad enabled otherwise          -> one warning (outputs are detached; wrap inference in torch.no_grad())."""
+      * train mode                               -> RuntimeError (stochastic depth / dropout would silently be skipped);
+      * grad enabled + a LEAF input that requires grad (the caller differentiates w.r.t. this very tensor)
+                                                  -> RuntimeError (outputs are detached, the gradient would silently be zero);
+      * grad enabled otherwise                   -> one warning; the stage runs and returns detached outputs.  This covers
+        ``model.eval()(x)`` without ``torch.no_grad()``: there the stage input is the output of the conv modules, which requires
+        grad only because their parameters do (a non-leaf) -- not an error of the caller.  ``FasterViT.forward`` applies the leaf
+        check to the user's own tensor."""
     if layer.training:
         raise RuntimeError(f"{what}: the MI355X HAT path is inference-only (forward kernels, eval semantics); call model.eval(). "
                            "Backward kernels for the HAT block are not built (DESIGN.md, SURVEY.md §8f-4); the head-only training "
                            "step (fastervit_amd.head_train) keeps the backbone in eval mode.")
     if torch.is_grad_enabled():
-        if x.requires_grad:
+        if x.requires_grad and x.is_leaf:
             raise RuntimeError(f"{what}: the input requires grad, but the HIP HAT stage has no backward: its output would be silently "
                                "detached. Run under torch.no_grad() (or detach the input).")
         if what not in _WARNED:
@@ -474,8 +499,17 @@ def _check_mode(layer, x: torch.Tensor, what: str):
                           "Wrap inference in torch.no_grad().", stacklevel=3)
 
 
-def is_prepared(layer, device) -> bool:
-    """True if the packed weights of ``layer`` on ``device`` are current (no packing work will be enqueued by the next call)."""
+def check_user_input(x: torch.Tensor, what: str = "FasterViT") -> None:
+    """Model-level form of the leaf check above: the caller's own tensor asks for a gradient through a forward-only path."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        raise RuntimeError(f"{what}: the input requires grad, but the transformer stages run forward-only HIP kernels: the gradient "
+                           "w.r.t. the input would silently be cut. Run under torch.no_grad() (or detach the input).")
+
+
+def is_prepared(layer, device, batch: Optional[int] = None, hw=None, slots=(0,)) -> bool:
+    """True if the packed weights of ``layer`` on ``device`` are current (no packing work will be enqueued by the next call).  With
+    ``batch`` and ``hw`` = (H, W) of the stage input also: the index tables of that (padded) geometry and the workspaces of every
+    slot in ``slots`` exist -- so that a forked multi-stream forward issues no H2D copy / allocation on a side stream."""
     states = layer.__dict__.get("_fvit_state")
     if not states or getattr(layer, "_is_replica", False):
         return False
@@ -483,7 +517,17 @@ def is_prepared(layer, device) -> bool:
     if st is None or st.sig is None:
         return False
     op_name = getattr(layer, "hat_operand_dtype", "f16")
-    return st.sig[:-2] == _signature(layer.blocks, device, op_name)
+    if st.sig[:-2] != _signature(layer.blocks, device, op_name):
+        return False
+    if batch is None or hw is None:
+        return True
+    H, W = hw
+    ws = layer.window_size
+    Hp, Wp = H + (ws - H % ws) % ws, W + (ws - W % ws) % ws
+    if (Hp, Wp) not in st.tables:
+        return False
+    op_code = _OP[op_name][0]
+    return all((batch, Hp, Wp, H, W, op_code, s) in st.workspaces for s in slots)
 
 
 def stage_forward(layer, x: torch.Tensor, tokenizer=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

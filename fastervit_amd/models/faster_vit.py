@@ -425,9 +425,12 @@ class FasterViT(nn.Module):
         return {"rpb"}
 
     def set_hat_operand_dtype(self, name: str):
-        """Choose the 16-bit MFMA operand type of the HAT kernels ('f16' or 'bf16'; fp32 accumulate)."""
-        if name not in ("f16", "bf16"):
-            raise ValueError("operand dtype must be 'f16' or 'bf16'")
+        """Choose the operand mode of the HAT kernels (fp32 accumulate): 'f16' (default) or 'bf16' -- 16-bit operands rounded once --
+        or 'f16x2' / 'bf16x2' -- every Linear weight as two 16-bit terms hi + lo (twice the MFMA work on the weights' side; the
+        route to logits max-abs < 1e-3 with bf16 operands)."""
+        from ..hat_runtime import OPERAND_MODES
+        if name not in OPERAND_MODES:
+            raise ValueError(f"operand mode must be one of {OPERAND_MODES}")
         self.hat_operand_dtype = name
         for lvl in self.levels:
             lvl.hat_operand_dtype = name
@@ -494,6 +497,9 @@ class FasterViT(nn.Module):
         return CompiledInference(self, example, dtype=dtype, streams=streams, graph=graph)
 
     def forward(self, x):
+        if x.is_cuda and not self.training:
+            from ..hat_runtime import check_user_input
+            check_user_input(x)   # eval on the GPU = forward-only HIP stages: a caller asking for d/dx gets an error, not zeros
         plan = self.__dict__.get("_deploy_plan")
         # nn.DataParallel replicas share __dict__ with the original: the plan's folded weights live on the original's device, so
         # replicas run the module path (per-device HAT state in hat_runtime)

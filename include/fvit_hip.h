@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FVIT_ABI_VERSION 3
+#define FVIT_ABI_VERSION 4
 
 /* error codes */
 #define FVIT_OK 0
@@ -75,6 +75,12 @@ typedef struct FvitStageDesc {
     int32_t spad;           /* window sequence (ws^2 + cw^2) padded to a multiple of 16 */
     int32_t gpad;           /* carrier sequence G = cw^2 * nW padded to a multiple of 16 (hier) */
     float qk_scale;         /* score scale of attn and hat_attn; <= 0 selects head_dim^-0.5 (FV:538 `qk_scale or head_dim ** -0.5`) */
+    int32_t weight_terms;   /* 1: every Linear weight rounded once to the operand type.  2 ("f16x2" / "bf16x2"): every packed weight array
+                               holds TWO 16-bit terms, hi = round(w) and lo = round(w - hi): row-major arrays as [rows][2 * ldk] = [hi | lo]
+                               (K-concatenated; the kernels wrap the activation column at ldk), fragment-order arrays as two images back
+                               to back [hi image | lo image].  Activations stay single-rounded: the logits error of this path is dominated
+                               by the SYSTEMATIC weight rounding (identical for every token, it survives the average pool), not by the
+                               per-token activation rounding. */
 } FvitStageDesc;
 
 /* One attention sub-block: LayerNorm -> qkv -> softmax(q k^T * scale + bias) v -> proj -> gamma-residual.
@@ -215,6 +221,12 @@ int fvit_gemm_bias_act(int32_t operand_dtype, const void* A, int32_t lda, const 
 int fvit_gemm_residual(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw,
                        const float* bias, const float* gamma, float* x, int32_t ldx, int32_t M,
                        int32_t N, int32_t K, fvit_stream_t stream);
+
+/* The same GEMM with K-concatenated weight terms (FvitStageDesc.weight_terms): Wt is [pad128(N)][ldw >= K], K = ka or 2 * ka, the
+ * contraction index k reads activation column k mod ka (A is [pad128(M)][lda >= ka]).  epilogue: 0 bias, 1 bias + GELU (out op16),
+ * 2 gamma-residual into f32 out (gamma may be NULL = 1).  With K == ka this is fvit_gemm_bias_act / fvit_gemm_residual. */
+int fvit_gemm_terms(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias, const float* gamma,
+                    void* out, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t ka, int32_t epilogue, fvit_stream_t stream);
 /* Windowed multi-head attention core on packed qkv (op16 [rows][ldq], columns [q|k|v][head][dpad]):
  * out (op16 [rows][ldo], columns [head][dpad]) = softmax(q k^T * scale + bias) v per (window, head).
  * S tokens per window (rows w*S .. w*S+S-1), bias f32 [heads][Spad][Spad] as in FvitAttnWeights. */
@@ -253,6 +265,10 @@ int fvit_win_mlp_supported(int32_t C, int32_t hidden);
 int fvit_win_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,
                        float eps, const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2,
                        const float* gamma, fvit_stream_t stream);
+/* ... with `terms` weight images back to back in w_fc1_frag / w_fc2_frag (1, or 2 = [hi image | lo image]). */
+int fvit_win_mlp_fused_terms(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,
+                             float eps, const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2,
+                             const float* gamma, int32_t terms, fvit_stream_t stream);
 
 /* fvit_attn_block_fused's contract for C == 512, heads == 16, 48 < S <= 64 (stage 3 of FasterViT-0) with a different work split: one
  * workgroup per window, its 8 waves split heads / output channels and stream their weight slices from L2 into registers (fvit_winblk.hip);

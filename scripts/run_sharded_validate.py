@@ -92,7 +92,9 @@ def main(argv=None):
     lo, hi = dp.shard_bounds(n_total, world, rank)
     loader = ShardLoader(lo, hi, args.batch_size, size, model.num_classes, tensors)
     runner = None
-    if on_gpu and not args.eager:
+    # the hipGraph runner is the 16-bit deploy plan: it stands in for the reference's `validate.py --amp` only.  Without --amp the
+    # reference evaluates in fp32, so this script does too (eager module path: fp32 conv side, HIP HAT stages)
+    if on_gpu and not args.eager and args.amp:
         example = torch.zeros((args.batch_size, 3) + size, device=dev)
         if args.channels_last:
             example = example.contiguous(memory_format=torch.channels_last)
@@ -128,7 +130,9 @@ def main(argv=None):
     res = {"model": args.model, "top1": round(100.0 * c1_all / max(n_all, 1), 4), "top1_err": round(100.0 - 100.0 * c1_all / max(n_all, 1), 4),
            "top5": round(100.0 * c5_all / max(n_all, 1), 4), "top5_err": round(100.0 - 100.0 * c5_all / max(n_all, 1), 4),
            "param_count": round(sum(p.numel() for p in model.parameters()) / 1e6, 2), "img_size": size[-1], "samples": n_all,
-           "world_size": world, "shard": [lo, hi], "runner": "hipGraph" if runner is not None else "eager"}
+           "world_size": world, "shard": [lo, hi], "runner": "hipGraph" if runner is not None else "eager",
+           "dtype": ("float16 deploy plan (hipGraph)" if runner is not None else
+                     ("float16 autocast" if (args.amp and on_gpu) else "float32 conv side" + (", HIP HAT stages (fp16 operands, fp32 accumulate)" if on_gpu else "")))}
     if rank == 0:
         print(json.dumps(res))
         if args.results_file:

@@ -32,7 +32,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_abi_version_and_struct_sizes(lib):
     assert lib.fvit_abi_version() == _lib.FVIT_ABI_VERSION
-    assert ctypes.sizeof(_lib.FvitStageDesc) == 19 * 4
+    assert ctypes.sizeof(_lib.FvitStageDesc) == 20 * 4
     assert ctypes.sizeof(_lib.FvitAttnWeights) == 12 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.FvitMlpWeights) == 9 * 8
     assert ctypes.sizeof(_lib.FvitBlockWeights) == 2 * 104 + 2 * 72 + 16 + 8
@@ -46,8 +46,13 @@ def test_attention_spad(lib):
 
 def test_workspace_bytes_and_descriptor_validation(lib):
     d = _lib.FvitStageDesc(batch=256, C=256, heads=8, dpad=32, ws=7, H=14, W=14, Hp=14, Wp=14, cw=2, hier=1, square=1,
-                           hidden=1024, depth=6, do_propagation=0, operand_dtype=_lib.FVIT_F16, spad=64, gpad=16)
+                           hidden=1024, depth=6, do_propagation=0, operand_dtype=_lib.FVIT_F16, spad=64, gpad=16, weight_terms=1)
     n = lib.fvit_stage_workspace_bytes(ctypes.byref(d))
+    d.weight_terms = 2   # hi + lo weight terms: same workspace (activations are single-rounded in every mode)
+    assert lib.fvit_stage_workspace_bytes(ctypes.byref(d)) == n
+    d.weight_terms = 0
+    assert lib.fvit_stage_workspace_bytes(ctypes.byref(d)) == 0 and b"weight_terms" in lib.fvit_last_error()
+    d.weight_terms = 1
     rows = 256 * 4 * 53
     assert n >= rows * (256 * 4 + 256 * 2 + 768 * 2 + 256 * 2 + 1024 * 2)
     assert n < 2 * rows * (256 * 4 + 256 * 2 + 768 * 2 + 256 * 2 + 1024 * 2)
