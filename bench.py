@@ -46,6 +46,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROAR
 N_CU = 256                 # compute units of an MI355X (8 XCDs x 32)
 HBM_PEAK_GBS = 8000.0
 RIDGE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+OPERAND_MODES = ("f16", "bf16", "f16x2", "bf16x2")   # fastervit_amd.hat_runtime.OPERAND_MODES
 WEIGHT_SEED = 1234          # tests/cases.py SEED: the weights of the committed golden fixtures
 # scripts/gpu_pmc_traffic.sh -> scripts/pmc_traffic_summary.py; the newest committed round wins
 PMC_FILE = next((f for f in (os.path.join("profiles", f"r0{r}_pmc_hbm_traffic_by_kernel.json") for r in (3, 2))
@@ -61,7 +62,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--model-kwargs", default="", help="python dict literal passed to create_model (secondary configs)")
     ap.add_argument("--input-size", default="", help="HxW override (secondary configs, e.g. 576x960)")
-    ap.add_argument("--operand", default="f16", choices=["f16", "bf16"], help="MFMA operand type of the HAT kernels")
+    ap.add_argument("--operand", default="f16", choices=list(OPERAND_MODES),
+                    help="operand mode of the HAT kernels: f16 / bf16 (16-bit operands rounded once), f16x2 / bf16x2 (weights as two terms hi + lo)")
     ap.add_argument("--conv-dtype", default="f16", choices=["f16", "bf16", "f32"], help="dtype of the conv side")
     ap.add_argument("--mode", default="deploy", choices=["deploy", "module", "auto"],
                     help="deploy: BN folded into convs + fused HIP conv kernels (model.compile_inference); module: nn.Module forward under "
@@ -492,23 +494,36 @@ def main():
         cfg.plan.streams = n
         out["roofline_isolated"] = {"launch": "eager, 1 stream, whole-batch launches", "shapes": iso[:12]}
 
-    cpu = parity = parity_bf16 = None
+    cpu = parity = None
     arch = oracle_arch(args.model, mk)
     if world == 1 and arch is not None:   # N = 1 only: rank 0's host cores are shared with the other ranks otherwise
         sizes = [p.shape[0] for p in cfg.x_cpu.chunk(cfg.streams)] if cfg.streams > 1 else [args.batch]
         starts = [sum(sizes[:i]) for i in range(len(sizes))]
         idx = [s + j for s, n in zip(starts, sizes) for j in range(min(8, n))]
-        parity, _ = parity_vs_oracle(cfg, logits_gpu, arch, idx, f"CPU oracle fp32; 8 images from each of the {len(sizes)} stream shards (shard starts {starts})")
+        parity, ref_all = parity_vs_oracle(cfg, logits_gpu, arch, idx, f"CPU oracle fp32; 8 images from each of the {len(sizes)} stream shards (shard starts {starts})")
         parity["weights"] = f"tests/synth.py family 'init', seed {WEIGHT_SEED} (reference init + gamma ~ U(0.5,1.5), BN statistics, biases)"
         parity["tolerance"] = "north_star: logits max-abs < 1e-3"
-        # the other 16-bit operand type on the same images (eager, same plan): reported, not timed
-        other = "bf16" if args.operand == "f16" else "f16"
-        cfg.model.set_hat_operand_dtype(other)
-        y = cfg.eager(cfg.x).float().cpu()
+        # every other operand mode on the same images: its own error AND its own images/s (the runner is re-captured per mode:
+        # same deploy plan, stream shards and hipGraph as the timed configuration; a few timed replays each)
+        ref_first = ref_all[:8]   # idx[:8] = the first 8 images of shard 0
+        for other in [m for m in OPERAND_MODES if m != args.operand]:
+            try:
+                cfg.model.set_hat_operand_dtype(other)
+                if cfg.runner is not None:
+                    cfg.runner.recompile()
+                el = dp.timed_steps(cfg.step, max(5, args.steps // 4), 2, torch.cuda.synchronize, None, dev)
+                y = cfg.logits()
+                err = (y[idx[:8]] - ref_first).abs().max().item()
+                out["parity_" + other] = {"logits_max_abs_err": float(f"{err:.3e}"), "logits_abs_max": round(ref_first.abs().max().item(), 4),
+                                          "images": 8, "meets_1e-3": bool(err < 1e-3),
+                                          "images_per_s": round(args.batch * max(5, args.steps // 4) / el, 1),
+                                          "vs": f"CPU oracle fp32, first 8 images, HAT operands {other} (conv side {args.conv_dtype}), "
+                                                "same plan / stream shards / hipGraph as the timed configuration"}
+            except Exception as e:
+                out["parity_" + other] = {"error": f"{type(e).__name__}: {e}"[:300]}
         cfg.model.set_hat_operand_dtype(args.operand)
-        pb, _ = parity_vs_oracle(cfg, y, arch, idx[:8], f"CPU oracle fp32, first 8 images, HAT operands {other} (conv side {args.conv_dtype})")
-        pb["meets_1e-3"] = bool(pb["logits_max_abs_err"] < 1e-3)
-        out["parity_" + other] = pb
+        if cfg.runner is not None:
+            cfg.runner.recompile()
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, arch, args.cpu_seconds)
     out["cpu_baseline"], out["parity"] = cpu, parity

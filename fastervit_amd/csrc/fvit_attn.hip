@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[db * 4 + r] = (T)(o[db][r] * inv);
+                    for (int r = 0; r < 4; ++r) ov[db * 4 + r] = sat16<T>(o[db][r] * inv);
                 *(v8*)po = ov;
             } else {
 #pragma unroll
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
                     for (int d2 = 0; d2 < 2; ++d2)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ov[d2 * 4 + r] = (T)(o[hseg * 2 + d2][r] * inv);
+                        for (int r = 0; r < 4; ++r) ov[d2 * 4 + r] = sat16<T>(o[hseg * 2 + d2][r] * inv);
                     *(v8*)(po + hseg * 8) = ov;
                 }
             }

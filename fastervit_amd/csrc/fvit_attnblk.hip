@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
                 const f4 w = *(const f4*)(p.ln_w + co);
                 const f4 b = *(const f4*)(p.ln_b + co);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)((v[kk][h2][r] - mean) * rstd * w[r] + b[r]);
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = sat16<T>((v[kk][h2][r] - mean) * rstd * w[r] + b[r]);
             }
             xf[kk] = o;
         }
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
             const f4 bkv = *(const f4*)(bq + 32 + blk * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                qf[blk * 4 + r] = (T)(acc[blk][r] + bqv[r]);
-                kf[blk * 4 + r] = (T)(acc[2 + blk][r] + bkv[r]);
+                qf[blk * 4 + r] = sat16<T>(acc[blk][r] + bqv[r]);
+                kf[blk * 4 + r] = sat16<T>(acc[2 + blk][r] + bkv[r]);
             }
         }
         // exchange: this wave's k fragment and its half of the v fragments
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
             const float bv = bq[64 + db * 16 + s];
             v4 vh;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vh[r] = (T)(acc[4 + db][r] + bv);
+            for (int r = 0; r < 4; ++r) vh[r] = sat16<T>(acc[4 + db][r] + bv);
             *(v4*)(vx + ((wi * 2 + db) * NKB32 + (qb >> 1)) * 1024 + lane16 + (qb & 1) * 8) = vh;
         }
 
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
         v8 of;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            of[r] = (T)(o[0][r] * inv);
-            of[4 + r] = (T)(o[1][r] * inv);
+            of[r] = sat16<T>(o[0][r] * inv);
+            of[4 + r] = sat16<T>(o[1][r] * inv);
         }
         // ---- P3: out^T += Wproj[:, head h] . O^T (fragment batches of 4, batch c + 1 requested before the MFMAs of batch c) ----
         {

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
 #pragma unroll
             for (int d2 = 0; d2 < 2; ++d2)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ov[d2 * 4 + r] = (T)(o[hseg * 2 + d2][r] * inv);
+                for (int r = 0; r < 4; ++r) ov[d2 * 4 + r] = sat16<T>(o[hseg * 2 + d2][r] * inv);
             *(v8*)(po + hseg * 8) = ov;
         }
     }

@@ -33,6 +33,14 @@ template <> struct Op16<__bf16> {
     }
 };
 
+// Narrowing of an fp32 activation to the MFMA operand type.  fp16 SATURATES at +-65504 (one v_med3_f32): an activation beyond the
+// fp16 range becomes the largest finite value instead of inf, so that no inf - inf / 0 * inf NaN can appear downstream (softmax of
+// +-inf scores, a zero-padded weight column times inf) and a checkpoint with out-of-range activations degrades instead of
+// poisoning the batch (tests/test_gpu_kernels.py::test_f16_operands_saturate).  bf16 has the fp32 exponent range: plain cast.
+template <typename T> __device__ __forceinline__ T sat16(float x);
+template <> __device__ __forceinline__ _Float16 sat16<_Float16>(float x) { return (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+template <> __device__ __forceinline__ __bf16 sat16<__bf16>(float x) { return (__bf16)x; }
+
 // Cross-row lane exchanges on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap) instead of __shfl_xor, which is
 // ds_bpermute_b32 -- an LDS-pipeline instruction.  r02 finding (profiles/r02_repeatability_hunt.log): in kernels that have LDS-DMA
 // (global_load_lds) traffic landing in the workgroup's LDS, a ds_bpermute issued by a wave whose sibling waves' DMA is still in

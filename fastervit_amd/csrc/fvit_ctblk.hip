@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
                 const f4 w = *(const f4*)(lw + co);
                 const f4 b = *(const f4*)(lb + co);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)((v[cb][r] - mean) * rstd * w[r] + b[r]);
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = sat16<T>((v[cb][r] - mean) * rstd * w[r] + b[r]);
             }
             xf[kk] = o;
         }
@@ -219,14 +219,14 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
                 const f4 bb = *(const f4*)(bq + (ub >> 1) * 32 + (ub & 1) * 16 + g * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (ub < 2) qf[(ub & 1) * 4 + r] = (T)(a[r] + bb[r]);
-                    else kf[(ub & 1) * 4 + r] = (T)(a[r] + bb[r]);
+                    if (ub < 2) qf[(ub & 1) * 4 + r] = sat16<T>(a[r] + bb[r]);
+                    else kf[(ub & 1) * 4 + r] = sat16<T>(a[r] + bb[r]);
                 }
             } else {
                 const float bv = bq[64 + (ub - 4) * 16 + s];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    vf[ub - 4][r] = (T)(a[r] + bv);   // keys 4g + r of the only 16-key block; k slots 4..7 = keys 16.. do not exist
+                    vf[ub - 4][r] = sat16<T>(a[r] + bv);   // keys 4g + r of the only 16-key block; k slots 4..7 = keys 16.. do not exist
                     vf[ub - 4][4 + r] = (T)0.f;
                 }
             }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
         for (int db = 0; db < 2; ++db) {
             const f4 o = Op16<T>::mfma(vf[db], pf, (f4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-            for (int r = 0; r < 4; ++r) of[db * 4 + r] = (T)(o[r] * inv);
+            for (int r = 0; r < 4; ++r) of[db * 4 + r] = sat16<T>(o[r] * inv);
         }
         // out^T += Wproj[:, head h] . O^T
 #pragma unroll
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
         v8 pf;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            pf[r] = (T)gelu_fast(a1[0][r] + bA[r]);
-            pf[4 + r] = (T)gelu_fast(a1[1][r] + bB[r]);
+            pf[r] = sat16<T>(gelu_fast(a1[0][r] + bA[r]));
+            pf[4 + r] = sat16<T>(gelu_fast(a1[1][r] + bB[r]));
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {

@@ -87,12 +87,20 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
 // sustains ~16 KiB of loads in flight (scripts/probes/dma_probe.hip: 125 GB/s per CU from L2, 30-40 GB/s per CU from HBM / MALL,
 // independent of ring depth), and the A operand of these GEMMs was just written by the previous kernel and comes from the
 // memory side.  NW = 8 and NSTAGE = 3 are therefore opt-in knobs only.
-template <typename T, int EPI, int NSTAGE, int MI, int NW>
+// NI: 16-column fragments per wave along N (4: 128-column tile; 8: 256-column tile).  NW = 8, MI = 4, NI = 8 is the 256 x 256 x 64 tile
+//     (r03): 4 waves along M x 2 along N, each wave 64 rows x 128 columns = 128 accumulator registers, two waves per SIMD, 128 KiB of
+//     LDS (2 x (32 + 32) KiB), one workgroup per CU.  Per K step a wave reads 12 fragments per 32-deep half and issues 32 MFMAs on
+//     them (2.7 MFMAs per ds_read_b128 against 2.0 for the 128 x 128 tile), and a byte staged into LDS is used by 4 (activations) / 2
+//     (weights) waves: the shape for the large Linear layers of FasterViT-4 (K = 832 ... 6272), where the 128 x 128 tile plateaus
+//     at 0.22-0.25 of the MFMA peak.
+template <typename T, int EPI, int NSTAGE, int MI, int NW, int NI = 4>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int BMT = (NW / 2) * 16 * MI;            // rows of the workgroup tile (NW/2 waves along M)
-    constexpr int XT_BYTES = BMT * BK * 2;             // activation tile bytes (W tile stays TILE_BYTES = 128 rows)
-    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * (XT_BYTES + TILE_BYTES)];  // X ring, then W ring
+    constexpr int BNT = 2 * 16 * NI;                   // columns of the workgroup tile (2 waves along N)
+    constexpr int XT_BYTES = BMT * BK * 2;             // activation tile bytes
+    constexpr int WT_BYTES = BNT * BK * 2;             // weight tile bytes
+    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * (XT_BYTES + WT_BYTES)];  // X ring, then W ring
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,14 +112,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
     const int q = nblk >> 3, rr = nblk & 7, xcd = b & 7, idx = b >> 3;
     const int v = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
-    const int m0 = tm * BMT, n0 = tn * BN;
+    const int m0 = tm * BMT, n0 = tn * BNT;
 
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ W = (const T*)p.W;
 
-    f4 acc[4][MI];  // [ni][mi]
+    f4 acc[NI][MI];  // [ni][mi]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
@@ -133,17 +141,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
     for (int st = 0; st < NSTAGE - 1; ++st) {
         if (st < nk) {
             stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(st), xring + st * XT_BYTES, wave, lane);
-            stage_tile<T, true, 128, NW>(W, p.ldw, n0, ktile(st) * BK, wring + st * TILE_BYTES, wave, lane);
+            stage_tile<T, true, BNT, NW>(W, p.ldw, n0, ktile(st) * BK, wring + st * WT_BYTES, wave, lane);
         }
     }
 
     // per-lane fragment addressing (bytes inside a tile)
     const int g = lane >> 4, s = lane & 15;
-    int xrow[MI], wrow[4];
+    int xrow[MI], wrow[NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) xrow[i] = wm * (16 * MI) + i * 16 + s;        // activation row (B operand column)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wrow[i] = wn * 64 + (s >> 2) * 16 + i * 4 + (s & 3);  // weight row for A-row slot s of fragment i
+    for (int i = 0; i < NI; ++i) wrow[i] = wn * (16 * NI) + (i >> 2) * 64 + (s >> 2) * 16 + (i & 3) * 4 + (s & 3);  // weight row for A-row slot s of fragment i
 
     int cur = 0;  // ring slot of tile kt
     for (int kt = 0; kt < nk; ++kt) {
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             // each wave issues PER LDS-DMA instructions per stage (X pieces + W pieces): tile kt has landed once at most the
             // instructions of the (up to NSTAGE - 2) tiles after it are still outstanding.  Raw barrier: __syncthreads() would
             // drain the queue (vmcnt(0)).
-            constexpr int PER = BMT / 8 / NW + 128 / 8 / NW;
+            constexpr int PER = BMT / 8 / NW + BNT / 8 / NW;
             const int ahead = min(NSTAGE - 2, nk - 1 - kt);
             if (NSTAGE >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PER) : "memory");
             else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PER) : "memory");
@@ -167,11 +175,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             if (slot >= NSTAGE) slot -= NSTAGE;
             if (nxt < nk) {
                 stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(nxt), xring + slot * XT_BYTES, wave, lane);
-                stage_tile<T, true, 128, NW>(W, p.ldw, n0, ktile(nxt) * BK, wring + slot * TILE_BYTES, wave, lane);
+                stage_tile<T, true, BNT, NW>(W, p.ldw, n0, ktile(nxt) * BK, wring + slot * WT_BYTES, wave, lane);
             }
         }
         const char* xt = xring + cur * XT_BYTES;
-        const char* wt = wring + cur * TILE_BYTES;
+        const char* wt = wring + cur * WT_BYTES;
+        if constexpr (NI == 8) {
+            // 256-column tile: one 32-deep half at a time (12 fragments = 48 registers in flight beside the 128 accumulators); the
+            // SIMD's second wave covers the LDS round trip
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = kk * 4 + g;
+                v8 xf[MI], wf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xf[i] = *(const v8*)(xt + xrow[i] * 128 + ((c ^ swz_x(xrow[i])) << 4));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) wf[i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[ni], xf[mi], acc[ni][mi]);
+            }
+        } else {
         // all fragment reads of the K step are issued up front (both 32-deep halves): left to itself the compiler reads one
         // half, drains lgkmcnt, multiplies, reads the next half, drains again -- three exposed LDS round trips per K step, which
         // is what bounds small grids (one wave per SIMD, nothing else to hide them)
@@ -191,12 +216,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[kk][ni], xf[kk][mi], acc[ni][mi]);
+        }
         if (++cur == NSTAGE) cur = 0;
     }
 
-    // ---- epilogue: lane holds out[m][nb .. nb+15] for 4 rows m (one per mi) ----
-    const int nb = n0 + wn * 64 + g * 16;
-    if (nb >= p.N) return;  // N is a multiple of 16
+    // ---- epilogue: per 64-column group cg the lane holds out[m][nb .. nb+15] for MI rows m (one per mi) ----
+#pragma unroll
+    for (int cg = 0; cg < NI / 4; ++cg) {
+    const int nb = n0 + wn * (16 * NI) + cg * 64 + g * 16;
+    if (nb >= p.N) continue;  // N is a multiple of 16
     float bias[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -225,7 +253,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     f4 x = *(f4*)(px + ni * 4);
-                    f4 a = acc[ni][mi];
+                    f4 a = acc[cg * 4 + ni][mi];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[r] += gam[ni * 4 + r] * (a[r] + bias[ni * 4 + r]);
                     if (pa) x += *(const f4*)(pa + ni * 4);
@@ -242,12 +270,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
                 v8 o0, o1;
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    f4 a = acc[ni][mi];
+                    f4 a = acc[cg * 4 + ni][mi];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float y = a[r] + bias[ni * 4 + r];
                         if (EPI == 1) y = gelu_fast(y);
-                        if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
+                        if (ni < 2) o0[ni * 4 + r] = sat16<T>(y); else o1[(ni - 2) * 4 + r] = sat16<T>(y);
                     }
                 }
                 T* po = O + (size_t)m * p.ldo + nb;
@@ -255,6 +283,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
                 *(v8*)(po + 8) = o1;
             }
         }
+    }
     }
 }
 
@@ -265,7 +294,11 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.lda = c.lda; p.ldw = c.ldw; p.ldo = c.ldo;
     p.M = c.M; p.N = c.N; p.K = c.K;
     p.ka = c.ka > 0 ? c.ka : c.K;
-    p.tiles_n = (c.N + BN - 1) / BN;
+    // 256 x 256 tiles once they fill the chip (fvit_tune "gemm256_min_tiles"; 0 = never): the large Linear layers of FasterViT-4
+    const int t256 = ((c.M + 255) / 256) * ((c.N + 255) / 256);
+    const int min256 = tune_get("gemm256_min_tiles", 192);
+    const bool big = min256 > 0 && t256 >= min256 && p.K / BK >= 4;
+    p.tiles_n = big ? (c.N + 255) / 256 : (c.N + BN - 1) / BN;
     p.stagger = tune_get("gemm_stagger", 0);
     p.add = c.epilogue == 2 ? c.add : nullptr;
     p.add_idx = c.add_idx;
@@ -275,9 +308,9 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     //   grid128 <= bm64_max : 64-row tiles (twice the workgroups; +2 % images/s on shard-sized launches), else 128-row tiles
     //   grid128 <= nw8_max  : 8 waves per workgroup (default off: no gain, see gemm_kernel)
     const int nw8_max = tune_get("gemm_nw8_max_grid", 0), bm64_max = tune_get("gemm_bm64_max_grid", 400);
-    const bool nw8 = grid128 <= nw8_max;
-    const bool small = grid128 <= bm64_max;   // 64-row tiles
-    p.tiles_m = small ? (c.M + 63) / 64 : (c.M + 127) / 128;
+    const bool nw8 = !big && grid128 <= nw8_max;
+    const bool small = !big && grid128 <= bm64_max;   // 64-row tiles
+    p.tiles_m = big ? (c.M + 255) / 256 : small ? (c.M + 63) / 64 : (c.M + 127) / 128;
     const int grid = p.tiles_m * p.tiles_n;
     const double flops = 2.0 * c.M * (double)c.N * p.ka;   // algorithmic: the extra weight terms are a precision cost, not work
     double bytes = 2.0 * c.M * (double)p.ka + 2.0 * c.N * (double)c.K;  // operands once
@@ -290,17 +323,19 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
         kind = c.epilogue == 1 ? FVIT_K_GEMM_GELU : FVIT_K_GEMM_BIAS;
     }
     ProfScope prof(kind, flops, bytes, stream);
-    prof_note(c.epilogue == 2 ? (small ? "gemm_kernel<2> 64-row" : "gemm_kernel<2> 128-row")
-                              : c.epilogue == 1 ? (small ? "gemm_kernel<1> 64-row" : "gemm_kernel<1> 128-row")
-                                                : (small ? "gemm_kernel<0> 64-row" : "gemm_kernel<0> 128-row"), grid);
+    prof_note(c.epilogue == 2 ? (big ? "gemm_kernel<2> 256x256" : small ? "gemm_kernel<2> 64-row" : "gemm_kernel<2> 128-row")
+                              : c.epilogue == 1 ? (big ? "gemm_kernel<1> 256x256" : small ? "gemm_kernel<1> 64-row" : "gemm_kernel<1> 128-row")
+                                                : (big ? "gemm_kernel<0> 256x256" : small ? "gemm_kernel<0> 64-row" : "gemm_kernel<0> 128-row"), grid);
     // measured r01: a 3-stage ring with counted vmcnt gave no gain over 2 stages at 64..392 workgroups => opt-in only
     const bool deep = !small && !nw8 && grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
     // ring depth of the 64-row tiles (small grids): 2 (48 KiB, three workgroups per CU), 3 (72 KiB, two) or 4 (96 KiB, one)
     const int ring = small && !nw8 && p.K / BK >= 4 ? tune_get("gemm_ring", 2) : 2;
 #define FVIT_GEMM(E, NS, MI_, NW_) hipLaunchKernelGGL((gemm_kernel<T, E, NS, MI_, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p)
+#define FVIT_GEMM256(E) hipLaunchKernelGGL((gemm_kernel<T, E, 2, 4, 8, 8>), dim3(grid), dim3(512), 0, stream, p)
 #define FVIT_GEMM_E(NS, MI_, NW_) \
     switch (c.epilogue) { case 0: FVIT_GEMM(0, NS, MI_, NW_); break; case 1: FVIT_GEMM(1, NS, MI_, NW_); break; default: FVIT_GEMM(2, NS, MI_, NW_); break; }
-    if (nw8 && small) { FVIT_GEMM_E(2, 1, 8) }        // 64 rows = 4 waves along M x 16 rows
+    if (big) { switch (c.epilogue) { case 0: FVIT_GEMM256(0); break; case 1: FVIT_GEMM256(1); break; default: FVIT_GEMM256(2); break; } }
+    else if (nw8 && small) { FVIT_GEMM_E(2, 1, 8) }        // 64 rows = 4 waves along M x 16 rows
     else if (nw8) { FVIT_GEMM_E(2, 2, 8) }            // 128 rows = 4 waves x 32 rows
     else if (small && ring == 4) { FVIT_GEMM_E(4, 2, 4) }
     else if (small && ring == 3) { FVIT_GEMM_E(3, 2, 4) }
@@ -308,6 +343,7 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     else if (deep) { FVIT_GEMM_E(3, 4, 4) }
     else { FVIT_GEMM_E(2, 4, 4) }
 #undef FVIT_GEMM_E
+#undef FVIT_GEMM256
 #undef FVIT_GEMM
     return check_launch("gemm_kernel");
 }

@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256, 1) void lngemm_kernel(LnGemmParams p) {
             v8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o[e] = (T)(d0[e] * rstd * w0[e] + b0[e]);
-                o[4 + e] = (T)(d1[e] * rstd * w1[e] + b1[e]);
+                o[e] = sat16<T>(d0[e] * rstd * w0[e] + b0[e]);
+                o[4 + e] = sat16<T>(d1[e] * rstd * w1[e] + b1[e]);
             }
             *(v8*)(apanel + kt * A_CHUNK_BYTES + r * 128 + ((c ^ swz_x(r)) << 4)) = o;
         }
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void lngemm_kernel(LnGemmParams p) {
                             for (int r = 0; r < 4; ++r) {
                                 float y = a[r] + bias[ni * 4 + r];
                                 if (EPI == 1) y = gelu_fast(y);
-                                if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
+                                if (ni < 2) o0[ni * 4 + r] = sat16<T>(y); else o1[(ni - 2) * 4 + r] = sat16<T>(y);
                             }
                         }
                         T* po = O + (size_t)m * p.ldo + nb;

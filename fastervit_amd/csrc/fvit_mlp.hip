@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
                 const f4 w = *(const f4*)(lw + h * 4);
                 const f4 b = *(const f4*)(lb + h * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[h * 4 + r] = (T)((v[kk][h][r] - mean) * rstd * w[r] + b[r]);
+                for (int r = 0; r < 4; ++r) o[h * 4 + r] = sat16<T>((v[kk][h][r] - mean) * rstd * w[r] + b[r]);
             }
             xf[rb][kk] = o;
         }
@@ -291,8 +291,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
                 if (TRACE && dq) dq[(size_t)(4 + 5 * it + 1) * 64] = fold4(fold4(0u, h0), h1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pf[rb][r] = (T)gelu_fast(h0[r] + bA[r]);
-                    pf[rb][4 + r] = (T)gelu_fast(h1[r] + bB[r]);
+                    pf[rb][r] = sat16<T>(gelu_fast(h0[r] + bA[r]));
+                    pf[rb][4 + r] = sat16<T>(gelu_fast(h1[r] + bB[r]));
                 }
             }
             if (TRACE && dq) dq[(size_t)(4 + 5 * it + 2) * 64] = fold8(0u, pf[0]);
@@ -361,8 +361,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float u0 = acc1[0][rb][r] + bA[r], u1 = acc1[1][rb][r] + bB[r];
-                    pf[rb][r] = (T)gelu_fast(u0);
-                    pf[rb][4 + r] = (T)gelu_fast(u1);
+                    pf[rb][r] = sat16<T>(gelu_fast(u0));
+                    pf[rb][4 + r] = sat16<T>(gelu_fast(u1));
                 }
             }
             // ---- GEMM2: OUT^T[channel][row] += W2[channel][chunk units] . H^T ----

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnParams p) {
             const f4 bb = *(const f4*)(p.ln_b + c4 * 4);
             v4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (T)((v[i][r] - mean) * rstd * w[r] + bb[r]);
+            for (int r = 0; r < 4; ++r) o[r] = sat16<T>((v[i][r] - mean) * rstd * w[r] + bb[r]);
             *(v4*)(no + c4 * 4) = o;
         } else if (c4 < L4) {
             v4 z;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
                 const f4 w = *(const f4*)(p.ln_w + co);
                 const f4 bb = *(const f4*)(p.ln_b + co);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)((xs[r] - mean) * rstd * w[r] + bb[r]);
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = sat16<T>((xs[r] - mean) * rstd * w[r] + bb[r]);
             }
             *(v8*)(smem + ((rb * KK + k8 + part * KP) * 1024) + lane16) = o;
         }
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    qf[rb][blk * 4 + r] = (T)(acc[blk][rb][r] + bqv[r]);
-                    kf[rb][blk * 4 + r] = (T)(acc[2 + blk][rb][r] + bkv[r]);
+                    qf[rb][blk * 4 + r] = sat16<T>(acc[blk][rb][r] + bqv[r]);
+                    kf[rb][blk * 4 + r] = sat16<T>(acc[2 + blk][rb][r] + bkv[r]);
                 }
         }
 #pragma unroll
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
             for (int k32 = 0; k32 < 2; ++k32)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    vf[db][k32][r] = (T)(acc[4 + db][2 * k32][r] + bv);          // keys 32 k32 + 4g + r
-                    vf[db][k32][4 + r] = (T)(acc[4 + db][2 * k32 + 1][r] + bv);  // keys 32 k32 + 16 + 4g + r
+                    vf[db][k32][r] = sat16<T>(acc[4 + db][2 * k32][r] + bv);          // keys 32 k32 + 4g + r
+                    vf[db][k32][4 + r] = sat16<T>(acc[4 + db][2 * k32 + 1][r] + bv);  // keys 32 k32 + 16 + 4g + r
                 }
         }
         // scores^T, softmax over keys, O^T, per query row block; the bias tiles of (h, qb) are step hh * SPH + KK + qb
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
             v8 of;   // normalised O^T fragment of (head h, query block qb) -> O[qb][h] for phase C
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                of[r] = (T)(o[0][r] * inv);
-                of[4 + r] = (T)(o[1][r] * inv);
+                of[r] = sat16<T>(o[0][r] * inv);
+                of[4 + r] = sat16<T>(o[1][r] * inv);
             }
             *(v8*)(smem + OFF_O + ((qb * HEADS + h) * 1024) + lane16) = of;
         }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
                 const f4 w = *(const f4*)(p.ln_w + co);
                 const f4 bb = *(const f4*)(p.ln_b + co);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = (T)((xs[r] - mean) * rstd * w[r] + bb[r]);
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = sat16<T>((xs[r] - mean) * rstd * w[r] + bb[r]);
             }
             *(v8*)(smem + ((rb * KK + k8 + part * KP) * 1024) + lane16) = o;
         }
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
             v8 pf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pf[r] = (T)gelu_fast(acc1[0][rb][r] + bA[r]);
-                pf[4 + r] = (T)gelu_fast(acc1[1][rb][r] + bB[r]);
+                pf[r] = sat16<T>(gelu_fast(acc1[0][rb][r] + bA[r]));
+                pf[4 + r] = sat16<T>(gelu_fast(acc1[1][rb][r] + bB[r]));
             }
             *(v8*)(hw + rb * 1024) = pf;
         }

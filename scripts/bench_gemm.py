@@ -29,6 +29,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "old":   # r01 sweep: waves per workgrou
                 ("8 waves, 128-row", dict(gemm_nw8_max_grid=400, gemm_bm64_max_grid=0)),
                 ("4 waves, 64-row", dict(gemm_nw8_max_grid=0, gemm_bm64_max_grid=400)),
                 ("4 waves, 128-row", dict(gemm_nw8_max_grid=0, gemm_bm64_max_grid=0))]
+if len(sys.argv) > 1 and sys.argv[1] == "fv4":   # r03: the Linear layers of FasterViT-4 (bs 128 / 3 shards and whole batch), 128 x 128 vs 256 x 256 tiles
+    VARIANTS = [("128x128", dict(gemm256_min_tiles=0)), ("256x256", dict(gemm256_min_tiles=1))]
+    SHAPES = [("fv4 s2 qkv shard", 9116, 3072, 832, 0), ("fv4 s2 proj shard", 9116, 784, 1024, 2), ("fv4 s2 fc1 shard", 9116, 3136, 832, 1),
+              ("fv4 s2 fc2 shard", 9116, 784, 3136, 2), ("fv4 s3 qkv shard", 2107, 6144, 1600, 0), ("fv4 s3 proj shard", 2107, 1568, 2048, 2),
+              ("fv4 s3 fc1 shard", 2107, 6272, 1600, 1), ("fv4 s3 fc2 shard", 2107, 1568, 6272, 2),
+              ("fv4 s2 qkv full", 27136, 3072, 832, 0), ("fv4 s2 fc1 full", 27136, 3136, 832, 1), ("fv4 s2 fc2 full", 27136, 784, 3136, 2),
+              ("fv4 s3 fc1 full", 6272, 6272, 1600, 1), ("fv4 s3 fc2 full", 6272, 1568, 6272, 2),
+              ("anyres s2 qkv", 17760, 3072, 832, 0), ("anyres s2 fc2", 17760, 784, 3136, 2), ("8192^3/8", 8192, 8192, 1024, 0)]
 g = torch.Generator(device="cpu").manual_seed(0)
 for name, M, N, K, epi in SHAPES:
     Mp = (M + 127) // 128 * 128
@@ -48,7 +56,7 @@ for name, M, N, K, epi in SHAPES:
         else:
             _lib.check(lib.fvit_gemm_bias_act(code, As[k].data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), O[k].data_ptr(), N, M, N, K, epi, st),
                        "gemm_bias_act")
-    line = f"{name:14s} M={M:5d} N={N:4d} K={K:4d}:"
+    line = f"{name:18s} M={M:5d} N={N:4d} K={K:4d}:"
     for vname, knobs in VARIANTS:
         for k, v in knobs.items():
             _lib.tune(k, v)
@@ -62,5 +70,5 @@ for name, M, N, K, epi in SHAPES:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
-        line += f"  {vname}: {us:6.1f} us"
+        line += f"  {vname}: {us:6.1f} us ({2.0 * M * N * K / us / 1e6:6.1f} TF/s)"
     print(line, flush=True)

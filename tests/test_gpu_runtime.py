@@ -124,6 +124,19 @@ def test_device_and_mode_errors():
         lvl(xin.cpu())
     with pytest.raises(RuntimeError, match="requires grad"):
         lvl(xin.clone().requires_grad_(True))
+    # an eval-mode whole-model forward WITHOUT torch.no_grad() must run (the stage input then requires grad only because
+    # the conv parameters do -- a non-leaf): one warning, detached outputs, same numbers as under no_grad
+    import warnings
+    with torch.no_grad():
+        y_ref = model(x)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        y = model(x)
+    assert not y.requires_grad or y.grad_fn is not None
+    assert torch.equal(y.detach(), y_ref)
+    # ... while a caller who asks for d/dx of the forward-only path gets an error, not a zero gradient
+    with pytest.raises(RuntimeError, match="requires grad"):
+        model(x.clone().requires_grad_(True))
     model.train()
     with pytest.raises(RuntimeError, match="inference-only"), torch.no_grad():
         lvl(xin)
