@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--prof-steps", type=int, default=3, help="eager HIP-event passes for the roofline rows (0: skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 3 and 5")
     ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--no-modes", action="store_true", help="skip the parity / images-per-second legs of the other operand modes")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="exercise ONLY the rank launch / barrier / reduction path on CPU (gloo), no model: prints n_gpus = ranks that ran")
     return ap.parse_args()
@@ -506,7 +507,7 @@ def main():
         # every other operand mode on the same images: its own error AND its own images/s (the runner is re-captured per mode:
         # same deploy plan, stream shards and hipGraph as the timed configuration; a few timed replays each)
         ref_first = ref_all[:8]   # idx[:8] = the first 8 images of shard 0
-        for other in [m for m in OPERAND_MODES if m != args.operand]:
+        for other in [m for m in OPERAND_MODES if m != args.operand and not args.no_modes]:
             try:
                 cfg.model.set_hat_operand_dtype(other)
                 if cfg.runner is not None:

@@ -119,7 +119,7 @@ struct StageLayout {
     int nW, nloc, ncw, S, G;
     int64_t Mx, Mc;          // window-tensor rows, carrier rows
     int ldn, ldqkv, ldao, ldh;
-    size_t off_X, off_Xn, off_QKV, off_AO, off_H, off_R, off_Rn, off_RQKV, off_RAO, off_RH, total;
+    size_t off_X, off_Xn, off_QKV, off_AO, off_H, off_R, off_Rn, off_RQKV, off_RAO, off_RH, off_SLAB, off_CNT, total;
 };
 
 static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
@@ -157,6 +157,13 @@ static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
         L.off_RH = take((size_t)Mcp * L.ldh * 2);
     } else {
         L.off_R = L.off_Rn = L.off_RQKV = L.off_RAO = L.off_RH = 0;
+    }
+    // split-hidden form of the C = 512 MLP kernel (fvit_winmlp.hip): fp32 partial outputs of up to 4 sibling workgroups per 64-row
+    // group + one arrival counter per group (zero from the workspace's one-time zero fill; the kernel leaves them zero)
+    L.off_SLAB = L.off_CNT = 0;
+    if (d.C == 512 && winmlp_supported(d.C, d.hidden)) {
+        L.off_SLAB = take(winmlp_split_slab_bytes(L.Mx, d.C, 4));
+        L.off_CNT = take((size_t)((L.Mx + 63) / 64) * 4);
     }
     L.total = off;
     const int want_s = fvit_attention_spad(L.S), want_g = d.hier ? fvit_attention_spad(L.G) : d.gpad;
@@ -238,7 +245,7 @@ static bool mlp_takes_fused_kernel(const FvitStageDesc& d, const FvitMlpWeights&
 }
 
 static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWeights& w, float* x, int64_t rows, void* xn, void* h,
-                   hipStream_t st, const NextPe* next_pe = nullptr) {
+                   hipStream_t st, const NextPe* next_pe = nullptr, char* slab = nullptr) {
     const int dt = d.operand_dtype;
     const int T = d.weight_terms;
     // the fused kernel streams all MLP weights per 128-row workgroup: it wins once the launch fills the chip
@@ -249,6 +256,11 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
         // C = 512 (stage 3 of FasterViT-0): 64-row workgroups whose waves split hidden units / output channels (fvit_winmlp.hip)
         if (next_pe && next_pe->add) { set_error("internal: position-embedding pre-add requested on the fused MLP path"); return FVIT_EINVAL; }
         MlpFusedCall mc = {dt, x, (int)rows, d.C, d.hidden, w.ln_w, w.ln_b, 1e-5f, w.w_fc1_frag, w.b_fc1, w.w_fc2_frag, w.b_fc2, w.gamma, T};
+        if (slab && L.off_SLAB && rows <= L.Mx) {   // window branch of a C = 512 stage: hidden units split over sibling workgroups
+            mc.slab = (float*)(slab + L.off_SLAB);
+            mc.counters = (int*)(slab + L.off_CNT);
+            mc.nsplit = tune_get("win_mlp_split", 1);
+        }
         FVIT_TRY(launch_winmlp(mc, st));
         dbg_rowhash("winmlp.out", x, rows, d.C * 4, st);
         return FVIT_OK;
@@ -377,7 +389,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         dbg_rowhash("win.gather", X, L.Mx, d.C * 4, st);
         FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st));
     }
-    FVIT_TRY(run_mlp(d, L, w.mlp, X, L.Mx, Xn, Hb, st, next_pe));
+    FVIT_TRY(run_mlp(d, L, w.mlp, X, L.Mx, Xn, Hb, st, next_pe, ws));
     return FVIT_OK;
 }
 
@@ -596,6 +608,20 @@ int fvit_win_mlp_fused_terms(int32_t operand_dtype, float* x, int32_t M, int32_t
                              float eps, const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2,
                              const float* gamma, int32_t terms, fvit_stream_t stream) {
     MlpFusedCall mc = {operand_dtype, x, M, C, hidden, ln_w, ln_b, eps, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma, terms};
+    return launch_winmlp(mc, (hipStream_t)stream);
+}
+
+size_t fvit_win_mlp_split_bytes(int32_t M, int32_t C, int32_t nsplit) { return winmlp_split_slab_bytes(M, C, nsplit); }
+
+int fvit_win_mlp_fused_split(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,
+                             float eps, const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2,
+                             const float* gamma, int32_t terms, float* slab, int32_t* counters, int32_t nsplit, fvit_stream_t stream) {
+    if (C != 512 || (nsplit != 1 && nsplit != 2 && nsplit != 4) || (nsplit > 1 && (!slab || !counters))) {
+        set_error("win_mlp_fused_split: C = %d nsplit = %d (C must be 512, nsplit 1 / 2 / 4 with scratch)", C, nsplit);
+        return FVIT_EINVAL;
+    }
+    MlpFusedCall mc = {operand_dtype, x, M, C, hidden, ln_w, ln_b, eps, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma, terms};
+    mc.slab = slab; mc.counters = counters; mc.nsplit = nsplit;
     return launch_winmlp(mc, (hipStream_t)stream);
 }
 

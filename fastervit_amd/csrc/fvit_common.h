@@ -209,7 +209,12 @@ struct MlpFusedCall {
     const float* b2;
     const float* gamma;
     int terms = 1;    // weight terms (1, or 2 = [hi image | lo image]); fvit_winmlp.hip only
+    // fvit_winmlp.hip, C = 512: split the hidden units of every 64-row group over nsplit (2 / 4) workgroups that meet in L2
+    float* slab = nullptr;     // f32 [ceil(M / 64)][nsplit][64 x C], scratch
+    int* counters = nullptr;   // int32 [ceil(M / 64)], zero before the first launch (the kernel leaves them zero)
+    int nsplit = 1;
 };
+size_t winmlp_split_slab_bytes(int64_t M, int C, int nsplit);
 bool mlp_fused_supported(int C, int hidden);
 int launch_mlp_fused(const MlpFusedCall& c, hipStream_t stream);
 // same contract for C = 512 / hidden 2048: 64-row workgroups whose 8 waves split hidden units / output channels (fvit_winmlp.hip)

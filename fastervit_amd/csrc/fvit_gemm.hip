@@ -37,6 +37,7 @@ struct GemmParams {
     void* out;
     int lda, ldw, ldo;
     int M, N, K;
+    int arow_max, wrow_max;   // last valid row of the 128-row padded operands
     int ka;       // activation columns; the contraction index k reads A column k mod ka (K = terms x ka, see GemmCall)
     int tiles_m, tiles_n;
     int stagger;  // 1: workgroup (tm, tn) walks the K tiles starting at a tile-dependent offset (see gemm_kernel)
@@ -58,7 +59,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 
 template <typename T, bool IS_W, int ROWS, int NW>
 __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int row0, int k0, char* tile,
-                                           int wave, int lane) {
+                                           int wave, int lane, int rmax) {
     // ROWS/8 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces PW*w .. PW*w + PW-1.
     constexpr int PW = ROWS / 8 / NW;
     static_assert(PW >= 1, "tile too small for this many waves");
@@ -68,7 +69,8 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
         const int r = piece * 8 + (lane >> 3);
         const int f = IS_W ? swz_w(r) : swz_x(r);
         const int c = (lane & 7) ^ f;
-        const T* src = g + (size_t)(row0 + r) * ld + k0 + c * 8;
+        // rows are clamped to the last row of the (128-row padded) operand: the 256-row tiles reach up to 128 rows further
+        const T* src = g + (size_t)min(row0 + r, rmax) * ld + k0 + c * 8;
         glds16(src, tile + piece * 1024);
     }
 }
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st) {
         if (st < nk) {
-            stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(st), xring + st * XT_BYTES, wave, lane);
-            stage_tile<T, true, BNT, NW>(W, p.ldw, n0, ktile(st) * BK, wring + st * WT_BYTES, wave, lane);
+            stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(st), xring + st * XT_BYTES, wave, lane, p.arow_max);
+            stage_tile<T, true, BNT, NW>(W, p.ldw, n0, ktile(st) * BK, wring + st * WT_BYTES, wave, lane, p.wrow_max);
         }
     }
 
@@ -174,8 +176,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             int slot = cur + NSTAGE - 1;
             if (slot >= NSTAGE) slot -= NSTAGE;
             if (nxt < nk) {
-                stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(nxt), xring + slot * XT_BYTES, wave, lane);
-                stage_tile<T, true, BNT, NW>(W, p.ldw, n0, ktile(nxt) * BK, wring + slot * WT_BYTES, wave, lane);
+                stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(nxt), xring + slot * XT_BYTES, wave, lane, p.arow_max);
+                stage_tile<T, true, BNT, NW>(W, p.ldw, n0, ktile(nxt) * BK, wring + slot * WT_BYTES, wave, lane, p.wrow_max);
             }
         }
         const char* xt = xring + cur * XT_BYTES;
@@ -294,6 +296,8 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.lda = c.lda; p.ldw = c.ldw; p.ldo = c.ldo;
     p.M = c.M; p.N = c.N; p.K = c.K;
     p.ka = c.ka > 0 ? c.ka : c.K;
+    p.arow_max = (c.M + 127) / 128 * 128 - 1;
+    p.wrow_max = (c.N + 127) / 128 * 128 - 1;
     // 256 x 256 tiles once they fill the chip (fvit_tune "gemm256_min_tiles"; 0 = never): the large Linear layers of FasterViT-4
     const int t256 = ((c.M + 255) / 256) * ((c.N + 255) / 256);
     const int min256 = tune_get("gemm256_min_tiles", 192);

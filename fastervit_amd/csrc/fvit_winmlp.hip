@@ -41,6 +41,8 @@ struct WinMlpParams {
     const float* gamma;  // [C] or null
     float eps;
     int M;
+    float* slab;     // NSPLIT > 1: f32 partial outputs [row group][NSPLIT][waves][CBW * NRB][64 lanes][4], 64 x C x 4 bytes per (row group, split)
+    int* counters;   // NSPLIT > 1: one arrival counter per row group, zero before the launch, zero again after it
 };
 
 // CC / HID: channels / hidden units; NRB: row blocks of 16 per workgroup (4: 64 rows, C = 512; 8: 128 rows, C = 256)
@@ -48,12 +50,21 @@ struct WinMlpParams {
 // SP: weight terms (FvitStageDesc.weight_terms).  SP = 2: w1f / w2f are two images back to back (hi, lo); every weight step runs once
 // per term against the SAME activation fragments (hi steps first, then lo), so the hidden activation and the output accumulate
 // X . (W_hi + W_lo) with X rounded once -- twice the weight stream and twice the MFMAs, nothing else changes.
-template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1>
+// NSPLIT (r03, C = 512): the hidden units of a 64-row group are split over NSPLIT workgroups (each: LayerNorm of the 64 rows, fc1 + GELU
+// of ITS HID / NSPLIT units, the fc2 partial sum over those units for all C channels).  One workgroup per 64 rows streams all 4 MiB of
+// weights through one CU's L2 port (65-105 GB/s: >= 40 us whatever the instruction stream does); NSPLIT = 4 streams 1 MiB per CU on four
+// CUs.  The partial outputs meet in L2: every workgroup stores its fp32 partial (128 KiB, lane-linear), releases it at agent scope and
+// takes a ticket on the row group's counter; the LAST arriver acquires, re-reads all NSPLIT partials and adds them in the FIXED order
+// split 0, 1, .. (bitwise repeatable whoever arrives last), applies bias / gamma / residual and resets the counter.  Nobody waits for
+// anybody (no spin: placement- and residency-independent).  Sibling workgroups get block ids that differ by a multiple of 8 (same XCD
+// under the observed round-robin dispatch): their partials and the rows they all read stay in one L2 (speed only, never correctness).
+template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1, int NSPLIT = 1>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinMlpParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int C = CC, KK = C / 32, CB = C / 16, NW = NWV;
     constexpr int CBW = CB / NW;                   // output channel blocks per wave (4 / 2)
-    constexpr int NSC = HID / 32 / NW;             // super-chunks: NW chunks of 32 units each, one chunk per wave
+    constexpr int NSC = HID / 32 / NW / NSPLIT;    // super-chunks of this workgroup: NW chunks of 32 units each, one chunk per wave
+    static_assert(HID % (32 * NW * NSPLIT) == 0, "hidden units must split evenly");
     constexpr int F1S = 2 * KK / 8;                // fc1 steps of 8 fragments per chunk: 4 k steps x 2 unit blocks each
     constexpr int CPS = 8 / CBW;                   // chunks per fc2 step of 8 fragments
     constexpr int F2S = NW / CPS;                  // fc2 steps per super-chunk
@@ -73,7 +84,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, s = lane & 15;
     const int lane16 = lane * 16;
-    const int row0 = blockIdx.x * (16 * NRB);
+    int rg = blockIdx.x, sp = 0;
+    if constexpr (NSPLIT > 1) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        rg = (j / NSPLIT) * 8 + xcd;
+        sp = j % NSPLIT;
+        if (rg * (16 * NRB) >= p.M) return;   // the whole sibling group is out of range (grid padded to 8 x NSPLIT)
+    }
+    const int row0 = rg * (16 * NRB);
+    const int sc0 = sp * NSC;                     // first (global) super-chunk of this workgroup
 
     const char* W1 = (const char*)p.w1f + lane16;
     const char* W2 = (const char*)p.w2f + lane16;
@@ -84,12 +103,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
         if (sc < NSC) {
             if (u < F1T) {    // fc1, term u / F1S: chunk 8 sc + wave, k steps 4uu .. 4uu + 3 (uu = u % F1S), slot (kk - 4uu) * 2 + hb
                 const int uu = u % F1S;
-                const char* b = W1 + (size_t)(u / F1S) * WBYTES + (size_t)(sc * NW + wave) * 2 * KK * 1024;
+                const char* b = W1 + (size_t)(u / F1S) * WBYTES + (size_t)((sc0 + sc) * NW + wave) * 2 * KK * 1024;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ring[slot][i] = *(const v8*)(b + ((i & 1) * KK + 4 * uu + (i >> 1)) * 1024);
             } else {          // fc2, term (u - F1T) / F2S: chunks 8 sc + CPS vv + c (vv = (u - F1T) % F2S), channel blocks CBW wave + q, slot c * CBW + q
                 const int vv = (u - F1T) % F2S;
-                const char* b = W2 + (size_t)((u - F1T) / F2S) * WBYTES + ((size_t)(sc * NW + CPS * vv) * CB + CBW * wave) * 1024;
+                const char* b = W2 + (size_t)((u - F1T) / F2S) * WBYTES + ((size_t)((sc0 + sc) * NW + CPS * vv) * CB + CBW * wave) * 1024;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ring[slot][i] = *(const v8*)(b + ((i / CBW) * CB + (i % CBW)) * 1024);
             }
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
             __builtin_amdgcn_sched_barrier(0);
             issue(u + DEPTH < SPS ? sc : sc + 1, (u + DEPTH) % SPS, u % DEPTH);
         }
-        const int j = sc * NW + wave;
+        const int j = (sc0 + sc) * NW + wave;
         const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
         const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
         const int hbuf = HBUF == 2 ? (sc & 1) : 0;
@@ -219,6 +238,52 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
         if (HBUF == 1) __syncthreads();   // single H buffer: every wave is done reading it before the next super-chunk overwrites it
     }
 
+    if constexpr (NSPLIT > 1) {
+        // ---- partial sums of the NSPLIT sibling workgroups meet in L2; the last arriver finishes the row group ----
+        constexpr int FPW = CBW * NRB;   // accumulator fragments per wave
+        f4* const slab_rg = (f4*)p.slab + (size_t)rg * NSPLIT * NW * FPW * 64;
+        {
+            f4* mine = slab_rg + ((size_t)sp * NW + wave) * FPW * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < CBW; ++q)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) mine[(q * NRB + rb) * 64] = acc2[q][rb];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* const tick = (int*)(smem + OFF_B1);   // the fc1 bias copy is dead: every wave is past its last read (barriers of the last super-chunk)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the post-write-back wait where the compiler cannot drop it
+            *tick = __hip_atomic_fetch_add(p.counters + rg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*tick != NSPLIT - 1) return;              // not the last of this row group: done
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            p.counters[rg] = 0;                        // every ticket of this launch is drawn; the next launch finds zero
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CBW; ++q) {
+#pragma unroll
+            for (int rh = 0; rh < NRB; rh += 2) {     // two row blocks at a time: 2 NSPLIT 16-byte loads in flight per lane
+                f4 part[NSPLIT][2];
+#pragma unroll
+                for (int s2 = 0; s2 < NSPLIT; ++s2)   // all NSPLIT partials are loaded the same way (own one included): no per-element select
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) part[s2][r2] = slab_rg[(((size_t)s2 * NW + wave) * FPW + q * NRB + rh + r2) * 64 + lane];
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    f4 sum = part[0][r2];
+#pragma unroll
+                    for (int s2 = 1; s2 < NSPLIT; ++s2) sum += part[s2][r2];   // fixed order
+                    acc2[q][rh + r2] = sum;
+                }
+            }
+        }
+    }
+
     // ---- epilogue: x[row][c] += gamma * (out + b2); fragment cb = CBW w + q, slot 4g + r <-> channel (cb>>2)*64 + 16g + (cb&3)*4 + r, row rb * 16 + s ----
     const bool has_g = p.gamma != nullptr;
 #pragma unroll
@@ -243,6 +308,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
 
 }  // namespace
 
+size_t winmlp_split_slab_bytes(int64_t M, int C, int nsplit) { return (size_t)((M + 63) / 64) * (size_t)nsplit * 64 * C * 4; }
+
 bool winmlp_supported(int C, int hidden) { return (C == 512 && hidden == 2048) || (C == 256 && hidden == 1024); }
 
 int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
@@ -252,13 +319,16 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     }
     WinMlpParams p;
     p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma; p.eps = c.eps; p.M = c.M;
+    p.slab = c.slab; p.counters = c.counters;
+    const int nsplit = (c.C == 512 && c.slab && c.counters && (c.nsplit == 2 || c.nsplit == 4)) ? c.nsplit : 1;
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
     ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
     const int small = c.C == 256 && tune_get("win_mlp256", 2) == 2;   // 4-wave, 64-row workgroups, two per CU
     const int rows_per_wg = c.C == 512 || small ? 64 : 128;
-    const int grid = (c.M + rows_per_wg - 1) / rows_per_wg;
-    prof_note(c.C == 512 ? "winmlp_kernel<512>" : "winmlp_kernel<256>", grid);
+    const int nrg = (c.M + rows_per_wg - 1) / rows_per_wg;
+    const int grid = nsplit > 1 ? (nrg + 7) / 8 * 8 * nsplit : nrg;
+    prof_note(c.C == 512 ? (nsplit == 4 ? "winmlp_kernel<512,split4>" : nsplit == 2 ? "winmlp_kernel<512,split2>" : "winmlp_kernel<512>") : "winmlp_kernel<256>", grid);
     if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_mlp: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
     if (c.terms != 1 && c.terms != 2) { set_error("win_mlp: weight terms %d not supported", c.terms); return FVIT_EINVAL; }
 #define FVIT_WINMLP(T, CC_, HID_, NRB_, NWV_, SP_) \
@@ -268,9 +338,19 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
         if (c.dtype == FVIT_F16) { if (c.terms == 2) FVIT_WINMLP(_Float16, CC_, HID_, NRB_, NWV_, 2); else FVIT_WINMLP(_Float16, CC_, HID_, NRB_, NWV_, 1); } \
         else { if (c.terms == 2) FVIT_WINMLP(__bf16, CC_, HID_, NRB_, NWV_, 2); else FVIT_WINMLP(__bf16, CC_, HID_, NRB_, NWV_, 1); } \
     } while (0)
-    if (c.C == 512) FVIT_WINMLP_T(512, 2048, 4, 8);
+#define FVIT_WINMLP_S(T, SP_, NS_) hipLaunchKernelGGL((winmlp_kernel<T, 512, 2048, 4, 2, 8, SP_, NS_>), dim3(grid), dim3(512), 0, stream, p)
+#define FVIT_WINMLP_ST(NS_)                                                                      \
+    do {                                                                                         \
+        if (c.dtype == FVIT_F16) { if (c.terms == 2) FVIT_WINMLP_S(_Float16, 2, NS_); else FVIT_WINMLP_S(_Float16, 1, NS_); } \
+        else { if (c.terms == 2) FVIT_WINMLP_S(__bf16, 2, NS_); else FVIT_WINMLP_S(__bf16, 1, NS_); } \
+    } while (0)
+    if (c.C == 512 && nsplit == 4) FVIT_WINMLP_ST(4);
+    else if (c.C == 512 && nsplit == 2) FVIT_WINMLP_ST(2);
+    else if (c.C == 512) FVIT_WINMLP_T(512, 2048, 4, 8);
     else if (small) FVIT_WINMLP_T(256, 1024, 4, 4);
     else FVIT_WINMLP_T(256, 1024, 8, 8);
+#undef FVIT_WINMLP_ST
+#undef FVIT_WINMLP_S
 #undef FVIT_WINMLP_T
 #undef FVIT_WINMLP
     return check_launch("winmlp_kernel");

@@ -286,10 +286,11 @@ def _signature(blocks, device, op_name, replica=False):
 # --------------------------------------------------------------------------------------------
 class _Workspace:
     """One zero-initialised scratch allocation of a stage geometry + the bookkeeping that makes sharing it between HIP streams safe."""
-    __slots__ = ("desc", "buf", "last_stream", "event")
+    __slots__ = ("desc", "descs", "buf", "last_stream", "event")
 
     def __init__(self, desc, buf):
         self.desc, self.buf = desc, buf
+        self.descs = {}
         self.last_stream = None
         self.event = None
 
@@ -402,18 +403,25 @@ def workspace_slot(slot: int):
 
 
 def _workspace(st: StageState, desc_common: dict, B: int, H: int, W: int, device) -> _Workspace:
-    # (the workspace layout does not depend on the weight terms: activations are single-rounded in every mode)
+    # (the workspace LAYOUT does not depend on the weight terms -- activations are single-rounded in every mode -- but the
+    # descriptor carries them: one scratch buffer per key, one descriptor per weight-term count)
     key = (B, desc_common["Hp"], desc_common["Wp"], H, W, desc_common["operand_dtype"], _slot())
     hit = st.workspaces.get(key)
+    terms = desc_common["weight_terms"]
     if hit is not None:
+        d = hit.descs.get(terms)
+        if d is None:
+            d = hit.descs[terms] = FvitStageDesc(batch=B, H=H, W=W, **desc_common)
+        hit.desc = d
         return hit
-    lib = _lib.lib()
     desc = FvitStageDesc(batch=B, H=H, W=W, **desc_common)
+    lib = _lib.lib()
     nbytes = lib.fvit_stage_workspace_bytes(C.byref(desc))
     if nbytes == 0:
         _lib.check(-1, "fvit_stage_workspace_bytes")
     ws_t = torch.zeros(nbytes, dtype=torch.uint8, device=device)  # zero-filled once, dedicated to this geometry
     ws = st.workspaces[key] = _Workspace(desc, ws_t)
+    ws.descs[terms] = desc
     return ws
 
 
