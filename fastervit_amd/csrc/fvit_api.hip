@@ -163,7 +163,7 @@ static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
     L.off_SLAB = L.off_CNT = 0;
     if (d.C == 512 && winmlp_supported(d.C, d.hidden)) {
         L.off_SLAB = take(winmlp_split_slab_bytes(L.Mx, d.C, 4));
-        L.off_CNT = take((size_t)((L.Mx + 63) / 64) * 4);
+        L.off_CNT = take((size_t)(L.Mx / 32 + 8) * 4);   // >= windows (winblk split) and >= 64-row groups (winmlp split)
     }
     L.total = off;
     const int want_s = fvit_attention_spad(L.S), want_g = d.hier ? fvit_attention_spad(L.G) : d.gpad;
@@ -365,6 +365,11 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         AttnBlkCall ab = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, w.attn.ln_w, w.attn.ln_b, 1e-5f, rpi,
                           w.attn.w_qkv_frag, w.attn.b_qkv_heads, w.attn.w_proj_frag, w.attn.b_proj, w.attn.gamma, w.attn.bias, X,
                           d.batch * L.nW, L.S, d.heads, d.C, scale};
+        if (L.off_SLAB && d.C == 512) {   // heads of a window split over two sibling workgroups (fvit_tune "win_blk_split" = 2)
+            ab.slab = (float*)(ws + L.off_SLAB);
+            ab.counters = (int*)(ws + L.off_CNT);
+            ab.nsplit = tune_get("win_blk_split", 1);
+        }
         FVIT_TRY(launch_winblk(ab, st));
         dbg_rowhash("win.winblk", X, L.Mx, d.C * 4, st);
     } else if (fused_attn_ok(d, w.attn, L.S, L.Mx)) {
@@ -634,6 +639,30 @@ int fvit_win_block_fused(int32_t operand_dtype, const float* srcA, int32_t rowsA
                          int32_t heads, int32_t C, float scale, fvit_stream_t stream) {
     AttnBlkCall ab = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, ln_w, ln_b, eps, rows_per_image, w_qkv_frag,
                       b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
+    return launch_winblk(ab, (hipStream_t)stream);
+}
+
+int fvit_debug_win_mlp_timeline(float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b, float eps,
+                                const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2, const float* gamma,
+                                void* stamps, fvit_stream_t stream) {
+    if (!stamps) { set_error("debug_win_mlp_timeline: null stamp buffer"); return FVIT_EINVAL; }
+    MlpFusedCall mc = {FVIT_F16, x, M, C, hidden, ln_w, ln_b, eps, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma, 1};
+    mc.ts = stamps;
+    return launch_winmlp(mc, (hipStream_t)stream);
+}
+
+int fvit_win_block_fused_split(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                               const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
+                               int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
+                               const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
+                               int32_t heads, int32_t C, float scale, float* slab, int32_t* counters, int32_t nsplit, fvit_stream_t stream) {
+    if (C != 512 || (nsplit != 1 && nsplit != 2) || (nsplit > 1 && (!slab || !counters))) {
+        set_error("win_block_fused_split: C = %d nsplit = %d (C must be 512, nsplit 1 / 2 with scratch)", C, nsplit);
+        return FVIT_EINVAL;
+    }
+    AttnBlkCall ab = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, ln_w, ln_b, eps, rows_per_image, w_qkv_frag,
+                      b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
+    ab.slab = slab; ab.counters = counters; ab.nsplit = nsplit;
     return launch_winblk(ab, (hipStream_t)stream);
 }
 

@@ -213,6 +213,7 @@ struct MlpFusedCall {
     float* slab = nullptr;     // f32 [ceil(M / 64)][nsplit][64 x C], scratch
     int* counters = nullptr;   // int32 [ceil(M / 64)], zero before the first launch (the kernel leaves them zero)
     int nsplit = 1;
+    void* ts = nullptr;        // diagnosis (fvit_debug_win_mlp_timeline): u64 [workgroups][waves][16] phase stamps
 };
 size_t winmlp_split_slab_bytes(int64_t M, int C, int nsplit);
 bool mlp_fused_supported(int C, int hidden);
@@ -245,6 +246,10 @@ struct AttnBlkCall {
     float* x_out;
     int nwin, S, heads, C;
     float scale;
+    // fvit_winblk.hip, C = 512: split the heads of every window over two workgroups that meet in L2
+    float* slab = nullptr;     // f32 [nwin][nsplit][64 x C], scratch
+    int* counters = nullptr;   // int32 [nwin], zero before the first launch (the kernel leaves them zero)
+    int nsplit = 1;
 };
 bool attnblk_supported(int C, int heads, int S);
 int launch_attnblk(const AttnBlkCall& c, hipStream_t stream);

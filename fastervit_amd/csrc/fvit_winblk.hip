@@ -49,19 +49,27 @@ struct WinBlkParams {
     float* x_out;
     int nwin, S;
     float scale;
+    float* slab;     // NSPLIT > 1: f32 partial outputs [window][NSPLIT][waves][16][64 lanes][4] (64 x C x 4 bytes per (window, split))
+    int* counters;   // NSPLIT > 1: one arrival counter per window, zero before the launch, zero again after it
 };
 
 // CC = 512: 8 waves, one workgroup per CU.  CC = 256 (stage 2, 8 heads): 4 waves (two heads and four channel blocks each, like the 8-wave
 // form), <= 256 registers and 67 KiB of LDS, so two workgroups share a CU and their phases interleave.
-template <typename T, int CC, int NWV>
+// NSPLIT = 2 (r03, C = 512): the 16 heads of a window are split over two sibling workgroups (8 heads each, one per wave): each streams
+// half of the qkv / bias / proj weights (1.15 MiB instead of 2.3 MiB through one CU's L2 port), computes the proj partial sum over ITS
+// heads for all C channels, and the two partials meet in L2 exactly as in winmlp_kernel (fp32 partial stored, agent-scope release,
+// ticket; the last arriver acquires, adds the partials in split order and applies the residual; nobody waits).
+template <typename T, int CC, int NWV, int NSPLIT = 1>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinBlkParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int C = CC, KK = C / 32, CB = C / 16, HEADS = C / 32, NW = NWV, NRB = 4, SP = 64;
-    static_assert(HEADS == 2 * NW && CB == 4 * NW, "two heads and four output channel blocks per wave");
+    constexpr int HW = HEADS / NSPLIT;             // heads of this workgroup
+    constexpr int NH = HW / NW;                    // heads per wave (2, or 1 when split)
+    static_assert(HW == NH * NW && NH >= 1 && CB == 4 * NW, "heads split evenly over the waves; four output channel blocks per wave");
     constexpr int SPH = KK + 4;                    // steps per head: KK qkv steps + 4 bias-tile steps
     constexpr int DEPTH = 2;                       // ring slots of 6 fragments (6 KiB) per wave (3 slots spill at the 256-register budget of 8 waves)
     constexpr int OFF_O = NRB * KK * 1024;         // XN: 64 KiB, then O: 64 KiB (a separate region: each head's O^T fragments leave the
-    constexpr int OFF_BQ = OFF_O + NRB * HEADS * 1024;   // registers at once -- held across the next head they spilled, and a scratch reload
+    constexpr int OFF_BQ = OFF_O + NRB * HW * 1024;      // registers at once -- held across the next head they spilled, and a scratch reload
                                                          // inside the loop queues behind the ring's prefetches and drains it)
     __shared__ __attribute__((aligned(16))) char smem[OFF_BQ + HEADS * 96 * 4];
     float* bqs = (float*)(smem + OFF_BQ);
@@ -71,7 +79,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, s = lane & 15;
     const int lane16 = lane * 16;
-    const int win = blockIdx.x;
+    int win = blockIdx.x, sp = 0;
+    if constexpr (NSPLIT > 1) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;   // siblings: block ids that differ by a multiple of 8 (same XCD, speed only)
+        win = (j / NSPLIT) * 8 + xcd;
+        sp = j % NSPLIT;
+        if (win >= p.nwin) return;
+    }
+    const int h0 = sp * HW;                         // first head of this workgroup
 
     // ---- the wave's stream: head hh of {2w, 2w+1}: 16 k steps of 6 qkv fragments, then 16 bias tiles (4 query blocks x 4 key blocks);
     //      then 16 heads x 4 proj fragments (this wave's channel blocks).  Steps are addressed by a running index. ----
@@ -94,12 +109,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
     };
     // per head KK + 4 steps; two heads; then one proj step per head of the layer.  issue(t) requests step t into slot t % DEPTH.
     auto issue = [&](int t) {
-        if (t < 2 * SPH) {
-            const int hh = t / SPH, u = t - hh * SPH, h = 2 * wave + hh;
+        if (t < NH * SPH) {
+            const int hh = t / SPH, u = t - hh * SPH, h = h0 + NH * wave + hh;
             if (u < KK) load_qkv(t % DEPTH, h, u);
             else load_bias(t % DEPTH, h, u - KK);
-        } else if (t < 2 * SPH + HEADS) {
-            load_proj(t % DEPTH, t - 2 * SPH);
+        } else if (t < NH * SPH + HW) {
+            load_proj(t % DEPTH, h0 + t - NH * SPH);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -169,11 +184,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
     }
     __syncthreads();
 
-    // ---- phase B: heads 2w, 2w + 1 ----
+    // ---- phase B: heads h0 + NH w .. + NH - 1 ----
     const char* xn = smem + lane16;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        const int h = 2 * wave + hh;
+    for (int hh = 0; hh < NH; ++hh) {
+        const int h = h0 + NH * wave + hh;
         f4 acc[6][NRB];
 #pragma unroll
         for (int ub = 0; ub < 6; ++ub)
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
                 of[r] = sat16<T>(o[0][r] * inv);
                 of[4 + r] = sat16<T>(o[1][r] * inv);
             }
-            *(v8*)(smem + OFF_O + ((qb * HEADS + h) * 1024) + lane16) = of;
+            *(v8*)(smem + OFF_O + ((qb * HW + (h - h0)) * 1024) + lane16) = of;
         }
     }
     __syncthreads();   // O^T fragments of all heads visible
@@ -281,17 +296,59 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) oacc[q][rb] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int h = 0; h < HEADS; ++h) {
-        const int t = 2 * SPH + h;
+    for (int h = 0; h < HW; ++h) {   // local head index; the ring step holds the proj fragments of head h0 + h
+        const int t = NH * SPH + h;
         v8 ob[NRB];
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) ob[rb] = *(const v8*)(xn + OFF_O + (rb * HEADS + h) * 1024);
+        for (int rb = 0; rb < NRB; ++rb) ob[rb] = *(const v8*)(xn + OFF_O + (rb * HW + h) * 1024);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) oacc[q][rb] = Op16<T>::mfma(ring[t % DEPTH][q], ob[rb], oacc[q][rb]);
         __builtin_amdgcn_sched_barrier(0);
         issue(t + DEPTH);
+    }
+
+    if constexpr (NSPLIT > 1) {
+        // ---- the two head halves meet in L2; the last arriver finishes the window (see winmlp_kernel) ----
+        f4* const slab_w = (f4*)p.slab + (size_t)win * NSPLIT * NW * 16 * 64;
+        {
+            f4* mine = slab_w + ((size_t)sp * NW + wave) * 16 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) mine[(q * NRB + rb) * 64] = oacc[q][rb];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* const tick = (int*)(smem + OFF_BQ);   // the qkv bias copy is dead after phase B
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *tick = __hip_atomic_fetch_add(p.counters + win, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*tick != NSPLIT - 1) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            p.counters[win] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f4 part[NSPLIT][NRB];
+#pragma unroll
+            for (int s2 = 0; s2 < NSPLIT; ++s2)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) part[s2][rb] = slab_w[(((size_t)s2 * NW + wave) * 16 + q * NRB + rb) * 64 + lane];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                f4 sum = part[0][rb];
+#pragma unroll
+                for (int s2 = 1; s2 < NSPLIT; ++s2) sum += part[s2][rb];   // fixed order
+                oacc[q][rb] = sum;
+            }
+        }
     }
 
     // ---- epilogue: x_out[row][c] = x_in + gamma * (out + bproj); fragment (4w + q), slot 4g + r <-> channel 64w + 16g + 4q + r, row rb * 16 + s ----
@@ -340,13 +397,19 @@ int launch_winblk(const AttnBlkCall& c, hipStream_t stream) {
     p.rowsA = c.rowsA; p.rowsB = c.rowsB; p.rows_per_image = c.rows_per_image > 0 ? c.rows_per_image : 1;
     p.wqkv_f = c.wqkv_f; p.bqkv = c.bqkv; p.wproj_f = c.wproj_f; p.bproj = c.bproj; p.gamma = c.gamma; p.bias = c.bias; p.x_out = c.x_out;
     p.nwin = c.nwin; p.S = c.S; p.scale = c.scale;
+    p.slab = c.slab; p.counters = c.counters;
+    const bool split = c.C == 512 && c.nsplit == 2 && c.slab && c.counters;
     const double rows = (double)c.nwin * c.S;
     const double flops = rows * (2.0 * c.C * 3 * c.C + 4.0 * c.S * c.C + 2.0 * c.C * c.C);
     const double bytes = rows * c.C * 8.0 + 2.0 * 4.0 * c.C * c.C;
     ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
-    prof_note(c.C == 512 ? "winblk_kernel<512,S64>" : "winblk_kernel<256,S64>", c.nwin);
+    const int grid = split ? (c.nwin + 7) / 8 * 8 * 2 : c.nwin;
+    prof_note(c.C == 512 ? (split ? "winblk_kernel<512,S64,split2>" : "winblk_kernel<512,S64>") : "winblk_kernel<256,S64>", grid);
     if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_block: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
-    if (c.C == 512) {
+    if (split) {
+        if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winblk_kernel<_Float16, 512, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((winblk_kernel<__bf16, 512, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
+    } else if (c.C == 512) {
         if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winblk_kernel<_Float16, 512, 8>), dim3(c.nwin), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((winblk_kernel<__bf16, 512, 8>), dim3(c.nwin), dim3(512), 0, stream, p);
     } else {

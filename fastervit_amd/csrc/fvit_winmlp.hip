@@ -43,7 +43,17 @@ struct WinMlpParams {
     int M;
     float* slab;     // NSPLIT > 1: f32 partial outputs [row group][NSPLIT][waves][CBW * NRB][64 lanes][4], 64 x C x 4 bytes per (row group, split)
     int* counters;   // NSPLIT > 1: one arrival counter per row group, zero before the launch, zero again after it
+    unsigned long long* ts;   // TS instances only (fvit_debug_win_mlp_timeline): s_memtime stamps [workgroup][wave][16]
 };
+
+// phase stamps of the TS (timeline) instances: 0 kernel entry, 1 first ring steps issued, 2 rows loaded, 3 LayerNorm written + barrier,
+// 4 .. 4 + NSC - 1 end of super-chunk sc (capped at slot 13), 14 before the epilogue, 15 end
+template <bool TS>
+__device__ __forceinline__ void stamp(const WinMlpParams& p, int wave, int lane, int nw, int k) {
+    if constexpr (TS) {
+        if (p.ts && lane == 0) p.ts[((size_t)blockIdx.x * nw + wave) * 16 + (k < 15 ? k : 15)] = __builtin_amdgcn_s_memtime();
+    }
+}
 
 // CC / HID: channels / hidden units; NRB: row blocks of 16 per workgroup (4: 64 rows, C = 512; 8: 128 rows, C = 256)
 // NWV: waves per workgroup (8: one workgroup per CU; 4: 256 registers per wave and <= 70 KiB of LDS, two workgroups per CU whose phases interleave)
@@ -58,7 +68,7 @@ struct WinMlpParams {
 // split 0, 1, .. (bitwise repeatable whoever arrives last), applies bias / gamma / residual and resets the counter.  Nobody waits for
 // anybody (no spin: placement- and residency-independent).  Sibling workgroups get block ids that differ by a multiple of 8 (same XCD
 // under the observed round-robin dispatch): their partials and the rows they all read stay in one L2 (speed only, never correctness).
-template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1, int NSPLIT = 1>
+template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1, int NSPLIT = 1, bool TS = false>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinMlpParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int C = CC, KK = C / 32, CB = C / 16, NW = NWV;
@@ -94,6 +104,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
     const int row0 = rg * (16 * NRB);
     const int sc0 = sp * NSC;                     // first (global) super-chunk of this workgroup
 
+    stamp<TS>(p, wave, lane, NWV, 0);
     const char* W1 = (const char*)p.w1f + lane16;
     const char* W2 = (const char*)p.w2f + lane16;
     v8 ring[DEPTH][8];
@@ -127,6 +138,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
 #pragma unroll
         for (int i = 0; i < HID / NT; ++i) b1s[tid + NT * i] = c1[i];
     }
+    stamp<TS>(p, wave, lane, NWV, 1);
 
     // ---- phase A: LayerNorm; WPR waves share a row block: each reads the full rows and writes KK / WPR of the k steps ----
     {
@@ -142,6 +154,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
         sum = sum_xor32(sum_xor16(sum));
+        stamp<TS>(p, wave, lane, NWV, 2);
         const float mean = sum / (float)C;
         float sq = 0.f;
 #pragma unroll
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
         }
     }
     __syncthreads();
+    stamp<TS>(p, wave, lane, NWV, 3);
 
     const char* xn = smem + lane16;
     f4 acc2[CBW][NRB];
@@ -236,7 +250,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
             issue(u + DEPTH < SPS ? sc : sc + 1, (u + DEPTH) % SPS, u % DEPTH);
         }
         if (HBUF == 1) __syncthreads();   // single H buffer: every wave is done reading it before the next super-chunk overwrites it
+        stamp<TS>(p, wave, lane, NWV, sc + 4 < 13 ? sc + 4 : 13);
     }
+    stamp<TS>(p, wave, lane, NWV, 14);
 
     if constexpr (NSPLIT > 1) {
         // ---- partial sums of the NSPLIT sibling workgroups meet in L2; the last arriver finishes the row group ----
@@ -304,6 +320,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
             }
         }
     }
+    if constexpr (TS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp<TS>(p, wave, lane, NWV, 15);
+    }
 }
 
 }  // namespace
@@ -319,7 +339,7 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     }
     WinMlpParams p;
     p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma; p.eps = c.eps; p.M = c.M;
-    p.slab = c.slab; p.counters = c.counters;
+    p.slab = c.slab; p.counters = c.counters; p.ts = (unsigned long long*)c.ts;
     const int nsplit = (c.C == 512 && c.slab && c.counters && (c.nsplit == 2 || c.nsplit == 4)) ? c.nsplit : 1;
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
@@ -344,7 +364,10 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
         if (c.dtype == FVIT_F16) { if (c.terms == 2) FVIT_WINMLP_S(_Float16, 2, NS_); else FVIT_WINMLP_S(_Float16, 1, NS_); } \
         else { if (c.terms == 2) FVIT_WINMLP_S(__bf16, 2, NS_); else FVIT_WINMLP_S(__bf16, 1, NS_); } \
     } while (0)
-    if (c.C == 512 && nsplit == 4) FVIT_WINMLP_ST(4);
+    if (c.ts && c.dtype == FVIT_F16 && c.terms == 1 && nsplit == 1 && (c.C == 512 || small)) {   // timeline instances (diagnosis)
+        if (c.C == 512) hipLaunchKernelGGL((winmlp_kernel<_Float16, 512, 2048, 4, 2, 8, 1, 1, true>), dim3(grid), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((winmlp_kernel<_Float16, 256, 1024, 4, 2, 4, 1, 1, true>), dim3(grid), dim3(256), 0, stream, p);
+    } else if (c.C == 512 && nsplit == 4) FVIT_WINMLP_ST(4);
     else if (c.C == 512 && nsplit == 2) FVIT_WINMLP_ST(2);
     else if (c.C == 512) FVIT_WINMLP_T(512, 2048, 4, 8);
     else if (small) FVIT_WINMLP_T(256, 1024, 4, 4);

@@ -288,6 +288,13 @@ int fvit_win_block_fused(int32_t operand_dtype, const float* srcA, int32_t rowsA
                          const float* b_qkv_heads, const void* w_proj_frag, const float* b_proj, const float* gamma,
                          const float* bias, float* x_out, int32_t nwin, int32_t S, int32_t heads, int32_t C, float scale,
                          fvit_stream_t stream);
+/* C = 512 only: the 16 heads of every window split over nsplit (1, 2) workgroups that meet in L2 (as fvit_win_mlp_fused_split).
+ *   slab     f32 scratch, nwin * nsplit * 64 * C * 4 bytes;  counters int32 [nwin], ZERO before the first launch (left zero). */
+int fvit_win_block_fused_split(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                               const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
+                               int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
+                               const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
+                               int32_t heads, int32_t C, float scale, float* slab, int32_t* counters, int32_t nsplit, fvit_stream_t stream);
 
 /* The whole carrier-token branch of one HAT block in one kernel (AR:679-686), one workgroup per image:
  *   ct[b][i] = X[b * rowsA + src_idx[i]] (+ add[i]);  ct += gamma1 * attn(LayerNorm1(ct));  ct += gamma2 * mlp(LayerNorm2(ct))  -> R [batch * G][C]
@@ -415,6 +422,12 @@ int fvit_debug_rowhash_dump(int32_t record, void* dst, int64_t capacity_bytes);
  * fragments; per hidden chunk: the W1 fragments as read from LDS, the pre-GELU accumulators, the GELU output fragment, the W2 fragments as
  * read, the output accumulators) to consecutive slices of buf: [workgroup * 4 + wave][1 + 5 * hidden / 32][64 lanes] words.  _end returns
  * the number of traced launches (<= 64) with their slice offsets (words) and row counts.  Single host thread only. */
+/* Phase timeline of the N-split MLP kernel (fp16, one weight term; C = 512, or C = 256 in its 4-wave form): the same launch as
+ * fvit_win_mlp_fused with lane 0 of every wave writing s_memtime stamps, u64 [workgroups][waves][16]:
+ * 0 entry, 1 first ring steps issued, 2 rows loaded, 3 LayerNorm published, 4..13 end of super-chunk, 14 before the epilogue, 15 end. */
+int fvit_debug_win_mlp_timeline(float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b, float eps,
+                                const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2, const float* gamma,
+                                void* stamps, fvit_stream_t stream);
 int fvit_debug_mlp_trace_begin(void* buf, int64_t capacity_words);
 int fvit_debug_mlp_trace_end(int64_t* offsets, int32_t* rows, int32_t max_launches);
 /* same protocol: every C = 256 fused-MLP launch stores its input rows exactly as its own loads returned them ([M][256] floats per launch) */

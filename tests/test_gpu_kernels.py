@@ -590,6 +590,21 @@ def test_attn_block_fused(opname, dt, code, S, nwin, use_tables, use_gamma, C):
     if out_win is not None:
         assert torch.isfinite(out_win).all()
         assert (out_win - ref).abs().max().item() < tol, f"win_block: {(out_win - ref).abs().max().item()} vs {tol}"
+    if S > 48 and C == 512:   # r03: the 16 heads split over two sibling workgroups that meet in L2 (last-arriver reduction in split order)
+        slab = torch.full((nwin * 2 * 64 * C,), float("nan"), device="cuda")
+        cnt = torch.zeros(nwin, dtype=torch.int32, device="cuda")
+        outs = []
+        for _ in range(3):
+            o2 = torch.full((rows, C), float("nan"), device="cuda")
+            _lib.check(lib.fvit_win_block_fused_split(*args, o2.data_ptr(), nwin, S, heads, C, ctypes.c_float(scale), slab.data_ptr(), cnt.data_ptr(), 2,
+                                                      _stream()), "win_block_fused_split")
+            torch.cuda.synchronize()
+            assert int(cnt.abs().sum().item()) == 0
+            outs.append(o2)
+        assert torch.isfinite(outs[0]).all()
+        assert (outs[0] - ref).abs().max().item() < tol
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert (outs[0] - out_win).abs().max().item() < 1e-4 * ref.abs().max().item()   # same numbers up to the order of the two partial sums
 
 
 @pytest.mark.parametrize("opname,dt,code", OPS)
