@@ -200,12 +200,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     dispatch_epilogue(p.act, R != nullptr, [&](auto act_tag, auto res_tag) {
         constexpr int ACT = decltype(act_tag)::value;
         constexpr bool RES = decltype(res_tag)::value != 0;
+        // residual rows of all four pixels first (r03): the residual map IS the output map (in-place update), so in one
+        // load-update-store loop every store had to stay ahead of the next pixel's load -- four dependent round trips per lane
+        vout rvs[4];
+        if (RES) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) rvs[mi] = *(const vout*)(R + (size_t)min(m0 + wm * 64 + mi * 16 + s, p.M - 1) * p.Cout + nb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int m = m0 + wm * 64 + mi * 16 + s;
             if (m < p.M) {
                 vout rv;
-                if (RES) rv = *(const vout*)(R + (size_t)m * p.Cout + nb);
+                if (RES) rv = rvs[mi];
                 vout ov;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {

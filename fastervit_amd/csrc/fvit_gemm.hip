@@ -241,6 +241,32 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             gam[j * 4 + 0] = t[0]; gam[j * 4 + 1] = t[1]; gam[j * 4 + 2] = t[2]; gam[j * 4 + 3] = t[3];
         }
         float* X = (float*)p.out;
+        if (!p.add) {
+            // two passes (r03): all residual rows first, then the updates and stores -- in one load-update-store loop every store
+            // had to stay ahead of the next load (possible alias): 4 MI dependent round trips per lane
+            f4 xr[MI][4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = min(m0 + wm * (16 * MI) + mi * 16 + s, p.M - 1);   // clamped for the load
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) xr[mi][ni] = *(const f4*)(X + (size_t)m * p.ldo + nb + ni * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = m0 + wm * (16 * MI) + mi * 16 + s;
+                if (m < p.M) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        f4 x = xr[mi][ni];
+                        const f4 a = acc[cg * 4 + ni][mi];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[r] += gam[ni * 4 + r] * (a[r] + bias[ni * 4 + r]);
+                        *(f4*)(X + (size_t)m * p.ldo + nb + ni * 4) = x;
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = m0 + wm * (16 * MI) + mi * 16 + s;
@@ -262,6 +288,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
                     *(f4*)(px + ni * 4) = x;
                 }
             }
+        }
         }
     } else {
         T* O = (T*)p.out;

@@ -301,7 +301,28 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
     }
 
     // ---- epilogue: x[row][c] += gamma * (out + b2); fragment cb = CBW w + q, slot 4g + r <-> channel (cb>>2)*64 + 16g + (cb&3)*4 + r, row rb * 16 + s ----
+    // Two passes (r03): ALL loads first, then the updates and stores.  Written as one load-update-store loop the compiler had to keep
+    // every store ahead of the next iteration's loads (they may alias): 16 dependent L2 / HBM round trips per lane, 8-12 us of a 45-76 us
+    // workgroup (phase timeline, profiles/r03_winmlp_phase_timeline.log).
     const bool has_g = p.gamma != nullptr;
+    f4 bvq[CBW], glq[CBW], xv[NRB][CBW];
+#pragma unroll
+    for (int q = 0; q < CBW; ++q) {
+        const int cb = CBW * wave + q;
+        const int c0 = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
+        bvq[q] = *(const f4*)(p.b2 + c0);
+        glq[q] = *(const f4*)((has_g ? p.gamma : p.b2) + c0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+        const int row = min(row0 + rb * 16 + s, p.M - 1);   // clamped for the load; rows >= M are not stored
+#pragma unroll
+        for (int q = 0; q < CBW; ++q) {
+            const int cb = CBW * wave + q;
+            xv[rb][q] = *(const f4*)(p.x + (size_t)row * C + (cb >> 2) * 64 + g * 16 + (cb & 3) * 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
         const int row = row0 + rb * 16 + s;
@@ -309,14 +330,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
 #pragma unroll
             for (int q = 0; q < CBW; ++q) {
                 const int cb = CBW * wave + q;
-                const int c0 = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
-                float* px = p.x + (size_t)row * C + c0;
-                f4 xv = *(const f4*)px;
-                const f4 bv = *(const f4*)(p.b2 + c0);
-                const f4 gl = *(const f4*)((has_g ? p.gamma : p.b2) + c0);
+                f4 o = xv[rb][q];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xv[r] += (has_g ? gl[r] : 1.f) * (acc2[q][rb][r] + bv[r]);
-                *(f4*)px = xv;
+                for (int r = 0; r < 4; ++r) o[r] += (has_g ? glq[q][r] : 1.f) * (acc2[q][rb][r] + bvq[q][r]);
+                *(f4*)(p.x + (size_t)row * C + (cb >> 2) * 64 + g * 16 + (cb & 3) * 4) = o;
             }
         }
     }

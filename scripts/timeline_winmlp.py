@@ -45,13 +45,20 @@ for C, M, nw in ((256, 18240, 4), (512, 4214, 8), (256, 54272, 4), (512, 12544, 
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3
-        t = ts.view(nwg, nw, 16).double()
-        t0 = t[..., 0].min()
-        span = (t[..., 15].max() - t0).item()
+        raw = ts.view(nwg, nw, 16)
+        nz = raw[raw != 0]
+        print(f"  raw stamps: {int((raw == 0).sum())} zero of {raw.numel()}, min nonzero {int(nz.min())}, max {int(nz.max())}; first wave: {raw[0, 0].tolist()}")
+        base = int(nz.min())
+        t = (raw - base).double()
+        t[raw == 0] = float("nan")
+        t0 = t[..., 0][~torch.isnan(t[..., 0])].min()
+        span = (t[..., 15][~torch.isnan(t[..., 15])].max() - t0).item()
         ghz = span / us / 1e3
         print(f"\nC={C} M={M} ({nwg} workgroups x {nw} waves) {'COLD' if cold else 'warm'}: launch {us:.1f} us, stamp span {span:.0f} ticks -> {ghz:.2f} GHz equivalent")
-        print(f"  workgroup start skew (entry - first entry): mean {((t[..., 0] - t0).mean() / ghz / 1e3).item():.2f} us, max {((t[..., 0] - t0).max() / ghz / 1e3).item():.2f} us")
-        print(f"  workgroup duration (entry -> end): mean {((t[..., 15] - t[..., 0]).mean() / ghz / 1e3).item():.2f} us, max {((t[..., 15] - t[..., 0]).max() / ghz / 1e3).item():.2f} us")
+        sk = (t[..., 0] - t0) / ghz / 1e3
+        du = (t[..., 15] - t[..., 0]) / ghz / 1e3
+        print(f"  workgroup start skew (entry - first entry): mean {sk.nanmean().item():.2f} us, max {sk[~torch.isnan(sk)].max().item():.2f} us")
+        print(f"  workgroup duration (entry -> end): mean {du.nanmean().item():.2f} us, max {du[~torch.isnan(du)].max().item():.2f} us")
         nsc = hid // 32 // nw
         idx = [0, 1, 2, 3] + [4 + i for i in range(min(nsc, 10))] + [14, 15]
         for a, b in zip(idx[:-1], idx[1:]):
@@ -61,4 +68,5 @@ for C, M, nw in ((256, 18240, 4), (512, 4214, 8), (256, 54272, 4), (512, 12544, 
                 name = "last sc -> pre-epilogue"
             if a == 14:
                 name = "epilogue"
-            print(f"  {a:2d}->{b:2d} {name:28s} mean {d.mean().item():7.2f} us   max {d.max().item():7.2f} us")
+            dd = d[~torch.isnan(d)]
+            print(f"  {a:2d}->{b:2d} {name:28s} mean {dd.mean().item():7.2f} us   max {dd.max().item():7.2f} us   (n {dd.numel()})")
