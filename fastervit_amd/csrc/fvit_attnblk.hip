@@ -402,6 +402,7 @@ bool attnblk_supported(int C, int heads, int S) {
 }
 
 int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
+    if (ablate_skip(8)) return FVIT_OK;
     if (!attnblk_supported(c.C, c.heads, c.S) || c.nwin <= 0 || !c.wqkv_f || !c.wproj_f || !c.x_out) {
         set_error("attn_block: unsupported arguments C=%d heads=%d S=%d nwin=%d", c.C, c.heads, c.S, c.nwin);
         return FVIT_EINVAL;

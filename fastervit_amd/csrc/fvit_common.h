@@ -152,6 +152,10 @@ int check_launch(const char* what);
 
 // ---- tuning knobs (A/B experiments inside one process; see fvit_tune in fvit_hip.h) ----
 int tune_get(const char* key, int dflt);
+// timing ablation (results are WRONG when non-zero; bench A/B only): skip the launches of a kernel family to measure its marginal cost
+// inside the concurrent stream shards.  bits: 1 winmlp<256>, 2 winmlp<512>, 4 winblk, 8 attnblk, 16 ctblk, 32 conv3x3 implicit GEMM,
+// 64 halo conv, 128 fused stem
+inline bool ablate_skip(int bit) { return (tune_get("ablate_skip", 0) & bit) != 0; }
 
 // ---- diagnostics state (kernel timer records, row-hash / MLP traces, poison sink) is process-global: every access -- including
 // the ones inside ProfScope, i.e. on every launch -- takes this mutex, so that host threads driving different devices / streams

@@ -763,8 +763,10 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
 template <typename T>
 int launch_t(ConvParams& p, hipStream_t stream) {
     if (p.Cin == 64 && p.Cout == 64 && p.stride == 1 && tune_get("conv_halo", 1)) {
+        if (ablate_skip(64)) return FVIT_OK;
         return launch_halo_t<T>(p, stream);
     }
+    if (ablate_skip(32)) return FVIT_OK;
     const double flops = 2.0 * p.M * (double)p.Cout * 9.0 * p.Cin;
     const double bytes = 2.0 * ((double)p.B * p.Hi * p.Wi * p.Cin + (double)p.M * p.Cout * (p.res ? 2.0 : 1.0) + 9.0 * p.Cin * p.Cout);
     ProfScope prof(FVIT_K_CONV, flops, bytes, stream);
@@ -862,6 +864,7 @@ extern "C" int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void*
         set_error("stem_fused: null or empty argument");
         return FVIT_EINVAL;
     }
+    if (fvit::ablate_skip(128)) return FVIT_OK;
     StemFusedParams p;
     p.in = *in; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.B = B; p.Hi = Hi; p.Wi = Wi;
     p.H1 = (Hi - 1) / 2 + 1; p.W1 = (Wi - 1) / 2 + 1;

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
 bool ctblk_supported(int C, int heads, int G, int hidden) { return C == 256 && heads == 8 && hidden == 1024 && G >= 1 && G <= 16; }
 
 int launch_ctblk(const CtBlkCall& c, hipStream_t stream) {
+    if (ablate_skip(16)) return FVIT_OK;
     if (!ctblk_supported(c.C, c.heads, c.G, c.hidden) || c.batch <= 0 || !c.X || !c.src_idx || !c.R || !c.wqkv_f || !c.wproj_f || !c.w1f || !c.w2f ||
         !c.bias || !c.bqkv) {
         set_error("ct_block: unsupported arguments C=%d heads=%d G=%d hidden=%d batch=%d", c.C, c.heads, c.G, c.hidden, c.batch);

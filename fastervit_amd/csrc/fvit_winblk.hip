@@ -413,6 +413,7 @@ int launch_winblk(const AttnBlkCall& c, hipStream_t stream) {
         set_error("win_block: unsupported arguments C=%d heads=%d S=%d nwin=%d", c.C, c.heads, c.S, c.nwin);
         return FVIT_EINVAL;
     }
+    if (ablate_skip(4)) return FVIT_OK;
     WinBlkParams p;
     p.srcA = c.srcA; p.srcB = c.srcB; p.src_idx = c.src_idx; p.add_idx = c.add_idx; p.add = c.add; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.eps = c.eps;
     p.rowsA = c.rowsA; p.rowsB = c.rowsB; p.rows_per_image = c.rows_per_image > 0 ? c.rows_per_image : 1;

@@ -354,6 +354,7 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
         set_error("win_mlp: unsupported arguments C=%d hidden=%d M=%d", c.C, c.hidden, c.M);
         return FVIT_EINVAL;
     }
+    if (ablate_skip(c.C == 512 ? 2 : 1)) return FVIT_OK;
     WinMlpParams p;
     p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma; p.eps = c.eps; p.M = c.M;
     p.slab = c.slab; p.counters = c.counters; p.ts = (unsigned long long*)c.ts;
