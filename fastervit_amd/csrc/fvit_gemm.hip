@@ -340,7 +340,9 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     //   grid128 <= nw8_max  : 8 waves per workgroup (default off: no gain, see gemm_kernel)
     const int nw8_max = tune_get("gemm_nw8_max_grid", 0), bm64_max = tune_get("gemm_bm64_max_grid", 400);
     const bool nw8 = !big && grid128 <= nw8_max;
-    const bool small = !big && grid128 <= bm64_max;   // 64-row tiles
+    // 64-row tiles only for short K (r03 sweep, profiles/r03_gemm_and_shard_launch_knob_sweeps.log): the long-K residual GEMMs of FasterViT-4
+    // (K = 2048 .. 6272, cold weights: every K step is a memory-side round trip) want more MFMA work per step: +2.6 % images/s
+    const bool small = !big && grid128 <= bm64_max && c.K <= tune_get("gemm_bm64_max_k", 1024);   // 64-row tiles
     p.tiles_m = big ? (c.M + 255) / 256 : small ? (c.M + 63) / 64 : (c.M + 127) / 128;
     const int grid = p.tiles_m * p.tiles_n;
     const double flops = 2.0 * c.M * (double)c.N * p.ka;   // algorithmic: the extra weight terms are a precision cost, not work
