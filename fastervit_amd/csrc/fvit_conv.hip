@@ -585,6 +585,8 @@ struct StemFusedParams {
     void* out;           // [B][H2][W2][64]
     int B, Hi, Wi, H1, W1, H2, W2;
     int tiles_x, tiles_y, tiles;
+    unsigned long long* ts;   // TS instance only (fvit_debug_stem_timeline): per wave [workgroup][wave][8] accumulated s_memtime ticks:
+                              // 0 phase A (gathers + conv1 + LDS writes), 1 barrier after A, 2 phase B, 3 epilogue, 4 barrier before A, 5 tiles, 6 total
 };
 
 constexpr int SF_ROWS = 2 * HALO_TH + 1, SF_COLS = 2 * HALO_TW + 1;         // 17 x 33 conv1 pixels per tile
@@ -592,10 +594,16 @@ constexpr int SF_PLANE = (HALO_TW + 1) * 128;                                // 
 constexpr int SF_ROWPITCH = 2 * SF_PLANE;                                    // plane E (17 px) then plane O (16 px + 1 unused)
 constexpr int SF_LDS = SF_ROWS * SF_ROWPITCH;                                // 73 984 B
 constexpr int SF_GROUPS = (SF_ROWS * SF_COLS + 15) / 16;                     // 36 groups of 16 conv1 pixels
-constexpr int SF_BATCH = 2;                                                  // groups whose gathers are in flight together (3 spills)
+constexpr int SF_BATCH = 3;                                                  // groups whose gathers are in flight together (r03: 3 fit since the per-lane gather constants; r01 / r02: 2)
 
-template <typename T>
+// IN: element type of the caller's image (float / _Float16 / __bf16) -- a compile-time parameter since r03: as a runtime switch it put two
+// scalar branches around every gathered element (~40 instructions per element, the whole of phase A: 12 of the 16.6 us a tile took)
+template <typename T, typename IN = float, bool TS = false>
 __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
+    unsigned long long tsA = 0, tsBar = 0, tsB = 0, tsE = 0, tsBar0 = 0, tsN = 0, tsT0 = 0, tsMark = 0;
+    unsigned pf_sink = 0;   // keeps the next-tile touch loads alive
+    if constexpr (TS) { tsT0 = __builtin_amdgcn_s_memtime(); }
+#define FVIT_SF_MARK(acc) if constexpr (TS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tsMark; tsMark = now_; }
     typedef typename Op16<T>::v8 v8;
     extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
     float* sb1 = (float*)smem_dyn;             // [64]
@@ -643,7 +651,9 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
         const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
         const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
         const int r0 = 2 * ty * HALO_TH - 1, c0 = 2 * tx * HALO_TW - 1;      // conv1 coordinates of local (0, 0)
+        if constexpr (TS) { tsMark = __builtin_amdgcn_s_memtime(); tsN += 1; }
         __syncthreads();   // every wave is done reading the previous tile's conv1 image (and sb1 / sb2 are visible)
+        FVIT_SF_MARK(tsBar0)
 
         // ================= phase A: conv1 + bias + ReLU of the tile's 17 x 33 conv1 pixels -> LDS =================
         {
@@ -653,12 +663,49 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
             v8 w1f[4];
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) w1f[ni] = *(const v8*)(W1 + ((lane_s >> 2) * 16 + ni * 4 + (lane_s & 3)) * 32 + lane_g * 8);
-            // per-image base pointer is wave-uniform (SGPRs); per-lane offsets inside one image fit 32 bits
-            const int esz = p.in.dtype == FVIT_F32 ? 4 : 2;
+            // per-image base pointer is wave-uniform (SGPRs); per-lane BYTE offsets inside one image fit 32 bits (unsigned: SGPR base +
+            // 32-bit VGPR offset addressing, no 64-bit address arithmetic per element)
+            constexpr int esz = (int)sizeof(IN);
             const char* ib = (const char*)p.in.data + (int64_t)b * p.in.stride_b * esz;
-            const int sc = (int)p.in.stride_c, sh = (int)p.in.stride_h, sw = (int)p.in.stride_w;
+            const int sc = (int)p.in.stride_c * esz, sh = (int)p.in.stride_h * esz, sw = (int)p.in.stride_w * esz;
+            // per-lane constants of the gather (r03): k slot 8g + e = (ky, kx, c) is fixed per lane, so its input offset and the border
+            // cases it can hit are too -- the per-element k / 9, r9 / 3, four compares and the select chain (~35 VALU per element, 78 % of
+            // the kernel in phase A: profiles/r03_stem_phase_accounting.log) collapse to one add and one bit test
+            int koff[8];
+            unsigned m_valid = 0, m_ky0 = 0, m_ky2 = 0, m_kx0 = 0, m_kx2 = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = lane_g * 8 + e;
+                const int ky = k / 9, r9 = k - ky * 9, kx = r9 / 3, c = r9 - kx * 3;
+                koff[e] = c * sc + ky * sh + kx * sw;
+                m_valid |= (k < 27 ? 1u : 0u) << e;
+                m_ky0 |= (ky == 0 ? 1u : 0u) << e;
+                m_ky2 |= (ky == 2 ? 1u : 0u) << e;
+                m_kx0 |= (kx == 0 ? 1u : 0u) << e;
+                m_kx2 |= (kx == 2 ? 1u : 0u) << e;
+            }
             // 9 groups per wave, SF_BATCH at a time: the scalar gathers of a batch are in flight together (with ~250 VGPRs there are
             // only two waves per SIMD to hide their latency; one group at a time costs nine memory round trips per tile)
+            // touch the NEXT tile's input patch (r03): the gathers below are the first touch of their lines, i.e. memory-side latency three
+            // times per tile and wave (12 of the 16.6 us a tile takes, profiles/r03_stem_phase_accounting.log).  One dword per 128-byte
+            // line of the next tile's 35 rows x 3 planes x 67 columns, requested BEFORE this tile's gathers (which wait for the same kind of
+            // miss anyway) and folded into a sink after them: a tile later its gathers find their lines in L2.
+            unsigned pf0 = 0, pf1 = 0;
+            const bool do_pf = false && esz == 4 && sw == esz && tile + per_xcd < t_end;   // measured r03: no gain (the gathers are instruction-bound, not miss-bound): off
+            if (do_pf) {
+                const int nt = tile + per_xcd;
+                const int ntx = nt % p.tiles_x, nt2 = nt / p.tiles_x;
+                const int nty = nt2 % p.tiles_y, nbi = nt2 / p.tiles_y;
+                const int y0 = 4 * nty * HALO_TH - 3, x0 = 4 * ntx * HALO_TW - 3;     // 2 * (2 ty TH - 1) - 1
+                const unsigned* nib = (const unsigned*)((const char*)p.in.data + (int64_t)nbi * p.in.stride_b * 4);
+                const int it0 = tid, it1 = tid + 256;                                  // 105 (row, plane) pairs x 4 column probes = 420 items
+                const int rc0 = it0 >> 2, rc1 = it1 >> 2;
+                const int xa = min(max(x0 + ((it0 & 3) < 3 ? 32 * (it0 & 3) : 66), 0), p.Wi - 1);
+                const int xb = min(max(x0 + ((it1 & 3) < 3 ? 32 * (it1 & 3) : 66), 0), p.Wi - 1);
+                const int ya = min(max(y0 + rc0 / 3, 0), p.Hi - 1), yb = min(max(y0 + rc1 / 3, 0), p.Hi - 1);
+                pf0 = nib[rc0 < 105 ? ((rc0 % 3) * sc + ya * sh + xa * sw) >> 2 : 0];
+                pf1 = nib[rc1 < 105 ? ((rc1 % 3) * sc + yb * sh + xb * sw) >> 2 : 0];
+            }
             for (int g3 = wave; g3 < SF_GROUPS; g3 += 4 * SF_BATCH) {
                 v8 xfb[SF_BATCH];
                 int qv[SF_BATCH], lrv[SF_BATCH], lcv[SF_BATCH];
@@ -671,18 +718,19 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
                     const bool v1 = q < SF_ROWS * SF_COLS && R >= 0 && R < p.H1 && Cc >= 0 && Cc < p.W1;
                     const int yi = 2 * R - 1, xi = 2 * Cc - 1;
                     qv[u] = q; lrv[u] = lr; lcv[u] = lc; v1v[u] = v1;
+                    // rows / columns yi .. yi + 2, xi .. xi + 2 leave the image only through the first tap (yi = -1) or the last one
+                    unsigned mask = v1 ? m_valid : 0u;
+                    if (yi < 0) mask &= ~m_ky0;
+                    if (yi + 2 >= p.Hi) mask &= ~m_ky2;
+                    if (xi < 0) mask &= ~m_kx0;
+                    if (xi + 2 >= p.Wi) mask &= ~m_kx2;
+                    const int base = yi * sh + xi * sw;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int k = lane_g * 8 + e;
-                        const int ky = k / 9, r9 = k - ky * 9, kx = r9 / 3, c = r9 - kx * 3;
-                        const int y = yi + ky, x = xi + kx;
-                        const bool inb = v1 && k < 27 && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi;
+                        const bool inb = (mask >> e) & 1u;
                         // always a legal address (the image's first element when masked), then select
-                        const int off = inb ? c * sc + y * sh + x * sw : 0;
-                        float val;
-                        if (p.in.dtype == FVIT_F32) val = ((const float*)ib)[off];
-                        else if (p.in.dtype == FVIT_F16) val = (float)((const _Float16*)ib)[off];
-                        else val = (float)((const __bf16*)ib)[off];
+                        const unsigned off = inb ? (unsigned)(base + koff[e]) : 0u;
+                        const float val = (float)*(const IN*)(ib + off);
                         xfb[u][e] = (T)(inb ? val : 0.f);
                     }
                 }
@@ -711,8 +759,11 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
                     }
                 }
             }
+            pf_sink ^= pf0 ^ pf1;
         }
+        FVIT_SF_MARK(tsA)
         __syncthreads();
+        FVIT_SF_MARK(tsBar)
 
         // ================= phase B: conv2 (stride 2) over the LDS image, weights in registers =================
         const char* hb = img + (2 * ph * 4) * SF_ROWPITCH;
@@ -741,6 +792,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        FVIT_SF_MARK(tsB)
         // ---- epilogue: bias + ReLU, out[b][y][x][nb .. nb+7] for rows y = 8ty + 4ph + mi, column x = 16tx + s ----
         const f4 t0 = *(const f4*)(sb2 + nb), t1 = *(const f4*)(sb2 + nb + 4);
         const float bias[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
@@ -757,7 +809,16 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
                 *(v8*)(O + (((size_t)b * p.H2 + y) * p.W2 + x) * 64 + nb) = ov;
             }
         }
+        FVIT_SF_MARK(tsE)
     }
+    if (pf_sink == 0x9E3779B1u && p.tiles == -12345) ((unsigned*)p.out)[0] = pf_sink;   // never true
+    if constexpr (TS) {
+        if (p.ts && lane == 0) {
+            unsigned long long* o = p.ts + ((size_t)blockIdx.x * 4 + wave) * 8;
+            o[0] = tsA; o[1] = tsBar; o[2] = tsB; o[3] = tsE; o[4] = tsBar0; o[5] = tsN; o[6] = __builtin_amdgcn_s_memtime() - tsT0; o[7] = 0;
+        }
+    }
+#undef FVIT_SF_MARK
 }
 
 template <typename T>
@@ -858,8 +919,24 @@ extern "C" int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const v
     return check_launch("stem_conv_kernel");
 }
 
+static int stem_fused_impl(int32_t dtype, const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2,
+                           void* out, int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream, void* stamps);
+
 extern "C" int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2,
                                void* out, int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream) {
+    return stem_fused_impl(dtype, in, w1, b1, w2, b2, out, B, Hi, Wi, stream, nullptr);
+}
+
+// diagnosis: the fp16 kernel with per-wave phase accumulators (u64 [workgroups <= 512][4 waves][8]: ticks in phase A, barrier after A, phase B,
+// epilogue, barrier before A, tiles processed, total)
+extern "C" int fvit_debug_stem_timeline(const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
+                                        int32_t B, int32_t Hi, int32_t Wi, void* stamps, fvit_stream_t stream) {
+    if (!stamps) { set_error("debug_stem_timeline: null stamp buffer"); return FVIT_EINVAL; }
+    return stem_fused_impl(FVIT_F16, in, w1, b1, w2, b2, out, B, Hi, Wi, stream, stamps);
+}
+
+static int stem_fused_impl(int32_t dtype, const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2,
+                           void* out, int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream, void* stamps) {
     if (!in || !in->data || !w1 || !b1 || !w2 || !b2 || !out || B <= 0 || Hi <= 0 || Wi <= 0) {
         set_error("stem_fused: null or empty argument");
         return FVIT_EINVAL;
@@ -877,6 +954,7 @@ extern "C" int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void*
         return FVIT_EINVAL;
     }
     p.tiles = (int)tiles;
+    p.ts = (unsigned long long*)stamps;
     int maxgrid = tune_get("stem_fused_grid", 512);
     if (maxgrid < 8) maxgrid = 8;
     const int grid = p.tiles < maxgrid ? p.tiles : maxgrid;
@@ -885,19 +963,32 @@ extern "C" int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void*
     const double bytes = (double)B * 3 * Hi * Wi * (in->dtype == FVIT_F32 ? 4 : 2) + 2.0 * M2 * 64;
     ProfScope prof(FVIT_K_CONV, 2.0 * M1 * 64 * 27 + 2.0 * M2 * 64 * 576, bytes, (hipStream_t)stream);
     prof_note("stem_fused_kernel", grid);
-    if (dtype == FVIT_F16) {
-        static DeviceOnce once;
-        if (once.first_on_current_device())
-            hipFuncSetAttribute((const void*)stem_fused_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((stem_fused_kernel<_Float16>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+#define FVIT_STEM_LAUNCH(T_, IN_, TS_)                                                                                                   \
+    do {                                                                                                                                 \
+        static DeviceOnce once;                                                                                                          \
+        if (once.first_on_current_device())                                                                                              \
+            hipFuncSetAttribute((const void*)stem_fused_kernel<T_, IN_, TS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        hipLaunchKernelGGL((stem_fused_kernel<T_, IN_, TS_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);                      \
+    } while (0)
+#define FVIT_STEM_IN(T_)                                                                   \
+    do {                                                                                   \
+        if (in->dtype == FVIT_F32) FVIT_STEM_LAUNCH(T_, float, false);                     \
+        else if (in->dtype == FVIT_F16) FVIT_STEM_LAUNCH(T_, _Float16, false);             \
+        else if (in->dtype == FVIT_BF16) FVIT_STEM_LAUNCH(T_, __bf16, false);              \
+        else { set_error("stem_fused: input dtype %d not supported", in->dtype); return FVIT_EINVAL; } \
+    } while (0)
+    if (stamps) {
+        if (in->dtype != FVIT_F32) { set_error("debug_stem_timeline: fp32 input only"); return FVIT_EINVAL; }
+        FVIT_STEM_LAUNCH(_Float16, float, true);
+    } else if (dtype == FVIT_F16) {
+        FVIT_STEM_IN(_Float16);
     } else if (dtype == FVIT_BF16) {
-        static DeviceOnce once;
-        if (once.first_on_current_device())
-            hipFuncSetAttribute((const void*)stem_fused_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((stem_fused_kernel<__bf16>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+        FVIT_STEM_IN(__bf16);
     } else {
         set_error("stem_fused: dtype %d not supported (16-bit output only)", dtype);
         return FVIT_EINVAL;
     }
+#undef FVIT_STEM_IN
+#undef FVIT_STEM_LAUNCH
     return check_launch("stem_fused_kernel");
 }

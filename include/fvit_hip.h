@@ -422,6 +422,11 @@ int fvit_debug_rowhash_dump(int32_t record, void* dst, int64_t capacity_bytes);
  * fragments; per hidden chunk: the W1 fragments as read from LDS, the pre-GELU accumulators, the GELU output fragment, the W2 fragments as
  * read, the output accumulators) to consecutive slices of buf: [workgroup * 4 + wave][1 + 5 * hidden / 32][64 lanes] words.  _end returns
  * the number of traced launches (<= 64) with their slice offsets (words) and row counts.  Single host thread only. */
+/* Phase accounting of the fused stem kernel (fp16): the same launch as fvit_stem_fused with every wave accumulating s_memtime ticks per phase,
+ * u64 [workgroups (<= 512)][4 waves][8]: 0 phase A (gathers + conv1 + LDS writes), 1 barrier after A, 2 phase B (conv2), 3 epilogue,
+ * 4 barrier before A, 5 tiles processed, 6 kernel entry -> exit. */
+int fvit_debug_stem_timeline(const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
+                             int32_t B, int32_t Hi, int32_t Wi, void* stamps, fvit_stream_t stream);
 /* Phase timeline of the N-split MLP kernel (fp16, one weight term; C = 512, or C = 256 in its 4-wave form): the same launch as
  * fvit_win_mlp_fused with lane 0 of every wave writing s_memtime stamps, u64 [workgroups][waves][16]:
  * 0 entry, 1 first ring steps issued, 2 rows loaded, 3 LayerNorm published, 4..13 end of super-chunk, 14 before the epilogue, 15 end. */

@@ -36,13 +36,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "fv4":   # r03: the Linear layers of Fas
               ("fv4 s3 fc1 shard", 2107, 6272, 1600, 1), ("fv4 s3 fc2 shard", 2107, 1568, 6272, 2),
               ("fv4 s2 qkv full", 27136, 3072, 832, 0), ("fv4 s2 fc1 full", 27136, 3136, 832, 1), ("fv4 s2 fc2 full", 27136, 784, 3136, 2),
               ("fv4 s3 fc1 full", 6272, 6272, 1600, 1), ("fv4 s3 fc2 full", 6272, 1568, 6272, 2),
-              ("anyres s2 qkv", 17760, 3072, 832, 0), ("anyres s2 fc2", 17760, 784, 3136, 2), ("8192^3/8", 8192, 8192, 1024, 0)]
+              ("anyres s2 qkv", 17760, 3072, 832, 0), ("anyres s2 fc2", 17760, 784, 3136, 2), ("8192x8192x1024", 8192, 8192, 1024, 0),
+              ("8192x8192x4096", 8192, 8192, 4096, 0), ("4096^3", 4096, 4096, 4096, 0)]
 g = torch.Generator(device="cpu").manual_seed(0)
 for name, M, N, K, epi in SHAPES:
-    Mp = (M + 127) // 128 * 128
+    Mp = (M + 255) // 256 * 256
     NBUF = 6   # rotate operands so that a launch does not find its own A tile in L2 from the previous launch
     As = [torch.randn(Mp, K, generator=g).to(dt).cuda() for _ in range(NBUF)]
-    W = (torch.randn((N + 127) // 128 * 128, K, generator=g) / K ** 0.5).to(dt).cuda()
+    W = (torch.randn((N + 255) // 256 * 256, K, generator=g) / K ** 0.5).to(dt).cuda()
     bias = torch.zeros(N).cuda()
     gamma = torch.ones(N).cuda()
     X = [torch.zeros(Mp, N).cuda() for _ in range(NBUF)]

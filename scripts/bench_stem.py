@@ -47,3 +47,23 @@ for rnd in range(2):
         e1.record()
         torch.cuda.synchronize()
         print(f"B={B} {name:12s}: {e0.elapsed_time(e1) * 1e3 / 20:7.1f} us", flush=True)
+
+# phase accounting of the fused kernel (fvit_debug_stem_timeline): ticks per wave accumulated over its tiles
+ts = torch.zeros(512 * 4 * 8, dtype=torch.int64, device="cuda")
+v = hat_runtime._map_view(xs[0])
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+_lib.check(lib.fvit_debug_stem_timeline(C.byref(v), wk1.data_ptr(), b1.data_ptr(), wk2.data_ptr(), b2.data_ptr(), out.data_ptr(), B, 224, 224,
+                                        ts.data_ptr(), st), "timeline")
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3
+t = ts.view(512, 4, 8).double()
+t = t[t[..., 5] > 0]
+tot = t[:, 6]
+ghz = tot.max().item() / us / 1e3
+print(f"timeline launch {us:.1f} us; {t.shape[0]} waves, tiles per wave mean {t[:, 5].mean().item():.2f}; longest wave {tot.max().item():.0f} ticks -> {ghz:.2f} ticks/ns")
+for i, name in enumerate(["phase A (gathers + conv1 + LDS writes)", "barrier after A", "phase B (conv2)", "epilogue (bias, ReLU, stores)", "barrier before A"]):
+    per_tile = (t[:, i] / t[:, 5]) / ghz / 1e3
+    print(f"  {name:40s} {100 * (t[:, i].sum() / tot.sum()).item():5.1f} % of wave time   {per_tile.mean().item():6.2f} us per tile (max {per_tile.max().item():.2f})")
+print(f"  wave total per tile {((tot / t[:, 5]) / ghz / 1e3).mean().item():.2f} us")
