@@ -373,12 +373,14 @@ def run_secondary(args, dev):
     """BASELINE configs 3 and 5, a few steps each (N = 1 only): throughput, parity on 2 images vs the oracle, dominant-shape roofline."""
     from fastervit_amd import dp
     res = []
-    specs = [("faster_vit_4_224", 128, None, {}),
-             ("faster_vit_4_any_res", 8, (576, 960), dict(resolution=[576, 960], window_size=[7, 7, 12, 6], ct_size=2))]
-    for name, batch, hw, kw in specs:
+    # stream shards per configuration: 3 for batch 128; 2 for the 8-image any-res batch (3 / 3 / 2 images per shard lose to 4 / 4: 553 vs 573
+    # images/s, profiles/r03_gemm_and_shard_launch_knob_sweeps.log)
+    specs = [("faster_vit_4_224", 128, None, {}, args.streams),
+             ("faster_vit_4_any_res", 8, (576, 960), dict(resolution=[576, 960], window_size=[7, 7, 12, 6], ct_size=2), min(args.streams, 2))]
+    for name, batch, hw, kw, nstreams in specs:
         t0 = time.perf_counter()
         try:
-            cfg = Config(args, dev, 0, name, batch, hw=hw, model_kwargs=kw, streams=args.streams)
+            cfg = Config(args, dev, 0, name, batch, hw=hw, model_kwargs=kw, streams=nstreams)
             cfg.prepare()
             elapsed = dp.timed_steps(cfg.step, args.secondary_steps, 3, torch.cuda.synchronize, None, dev)
             logits = cfg.logits()
