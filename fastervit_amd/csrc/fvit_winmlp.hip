@@ -82,7 +82,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
     constexpr int SPS = F1T + F2T;                 // steps per super-chunk (8 / 4 per term)
     constexpr size_t WBYTES = (size_t)HID * C * 2; // one fragment-order image of fc1 (= of fc2)
     static_assert(SPS % DEPTH == 0, "ring slots must be static inside the super-chunk loop");
-    constexpr int WPR = NW / NRB;                  // waves sharing a row block in the LayerNorm phase (2 / 1)
+    constexpr bool LN_EVEN = NW % NRB == 0;        // else (NRB = 5 / 6 with 8 waves): waves 0 .. NRB - 1 take one whole row block each in phase A
+    constexpr int WPR = LN_EVEN ? NW / NRB : 1;    // waves sharing a row block in the LayerNorm phase (2 / 1)
     constexpr int HBUF = (NRB * KK + 2 * NW * NRB) * 1024 + HID * 4 <= (NW == 8 ? 150 : 72) * 1024 ? 2 : 1;   // H double-buffered when it fits
     constexpr int OFF_H = NRB * KK * 1024;         // XN: 64 KiB; H: HBUF x NW x NRB KiB; fc1 bias
     constexpr int OFF_B1 = OFF_H + HBUF * NW * NRB * 1024;
@@ -141,9 +142,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
     stamp<TS>(p, wave, lane, NWV, 1);
 
     // ---- phase A: LayerNorm; WPR waves share a row block: each reads the full rows and writes KK / WPR of the k steps ----
-    {
+    if (LN_EVEN || wave < NRB) {
         constexpr int KP = KK / WPR;
-        const int rb = wave / WPR, part = wave % WPR;
+        const int rb = LN_EVEN ? wave / WPR : wave, part = LN_EVEN ? wave % WPR : 0;
         const int row = min(row0 + rb * 16 + s, p.M - 1);
         const float* src = p.x + (size_t)row * C;
         f4 v[2 * KK];
@@ -362,11 +363,26 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
     ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
-    const int small = c.C == 256 && tune_get("win_mlp256", 2) == 2;   // 4-wave, 64-row workgroups, two per CU
-    const int rows_per_wg = c.C == 512 || small ? 64 : 128;
+    // C = 256 forms (fvit_tune "win_mlp256"): 1 = 8 waves x 128 rows; 2 (default) = 4 waves x 64 rows, two workgroups per CU; 3 (r03, opt-in) = 2,
+    // except when 64-row workgroups would be just over one per CU (257 .. 384 row groups: the launch then lasts as long as its few doubled-up
+    // CUs, and everywhere else ONE 4-wave workgroup leaves every LDS round trip / vmcnt wait / GELU chain exposed,
+    // profiles/r03_winmlp_phase_timeline.log): then 8 waves x 80 or 96 rows = at most 256 workgroups, one per CU, two waves per SIMD, each weight
+    // fragment feeding 5 / 6 MFMAs.  Measured r03 (call 14, A/B in one box): the launch gets 24 % shorter (50.4 -> 38.2 us, 0.15 -> 0.20 of the
+    // MFMA peak, bitwise the same result) and the STEP gets slower (81.9k -> 80.6k images/s): 124 KiB of LDS and 8 x 200 registers take the
+    // whole CU, the 4-wave form (68 KiB, 4 x 210) leaves half of it to the other stream shards' kernels.  Same lesson as the r02 LDS rule.
+    const int form = c.C == 256 ? tune_get("win_mlp256", 2) : 0;
+    const int n64 = (c.M + 63) / 64;
+    int wide = 0;   // row blocks of the adaptive 8-wave form (0: not used)
+    if (form == 3 && n64 > 256 && !c.ts) {
+        if ((c.M + 79) / 80 <= 256) wide = 5;
+        else if ((c.M + 95) / 96 <= 256) wide = 6;
+    }
+    const int small = c.C == 256 && (form == 2 || form == 3) && !wide;   // 4-wave, 64-row workgroups, two per CU
+    const int rows_per_wg = wide ? 16 * wide : (c.C == 512 || small ? 64 : 128);
     const int nrg = (c.M + rows_per_wg - 1) / rows_per_wg;
     const int grid = nsplit > 1 ? (nrg + 7) / 8 * 8 * nsplit : nrg;
-    prof_note(c.C == 512 ? (nsplit == 4 ? "winmlp_kernel<512,split4>" : nsplit == 2 ? "winmlp_kernel<512,split2>" : "winmlp_kernel<512>") : "winmlp_kernel<256>", grid);
+    prof_note(c.C == 512 ? (nsplit == 4 ? "winmlp_kernel<512,split4>" : nsplit == 2 ? "winmlp_kernel<512,split2>" : "winmlp_kernel<512>")
+                         : (wide == 5 ? "winmlp_kernel<256,80rows>" : wide == 6 ? "winmlp_kernel<256,96rows>" : "winmlp_kernel<256>"), grid);
     if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_mlp: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
     if (c.terms != 1 && c.terms != 2) { set_error("win_mlp: weight terms %d not supported", c.terms); return FVIT_EINVAL; }
 #define FVIT_WINMLP(T, CC_, HID_, NRB_, NWV_, SP_) \
@@ -388,6 +404,8 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     } else if (c.C == 512 && nsplit == 4) FVIT_WINMLP_ST(4);
     else if (c.C == 512 && nsplit == 2) FVIT_WINMLP_ST(2);
     else if (c.C == 512) FVIT_WINMLP_T(512, 2048, 4, 8);
+    else if (wide == 5) FVIT_WINMLP_T(256, 1024, 5, 8);
+    else if (wide == 6) FVIT_WINMLP_T(256, 1024, 6, 8);
     else if (small) FVIT_WINMLP_T(256, 1024, 4, 4);
     else FVIT_WINMLP_T(256, 1024, 8, 8);
 #undef FVIT_WINMLP_ST
