@@ -156,7 +156,10 @@ __device__ __forceinline__ int64_t token_row(const MapParams& p, int b, int y, i
 }
 
 // --- channels-last: one wave per pixel ---
-template <bool REVERSE>
+// MT: element type of the map (compile-time since r03: load_elem / store_elem's runtime dtype switch cost a branch per element and, on the
+// 16-bit paths, a drained load per element).  VEC: C % 8 == 0 and a 16-byte aligned, channel-contiguous map: a lane moves 8 channels at a time
+// (one 16-byte map access, two 16-byte row accesses) instead of one.
+template <bool REVERSE, typename MT, bool VEC>
 __global__ __launch_bounds__(256) void map_rows_cl_kernel(MapParams p) {
     const int lane = threadIdx.x & 63;
     const int hh = REVERSE ? p.H : p.Hp, wwid = REVERSE ? p.W : p.Wp;
@@ -167,19 +170,46 @@ __global__ __launch_bounds__(256) void map_rows_cl_kernel(MapParams p) {
     const int y = rem / wwid, xx = rem - y * wwid;
     const int64_t trow = token_row(p, b, y, xx);
     float* xr = p.x + trow * p.C;
-    const int64_t moff = b * p.map.stride_b + y * p.map.stride_h + xx * p.map.stride_w;
-    if (!REVERSE) {
-        for (int c = lane; c < p.C; c += 64) xr[c] = load_elem(p.map.data, moff + c * p.map.stride_c, p.map.dtype);
-    } else {
-        const float* cr = nullptr;
-        if (p.up_idx) {
-            const int tok = (int)((trow % p.rows_per_win) - p.row_off);
-            cr = p.x + (trow - (trow % p.rows_per_win) + p.up_idx[tok]) * p.C;
+    MT* mp = (MT*)p.map.data + b * p.map.stride_b + y * p.map.stride_h + xx * p.map.stride_w;
+    const float* cr = nullptr;
+    if (REVERSE && p.up_idx) {
+        const int tok = (int)((trow % p.rows_per_win) - p.row_off);
+        cr = p.x + (trow - (trow % p.rows_per_win) + p.up_idx[tok]) * p.C;
+    }
+    if constexpr (VEC) {
+        typedef MT m8 __attribute__((ext_vector_type(8)));
+        for (int c = lane * 8; c < p.C; c += 512) {
+            if (!REVERSE) {
+                const m8 v = *(const m8*)(mp + c);
+                f4 a, bq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a[r] = (float)v[r]; bq[r] = (float)v[4 + r]; }
+                *(f4*)(xr + c) = a;
+                *(f4*)(xr + c + 4) = bq;
+            } else {
+                f4 a = *(const f4*)(xr + c), bq = *(const f4*)(xr + c + 4);
+                if (cr) {
+                    const f4 ca = *(const f4*)(cr + c), cb = *(const f4*)(cr + c + 4);
+                    const f4 ga = p.gamma ? *(const f4*)(p.gamma + c) : (f4){1.f, 1.f, 1.f, 1.f};
+                    const f4 gb = p.gamma ? *(const f4*)(p.gamma + c + 4) : (f4){1.f, 1.f, 1.f, 1.f};
+                    a += ga * ca;
+                    bq += gb * cb;
+                }
+                m8 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = (MT)a[r]; v[4 + r] = (MT)bq[r]; }
+                *(m8*)(mp + c) = v;
+            }
         }
-        for (int c = lane; c < p.C; c += 64) {
-            float v = xr[c];
-            if (cr) v += (p.gamma ? p.gamma[c] : 1.f) * cr[c];
-            store_elem(p.map.data, moff + c * p.map.stride_c, p.map.dtype, v);
+    } else {
+        if (!REVERSE) {
+            for (int c = lane; c < p.C; c += 64) xr[c] = (float)mp[c * p.map.stride_c];
+        } else {
+            for (int c = lane; c < p.C; c += 64) {
+                float v = xr[c];
+                if (cr) v += (p.gamma ? p.gamma[c] : 1.f) * cr[c];
+                mp[c * p.map.stride_c] = (MT)v;
+            }
         }
     }
 }
@@ -293,6 +323,11 @@ struct TokParams {
     int B, C, Hp, Wp, kh, kw, sh, sw, Ho, Wo, cw;
 };
 
+// IN: element type of the map (compile-time since r03: the runtime dtype switch of load_elem put a branch and -- on the 16-bit paths -- an
+// s_waitcnt vmcnt(0) around every one of the 49 patch elements: 49 dependent L2 round trips per thread, 33 us for a 0.4-MFLOP op).
+// SMALL: the (kh + 2) x (kw + 2) input patch fits 8 x 8 (pooling windows up to 6 x 6: every 224 / any-res entrypoint): the loops are fully
+// unrolled, every load is issued (clamped address, masked weight) before the first use.  Larger windows (21k 384 / 512 / 768) take the loop form.
+template <typename IN, bool SMALL>
 __global__ __launch_bounds__(256) void token_init_kernel(TokParams p) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int G = p.Ho * p.Wo;
@@ -306,28 +341,59 @@ __global__ __launch_bounds__(256) void token_init_kernel(TokParams p) {
     float wv[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) wv[j] = p.w[c * 9 + j];
-    const int64_t base = b * p.in.stride_b + c * p.in.stride_c;
+    const IN* __restrict__ src = (const IN*)p.in.data + b * p.in.stride_b + c * p.in.stride_c;
     // sum over the pooling window of the 3x3 depthwise responses == weighted sum over the (kh+2) x (kw+2) input patch:
     // input (dy, dx) feeds conv outputs (dy - ky, dx - kx) relative to the window, valid for ky in [max(0, dy-kh+1), min(2, dy)]
     // and the same for kx -- the effective weight is separable into a valid-ky column sum and a valid-kx range sum
     float acc = 0.f;
     const int y0 = oy * p.sh - 1, x0 = ox * p.sw - 1;
-    for (int dy = 0; dy < p.kh + 2; ++dy) {
-        const int y = y0 + dy;
-        if (y < 0 || y >= p.Hp) continue;
-        const int ky_lo = max(0, dy - p.kh + 1), ky_hi = min(2, dy);
-        // static register indexing only (a runtime-indexed register array would go to scratch)
-        const float m0 = (ky_lo <= 0 && ky_hi >= 0) ? 1.f : 0.f, m1 = (ky_lo <= 1 && ky_hi >= 1) ? 1.f : 0.f, m2 = ky_hi >= 2 ? 1.f : 0.f;
-        const float cw0 = m0 * wv[0] + m1 * wv[3] + m2 * wv[6];
-        const float cw1 = m0 * wv[1] + m1 * wv[4] + m2 * wv[7];
-        const float cw2 = m0 * wv[2] + m1 * wv[5] + m2 * wv[8];
-        const int64_t rowoff = base + y * p.in.stride_h;
-        for (int dx = 0; dx < p.kw + 2; ++dx) {
-            const int x = x0 + dx;
-            if (x < 0 || x >= p.Wp) continue;
-            const int kx_lo = max(0, dx - p.kw + 1), kx_hi = min(2, dx);
-            const float wsum = (kx_lo <= 0 && kx_hi >= 0 ? cw0 : 0.f) + (kx_lo <= 1 && kx_hi >= 1 ? cw1 : 0.f) + (kx_hi >= 2 ? cw2 : 0.f);
-            acc += wsum * load_elem(p.in.data, rowoff + x * p.in.stride_w, p.in.dtype);
+    if constexpr (SMALL) {
+        float val[8][8];
+#pragma unroll
+        for (int dy = 0; dy < 8; ++dy) {
+            const int y = min(max(y0 + dy, 0), p.Hp - 1);
+#pragma unroll
+            for (int dx = 0; dx < 8; ++dx) {
+                const int x = min(max(x0 + dx, 0), p.Wp - 1);
+                val[dy][dx] = (float)src[y * p.in.stride_h + x * p.in.stride_w];   // clamped: always a legal address; masked by the weight below
+            }
+        }
+#pragma unroll
+        for (int dy = 0; dy < 8; ++dy) {
+            const int y = y0 + dy;
+            const bool yok = dy < p.kh + 2 && y >= 0 && y < p.Hp;
+            const int ky_lo = max(0, dy - p.kh + 1), ky_hi = min(2, dy);
+            const float m0 = (yok && ky_lo <= 0 && ky_hi >= 0) ? 1.f : 0.f, m1 = (yok && ky_lo <= 1 && ky_hi >= 1) ? 1.f : 0.f, m2 = (yok && ky_hi >= 2) ? 1.f : 0.f;
+            const float cw0 = m0 * wv[0] + m1 * wv[3] + m2 * wv[6];
+            const float cw1 = m0 * wv[1] + m1 * wv[4] + m2 * wv[7];
+            const float cw2 = m0 * wv[2] + m1 * wv[5] + m2 * wv[8];
+#pragma unroll
+            for (int dx = 0; dx < 8; ++dx) {
+                const int x = x0 + dx;
+                const bool xok = dx < p.kw + 2 && x >= 0 && x < p.Wp;
+                const int kx_lo = max(0, dx - p.kw + 1), kx_hi = min(2, dx);
+                const float wsum = (kx_lo <= 0 && kx_hi >= 0 ? cw0 : 0.f) + (kx_lo <= 1 && kx_hi >= 1 ? cw1 : 0.f) + (kx_hi >= 2 ? cw2 : 0.f);
+                acc += (xok ? wsum : 0.f) * val[dy][dx];
+            }
+        }
+    } else {
+        for (int dy = 0; dy < p.kh + 2; ++dy) {
+            const int y = y0 + dy;
+            if (y < 0 || y >= p.Hp) continue;
+            const int ky_lo = max(0, dy - p.kh + 1), ky_hi = min(2, dy);
+            // static register indexing only (a runtime-indexed register array would go to scratch)
+            const float m0 = (ky_lo <= 0 && ky_hi >= 0) ? 1.f : 0.f, m1 = (ky_lo <= 1 && ky_hi >= 1) ? 1.f : 0.f, m2 = ky_hi >= 2 ? 1.f : 0.f;
+            const float cw0 = m0 * wv[0] + m1 * wv[3] + m2 * wv[6];
+            const float cw1 = m0 * wv[1] + m1 * wv[4] + m2 * wv[7];
+            const float cw2 = m0 * wv[2] + m1 * wv[5] + m2 * wv[8];
+            const IN* rowp = src + y * p.in.stride_h;
+            for (int dx = 0; dx < p.kw + 2; ++dx) {
+                const int x = x0 + dx;
+                if (x < 0 || x >= p.Wp) continue;
+                const int kx_lo = max(0, dx - p.kw + 1), kx_hi = min(2, dx);
+                const float wsum = (kx_lo <= 0 && kx_hi >= 0 ? cw0 : 0.f) + (kx_lo <= 1 && kx_hi >= 1 ? cw1 : 0.f) + (kx_hi >= 2 ? cw2 : 0.f);
+                acc += wsum * (float)rowp[x * p.in.stride_w];
+            }
         }
     }
     p.out[i] = acc / (float)(p.kh * p.kw) + p.bias[c];
@@ -338,8 +404,15 @@ int launch_map(const MapParams& p, bool reverse, hipStream_t stream) {
     if (p.map.stride_c == 1) {
         const int64_t pix = (int64_t)p.batch * hh * wwid;
         const int grid = (int)((pix + 3) / 4);
-        if (reverse) hipLaunchKernelGGL((map_rows_cl_kernel<true>), dim3(grid), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((map_rows_cl_kernel<false>), dim3(grid), dim3(256), 0, stream, p);
+        const int esz = p.map.dtype == FVIT_F32 ? 4 : 2;
+        const bool vec = esz == 2 && p.C % 8 == 0 && ((uintptr_t)p.map.data % 16) == 0 && (p.map.stride_b * esz) % 16 == 0 && (p.map.stride_h * esz) % 16 == 0 &&
+                         (p.map.stride_w * esz) % 16 == 0;
+#define FVIT_MAP_CL(MT_, VEC_) do { if (reverse) hipLaunchKernelGGL((map_rows_cl_kernel<true, MT_, VEC_>), dim3(grid), dim3(256), 0, stream, p); \
+                                    else hipLaunchKernelGGL((map_rows_cl_kernel<false, MT_, VEC_>), dim3(grid), dim3(256), 0, stream, p); } while (0)
+        if (p.map.dtype == FVIT_F32) FVIT_MAP_CL(float, false);
+        else if (p.map.dtype == FVIT_F16) { if (vec) FVIT_MAP_CL(_Float16, true); else FVIT_MAP_CL(_Float16, false); }
+        else { if (vec) FVIT_MAP_CL(__bf16, true); else FVIT_MAP_CL(__bf16, false); }
+#undef FVIT_MAP_CL
     } else {
         const int tiles_p = (hh * wwid + 63) / 64, tiles_c = (p.C + 31) / 32;
         const int grid = p.batch * tiles_p * tiles_c;
@@ -433,7 +506,15 @@ int launch_token_init(const FvitMapView& in, const float* w, const float* bias, 
     }
     const int64_t n = (int64_t)B * p.Ho * p.Wo * C;
     ProfScope prof(FVIT_K_OTHER, 0.0, (double)B * C * Hp * Wp * 2.0 + 4.0 * n, stream);
-    hipLaunchKernelGGL(token_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    const bool small_patch = kh + 2 <= 8 && kw + 2 <= 8;
+#define FVIT_TOK(IN_) do { if (small_patch) hipLaunchKernelGGL((token_init_kernel<IN_, true>), grid, dim3(256), 0, stream, p); \
+                           else hipLaunchKernelGGL((token_init_kernel<IN_, false>), grid, dim3(256), 0, stream, p); } while (0)
+    if (in.dtype == FVIT_F32) FVIT_TOK(float);
+    else if (in.dtype == FVIT_F16) FVIT_TOK(_Float16);
+    else if (in.dtype == FVIT_BF16) FVIT_TOK(__bf16);
+    else { set_error("token_init: map dtype %d not supported", in.dtype); return FVIT_EINVAL; }
+#undef FVIT_TOK
     return check_launch("token_init_kernel");
 }
 
