@@ -621,8 +621,8 @@ size_t fvit_win_mlp_split_bytes(int32_t M, int32_t C, int32_t nsplit) { return w
 int fvit_win_mlp_fused_split(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,
                              float eps, const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2,
                              const float* gamma, int32_t terms, float* slab, int32_t* counters, int32_t nsplit, fvit_stream_t stream) {
-    if (C != 512 || (nsplit != 1 && nsplit != 2 && nsplit != 4) || (nsplit > 1 && (!slab || !counters))) {
-        set_error("win_mlp_fused_split: C = %d nsplit = %d (C must be 512, nsplit 1 / 2 / 4 with scratch)", C, nsplit);
+    if (C != 512 || (nsplit != 1 && nsplit != 2) || (nsplit > 1 && (!slab || !counters))) {
+        set_error("win_mlp_fused_split: C = %d nsplit = %d (C must be 512, nsplit 1 / 2 with scratch)", C, nsplit);
         return FVIT_EINVAL;
     }
     MlpFusedCall mc = {operand_dtype, x, M, C, hidden, ln_w, ln_b, eps, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma, terms};

@@ -352,53 +352,34 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
     }
 
     // ---- epilogue: x_out[row][c] = x_in + gamma * (out + bproj); fragment (4w + q), slot 4g + r <-> channel 64w + 16g + 4q + r, row rb * 16 + s ----
-    // Two passes (r03, as in winmlp_kernel): first the row tables, then ALL row / parameter loads, then the updates and stores -- one
-    // load-update-store loop serialises into dependent round trips (table -> row -> store -> next table ...).
+    // (r03 tried the two-pass form of winmlp_kernel here -- all row / add loads first: no shorter launch, 57.4 vs 57.8 us, and at 256 registers it
+    // tipped instances into scratch; the r02 loop stays)
     const bool has_g = p.gamma != nullptr;
     const int c0 = wave * 64 + g * 16;
-    const float* srcs[NRB];
-    const float* adds[NRB];
-    int64_t rows[NRB];
-    int sis[NRB], ais[NRB], bs[NRB];
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
-        const int tok = rb * 16 + s;
-        rows[rb] = (int64_t)win * p.S + (tok < p.S ? tok : p.S - 1);   // clamped for the loads; padded tokens are not stored
-        bs[rb] = (int)(rows[rb] / p.rows_per_image);
-        const int pr = (int)(rows[rb] - (int64_t)bs[rb] * p.rows_per_image);
-        sis[rb] = p.src_idx ? p.src_idx[pr] : 0;
-        ais[rb] = p.add ? (p.add_idx ? p.add_idx[pr] : pr) : -1;
-    }
-    f4 xv[NRB][4], av[NRB][4], bv[4], gl[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        bv[q] = *(const f4*)(p.bproj + c0 + q * 4);
-        gl[q] = *(const f4*)((has_g ? p.gamma : p.bproj) + c0 + q * 4);
-    }
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
-        if (p.src_idx) srcs[rb] = sis[rb] >= 0 ? p.srcA + ((size_t)bs[rb] * p.rowsA + sis[rb]) * C : p.srcB + ((size_t)bs[rb] * p.rowsB + (-sis[rb] - 1)) * C;
-        else srcs[rb] = p.srcA + (size_t)rows[rb] * C;
-        adds[rb] = ais[rb] >= 0 ? p.add + (size_t)ais[rb] * C : srcs[rb];   // no add row: a valid address, its value is not used
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            xv[rb][q] = *(const f4*)(srcs[rb] + c0 + q * 4);
-            av[rb][q] = *(const f4*)(adds[rb] + c0 + q * 4);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
         const int tok = rb * 16 + s;
         if (tok < p.S) {
-            float* px = p.x_out + (size_t)rows[rb] * C + c0;
+            const int64_t row = (int64_t)win * p.S + tok;
+            const int b = (int)(row / p.rows_per_image), pr = (int)(row - (int64_t)b * p.rows_per_image);
+            const float* src;
+            if (p.src_idx) {
+                const int si = p.src_idx[pr];
+                src = si >= 0 ? p.srcA + ((size_t)b * p.rowsA + si) * C : p.srcB + ((size_t)b * p.rowsB + (-si - 1)) * C;
+            } else {
+                src = p.srcA + (size_t)row * C;
+            }
+            const int ai = p.add ? (p.add_idx ? p.add_idx[pr] : pr) : -1;
+            float* px = p.x_out + (size_t)row * C + c0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f4 o = xv[rb][q];
-                if (ais[rb] >= 0) o += av[rb][q];
+                f4 xv = *(const f4*)(src + c0 + q * 4);
+                if (ai >= 0) xv += *(const f4*)(p.add + (size_t)ai * C + c0 + q * 4);
+                const f4 bv = *(const f4*)(p.bproj + c0 + q * 4);
+                const f4 gl = *(const f4*)((has_g ? p.gamma : p.bproj) + c0 + q * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += (has_g ? gl[q][r] : 1.f) * (oacc[q][rb][r] + bv[q][r]);
-                *(f4*)(px + q * 4) = o;
+                for (int r = 0; r < 4; ++r) xv[r] += (has_g ? gl[r] : 1.f) * (oacc[q][rb][r] + bv[r]);
+                *(f4*)(px + q * 4) = xv;
             }
         }
     }

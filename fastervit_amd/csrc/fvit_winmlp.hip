@@ -128,32 +128,38 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    {   // fc1 bias to LDS (an ordinary load inside the loops would queue behind the ring's prefetches and drain it), then the first steps
-        constexpr int NT = 64 * NW;
-        float c1[HID / NT];
-#pragma unroll
-        for (int i = 0; i < HID / NT; ++i) c1[i] = p.b1[tid + NT * i];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < DEPTH; ++t) issue(0, t, t);
-#pragma unroll
-        for (int i = 0; i < HID / NT; ++i) b1s[tid + NT * i] = c1[i];
-    }
-    stamp<TS>(p, wave, lane, NWV, 1);
-
     // ---- phase A: LayerNorm; WPR waves share a row block: each reads the full rows and writes KK / WPR of the k steps ----
-    if (LN_EVEN || wave < NRB) {
-        constexpr int KP = KK / WPR;
-        const int rb = LN_EVEN ? wave / WPR : wave, part = LN_EVEN ? wave % WPR : 0;
-        const int row = min(row0 + rb * 16 + s, p.M - 1);
+    // request order (r03): fc1 bias, first ring steps, the rows -- all in flight before the first wait.  The bias goes to LDS (an ordinary load
+    // inside the chunk loops would queue behind the ring's prefetches and drain it); its LDS write used to sit BEFORE the row loads were even
+    // requested: one memory round trip (3.8 us at C = 512, profiles/r03_winmlp_phase_timeline.log) in front of the prologue.
+    constexpr int NT = 64 * NW;
+    const bool ln_wave = LN_EVEN || wave < NRB;
+    const int ln_rb = LN_EVEN ? wave / WPR : (wave < NRB ? wave : 0), ln_part = LN_EVEN ? wave % WPR : 0;
+    float c1[HID / NT];
+#pragma unroll
+    for (int i = 0; i < HID / NT; ++i) c1[i] = p.b1[tid + NT * i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < DEPTH; ++t) issue(0, t, t);
+    f4 v[2 * KK];
+    {
+        const int row = min(row0 + ln_rb * 16 + s, p.M - 1);
         const float* src = p.x + (size_t)row * C;
-        f4 v[2 * KK];
+        if (ln_wave) {
+#pragma unroll
+            for (int i = 0; i < 2 * KK; ++i) v[i] = *(const f4*)(src + (i >> 2) * 64 + g * 16 + (i & 3) * 4);   // i = 2 * kk + h2
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < HID / NT; ++i) b1s[tid + NT * i] = c1[i];
+    stamp<TS>(p, wave, lane, NWV, 1);
+    if (ln_wave) {
+        constexpr int KP = KK / WPR;
+        const int rb = ln_rb, part = ln_part;
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2 * KK; ++i) {
-            v[i] = *(const f4*)(src + (i >> 2) * 64 + g * 16 + (i & 3) * 4);   // i = 2 * kk + h2
-            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
+        for (int i = 0; i < 2 * KK; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         sum = sum_xor32(sum_xor16(sum));
         stamp<TS>(p, wave, lane, NWV, 2);
         const float mean = sum / (float)C;
@@ -359,7 +365,9 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     WinMlpParams p;
     p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma; p.eps = c.eps; p.M = c.M;
     p.slab = c.slab; p.counters = c.counters; p.ts = (unsigned long long*)c.ts;
-    const int nsplit = (c.C == 512 && c.slab && c.counters && (c.nsplit == 2 || c.nsplit == 4)) ? c.nsplit : 1;
+    // (the 4-way split measured in profiles/r03_stage3_split_over_sibling_workgroups_ab.log -- 288 workgroups, two rounds, 90 us -- is no longer
+    // instantiated: git history, commit "split-hidden form of the C = 512 MLP kernel")
+    const int nsplit = (c.C == 512 && c.slab && c.counters && c.nsplit == 2) ? 2 : 1;
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
     ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
@@ -381,7 +389,7 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     const int rows_per_wg = wide ? 16 * wide : (c.C == 512 || small ? 64 : 128);
     const int nrg = (c.M + rows_per_wg - 1) / rows_per_wg;
     const int grid = nsplit > 1 ? (nrg + 7) / 8 * 8 * nsplit : nrg;
-    prof_note(c.C == 512 ? (nsplit == 4 ? "winmlp_kernel<512,split4>" : nsplit == 2 ? "winmlp_kernel<512,split2>" : "winmlp_kernel<512>")
+    prof_note(c.C == 512 ? (nsplit == 2 ? "winmlp_kernel<512,split2>" : "winmlp_kernel<512>")
                          : (wide == 5 ? "winmlp_kernel<256,80rows>" : wide == 6 ? "winmlp_kernel<256,96rows>" : "winmlp_kernel<256>"), grid);
     if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_mlp: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
     if (c.terms != 1 && c.terms != 2) { set_error("win_mlp: weight terms %d not supported", c.terms); return FVIT_EINVAL; }
@@ -401,8 +409,7 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     if (c.ts && c.dtype == FVIT_F16 && c.terms == 1 && nsplit == 1 && (c.C == 512 || small)) {   // timeline instances (diagnosis)
         if (c.C == 512) hipLaunchKernelGGL((winmlp_kernel<_Float16, 512, 2048, 4, 2, 8, 1, 1, true>), dim3(grid), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((winmlp_kernel<_Float16, 256, 1024, 4, 2, 4, 1, 1, true>), dim3(grid), dim3(256), 0, stream, p);
-    } else if (c.C == 512 && nsplit == 4) FVIT_WINMLP_ST(4);
-    else if (c.C == 512 && nsplit == 2) FVIT_WINMLP_ST(2);
+    } else if (c.C == 512 && nsplit == 2) FVIT_WINMLP_ST(2);
     else if (c.C == 512) FVIT_WINMLP_T(512, 2048, 4, 8);
     else if (wide == 5) FVIT_WINMLP_T(256, 1024, 5, 8);
     else if (wide == 6) FVIT_WINMLP_T(256, 1024, 6, 8);

@@ -269,7 +269,7 @@ int fvit_win_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, in
 int fvit_win_mlp_fused_terms(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,
                              float eps, const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2,
                              const float* gamma, int32_t terms, fvit_stream_t stream);
-/* C = 512 only: the hidden units of every 64-row group split over nsplit (1, 2, 4) workgroups that meet in L2 -- each stores its fp32
+/* C = 512 only: the hidden units of every 64-row group split over nsplit (1, 2) workgroups that meet in L2 -- each stores its fp32
  * partial output, the last arriver of a group adds the partials in split order (bitwise repeatable) and applies the residual.
  *   slab     f32 scratch of fvit_win_mlp_split_bytes(M, C, nsplit) bytes
  *   counters int32 [ceil(M / 64)], ZERO before the first launch; the kernel leaves them zero. */
