@@ -172,19 +172,6 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
                 v[kk][h2] = t;
                 sum += (t[0] + t[1]) + (t[2] + t[3]);
             }
-        // LayerNorm weight / bias of this lane's channels, requested here (r03) -- behind the row loads, ahead of the two lane reductions --
-        // instead of inside the write loop below, where they were KK exposed L2 round trips per wave (C = 256 only: registers)
-        f4 lw[CC == 256 ? KK : 1][2], lbv[CC == 256 ? KK : 1][2];
-        if constexpr (CC == 256) {
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const int co = (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 + h2 * 4;
-                    lw[kk][h2] = *(const f4*)(p.ln_w + co);
-                    lbv[kk][h2] = *(const f4*)(p.ln_b + co);
-                }
-        }
         sum = sum_xor32(sum_xor16(sum));
         const float mean = sum / (float)C;
         float sq = 0.f;
@@ -203,9 +190,8 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int co = (kk >> 1) * 64 + g * 16 + (kk & 1) * 8 + h2 * 4;
-                f4 w, b;
-                if constexpr (CC == 256) { w = lw[kk][h2]; b = lbv[kk][h2]; }
-                else { w = *(const f4*)(p.ln_w + co); b = *(const f4*)(p.ln_b + co); }
+                const f4 w = *(const f4*)(p.ln_w + co);
+                const f4 b = *(const f4*)(p.ln_b + co);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = sat16<T>((v[kk][h2][r] - mean) * rstd * w[r] + b[r]);
             }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 evidence run (through gpurun): full GPU test suite, default bench line, rocprofv3 kernel-trace stats of the same command,
 # HBM-traffic PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs) and one SQ-counter pass.  usage: bash scripts/gpu_r3_evidence.sh <tag> [notest]
-# (the secondary configurations' stats / PMC passes: scripts/gpu_r3_call7.sh / gpu_r3_call8.sh)
+# (the secondary configurations' stats / PMC passes: scripts/r03_calls/gpu_r3_call7.sh / gpu_r3_call8.sh)
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 T=${1:-r3e}
