@@ -39,3 +39,23 @@ def test_world_size_mismatch_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-selftest"],
                        capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_roofline_selection_is_dominant_kernel_by_time():
+    """`roofline` = the kernel NAME with the largest summed time (conv kernels included, no CU weighting), reported through
+    its heaviest launch shape."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def row(kernel, kind, wg, ms, n=1, mflop=1.0):
+        return dict(kernel=kernel, kind=kind, workgroups=wg, launches_per_step=n, avg_launch_us=ms * 1e3 / n, ms_per_step=ms,
+                    algorithmic_mflop_per_launch=mflop, algorithmic_mbyte_per_launch=1.0, flop_per_byte=1.0, bound="mfma", tflops=1.0, gbs=1.0, frac=0.1)
+    shapes = [row("winmlp_kernel<256>", "mlp_fused", 285, 0.60), row("winmlp_kernel<512>", "mlp_fused", 66, 0.45), row("winmlp_kernel<512>", "mlp_fused", 65, 0.40),
+              row("conv3x3_kernel<2,2,4>", "conv3x3", 527, 0.50), row("other", "other", 0, 9.0, mflop=0.0)]
+    dom, fam_ms = bench.dominant_by_time(bench.shapes_cu(shapes))
+    assert dom["kernel"] == "winmlp_kernel<512>" and dom["workgroups"] == 66 and abs(fam_ms - 0.85) < 1e-9
+    shapes[3]["ms_per_step"] = 0.9    # a conv kernel can be the dominant one: no exclusion
+    dom, _ = bench.dominant_by_time(shapes)
+    assert dom["kernel"] == "conv3x3_kernel<2,2,4>"
+    e = bench.roofline_entry(dom, "f16", 0.9)
+    assert e["cu_share"] == 1.0 and "dominant kernel by time" in e["selection"]

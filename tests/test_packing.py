@@ -49,3 +49,31 @@ def test_frag_pack_qkv(C, heads):
         row = (ub >> 1) * C + h * 32 + (ub & 1) * 16 + s
         assert p[h, ub, kk, 16 * g + s, e] == w[row, kch(kk, g, e)]
     assert torch.equal(p.flatten().sort().values, w.flatten().sort().values)
+
+
+def test_two_term_weight_packing_reconstructs_the_weights():
+    """x2 operand modes (FvitStageDesc.weight_terms = 2): row-major arrays hold [hi | lo] along K, fragment-order arrays two images back to
+    back; hi + lo reproduces the fp32 weight to ~2^-16 (bf16) / 2^-21 (fp16) relative, and the hi part IS the single-term packing."""
+    import torch
+    from fastervit_amd import hat_runtime
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(96, 64, generator=g) * 0.05
+    for dt, rel in ((torch.bfloat16, 2.0 ** -15), (torch.float16, 2.0 ** -20)):
+        k1, k2 = hat_runtime._Keep(dt, 1), hat_runtime._Keep(dt, 2)
+        a1, a2 = k1.op16(w), k2.op16(w)
+        assert a1.shape == (96, 64) and a2.shape == (96, 128) and a2.dtype == dt and a2.is_contiguous()
+        assert torch.equal(a2[:, :64], a1)                                   # hi term = the single-term array
+        rec = a2[:, :64].float() + a2[:, 64:].float()
+        assert (rec - w).abs().max().item() <= rel * w.abs().max().item()
+        assert (a1.float() - w).abs().max().item() > 4 * (rec - w).abs().max().item()
+        f1, f2 = k1.frag16(w), k2.frag16(w)
+        assert f1.numel() == w.numel() and f2.numel() == 2 * w.numel()
+        assert torch.equal(f2[:w.numel()], f1)                               # [hi image | lo image]
+        assert torch.equal(f2[w.numel():].float(), (w - f1.view_as(w).float()).to(dt).float().reshape(-1))
+
+
+def test_operand_modes_table():
+    from fastervit_amd import hat_runtime, _lib
+    assert set(hat_runtime.OPERAND_MODES) == {"f16", "bf16", "f16x2", "bf16x2"}
+    assert hat_runtime._OP["bf16x2"][0] == _lib.FVIT_BF16 and hat_runtime._OP["bf16x2"][2] == 2
+    assert hat_runtime._OP["f16"][2] == 1
