@@ -298,7 +298,7 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
 // qkv GEMM.  Same two fp32 additions in the same order as the separate kernel (bitwise the same residual stream).
 // C = 512 (stage 3 of FasterViT-0): the attention sub-block with the waves of a window splitting heads / output channels (fvit_winblk.hip)
 static bool win_fused_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S) {
-    if (d.weight_terms != 1 || !winblk_supported(d.C, d.heads, S) || d.dpad != 32 || !w.w_qkv_frag || !w.b_qkv_heads || !w.w_proj_frag || !w.bias) return false;
+    if ((d.weight_terms != 1 && d.C != 512) || !winblk_supported(d.C, d.heads, S) || d.dpad != 32 || !w.w_qkv_frag || !w.b_qkv_heads || !w.w_proj_frag || !w.bias) return false;
     return d.C == 512 ? tune_get("win_fused", 1) != 0 : tune_get("win_fused256", 0) != 0;   // C = 256: the 4-wave form, two workgroups per CU
 }
 
@@ -324,13 +324,13 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         void* RH = ws + L.off_RH;
         const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
         bool ct_done = false;
-        if (d.weight_terms == 1 && ctblk_supported(d.C, d.heads, L.G, d.hidden) && d.dpad == 32 && w.hat_attn.w_qkv_frag && w.hat_attn.b_qkv_heads && w.hat_attn.w_proj_frag &&
+        if (ctblk_supported(d.C, d.heads, L.G, d.hidden) && d.dpad == 32 && w.hat_attn.w_qkv_frag && w.hat_attn.b_qkv_heads && w.hat_attn.w_proj_frag &&
             w.hat_attn.bias && w.hat_mlp.w_fc1_frag && w.hat_mlp.w_fc2_frag && tune_get("ct_fused", 1)) {
             // the whole carrier-token branch (AR:679-686) in one kernel, one workgroup per image
             CtBlkCall cb = {dt, X, rpi, t.ct_src, (d.square ? w.pe_ct : nullptr), R, d.batch, L.G, d.heads, d.C, d.hidden,
                             w.hat_attn.ln_w, w.hat_attn.ln_b, w.hat_attn.w_qkv_frag, w.hat_attn.b_qkv_heads, w.hat_attn.w_proj_frag, w.hat_attn.b_proj,
                             w.hat_attn.gamma, w.hat_attn.bias, scale, w.hat_mlp.ln_w, w.hat_mlp.ln_b, w.hat_mlp.w_fc1_frag, w.hat_mlp.b_fc1,
-                            w.hat_mlp.w_fc2_frag, w.hat_mlp.b_fc2, w.hat_mlp.gamma, 1e-5f};
+                            w.hat_mlp.w_fc2_frag, w.hat_mlp.b_fc2, w.hat_mlp.gamma, 1e-5f, d.weight_terms};
             FVIT_TRY(launch_ctblk(cb, st));
             ct_done = true;
             dbg_rowhash("ct.block", R, L.Mc, d.C * 4, st);
@@ -370,6 +370,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
             ab.counters = (int*)(ws + L.off_CNT);
             ab.nsplit = tune_get("win_blk_split", 1);
         }
+        ab.terms = d.weight_terms;
         FVIT_TRY(launch_winblk(ab, st));
         dbg_rowhash("win.winblk", X, L.Mx, d.C * 4, st);
     } else if (fused_attn_ok(d, w.attn, L.S, L.Mx)) {
@@ -666,6 +667,17 @@ int fvit_win_block_fused_split(int32_t operand_dtype, const float* srcA, int32_t
     return launch_winblk(ab, (hipStream_t)stream);
 }
 
+int fvit_win_block_fused_terms(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                               const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
+                               int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
+                               const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
+                               int32_t heads, int32_t C, float scale, int32_t terms, fvit_stream_t stream) {
+    AttnBlkCall ab = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, ln_w, ln_b, eps, rows_per_image, w_qkv_frag,
+                      b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
+    ab.terms = terms;
+    return launch_winblk(ab, (hipStream_t)stream);
+}
+
 int fvit_ct_block_supported(int32_t C, int32_t heads, int32_t G, int32_t hidden) { return ctblk_supported(C, heads, G, hidden) ? 1 : 0; }
 
 int fvit_ct_block_fused(int32_t operand_dtype, const float* X, int32_t rowsA, const int32_t* src_idx, const float* add, float* R,
@@ -675,6 +687,16 @@ int fvit_ct_block_fused(int32_t operand_dtype, const float* X, int32_t rowsA, co
                         const void* w_fc2_frag, const float* b_fc2, const float* gamma2, float eps, fvit_stream_t stream) {
     CtBlkCall cb = {operand_dtype, X, rowsA, src_idx, add, R, batch, G, heads, C, hidden, ln1_w, ln1_b, w_qkv_frag, b_qkv_heads, w_proj_frag,
                     b_proj, gamma1, bias, scale, ln2_w, ln2_b, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma2, eps};
+    return launch_ctblk(cb, (hipStream_t)stream);
+}
+
+int fvit_ct_block_fused_terms(int32_t operand_dtype, const float* X, int32_t rowsA, const int32_t* src_idx, const float* add, float* R,
+                              int32_t batch, int32_t G, int32_t heads, int32_t C, int32_t hidden, const float* ln1_w, const float* ln1_b,
+                              const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag, const float* b_proj, const float* gamma1,
+                              const float* bias, float scale, const float* ln2_w, const float* ln2_b, const void* w_fc1_frag, const float* b_fc1,
+                              const void* w_fc2_frag, const float* b_fc2, const float* gamma2, float eps, int32_t terms, fvit_stream_t stream) {
+    CtBlkCall cb = {operand_dtype, X, rowsA, src_idx, add, R, batch, G, heads, C, hidden, ln1_w, ln1_b, w_qkv_frag, b_qkv_heads, w_proj_frag,
+                    b_proj, gamma1, bias, scale, ln2_w, ln2_b, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma2, eps, terms};
     return launch_ctblk(cb, (hipStream_t)stream);
 }
 

@@ -254,6 +254,7 @@ struct AttnBlkCall {
     float* slab = nullptr;     // f32 [nwin][nsplit][64 x C], scratch
     int* counters = nullptr;   // int32 [nwin], zero before the first launch (the kernel leaves them zero)
     int nsplit = 1;
+    int terms = 1;             // weight terms of the fragment arrays (fvit_winblk.hip, C = 512: 1 or 2; fvit_attnblk.hip: 1)
 };
 bool attnblk_supported(int C, int heads, int S);
 int launch_attnblk(const AttnBlkCall& c, hipStream_t stream);
@@ -311,6 +312,7 @@ struct CtBlkCall {
     const float* bias; float scale;
     const float* ln2_w; const float* ln2_b; const void* w1f; const float* b1; const void* w2f; const float* b2; const float* gamma2;
     float eps;
+    int terms = 1;   // weight terms of the four fragment arrays (1 or 2)
 };
 bool ctblk_supported(int C, int heads, int G, int hidden);
 int launch_ctblk(const CtBlkCall& c, hipStream_t stream);

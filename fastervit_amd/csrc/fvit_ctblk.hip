@@ -48,13 +48,17 @@ struct CtBlkParams {
 
 // DEPTH: steps of the register ring in flight; MINB: workgroups per CU the register budget is sized for (1: one wave per SIMD, 512
 // registers, the ring and every phase's operands fit without scratch; 2: 256 registers, other kernels' waves can share the SIMD)
-template <typename T, int DEPTH, int MINB>
+// WT = 2 (r03): two-term weights (hi + lo 16-bit images, the lo image after the hi image in each fragment array): every 8-fragment step of
+// the stream is followed by the same step of the lo image and both accumulate into the same registers before the narrowing.
+template <typename T, int DEPTH, int MINB, int WT = 1>
 __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
     typedef typename Op16<T>::v8 v8;
     typedef typename Op16<T>::v4 v4;
     constexpr int C = 256, KK = 8, CB = 16, NW = 4, HID = 1024;
     constexpr int CPW = HID / 32 / NW;        // hidden chunks (of 32 units) per wave
-    constexpr int NSTEP = 16 + 4 * CPW;       // 8-fragment steps of a wave's weight stream: 2 heads x (6 qkv + 2 proj), CPW chunks x (2 fc1 + 2 fc2)
+    constexpr int SA = 16 * WT;               // steps of the attention phase
+    constexpr int NSTEP = SA + 4 * WT * CPW;  // 8-fragment steps of a wave's weight stream: 2 heads x (6 qkv + 2 proj), CPW chunks x (2 fc1 + 2 fc2), x WT
+    constexpr size_t QKV_IMG = (size_t)3 * C * C * 2, PROJ_IMG = (size_t)C * C * 2, FC_IMG = (size_t)C * HID * 2;   // bytes of one weight image
     // partial accumulators [wave][cb][lane] x 16 B, then the small constants of the inner loops (fc1 bias, qkv bias, attention bias tables):
     // an ordinary global load inside the loops would queue behind the ring's prefetches in the in-order vmcnt counter, and waiting for it
     // would drain the ring (first version: 56 us per launch instead of ~20)
@@ -78,17 +82,17 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
     const char* W1 = (const char*)p.w1f + lane16;
     const char* W2 = (const char*)p.w2f + lane16;
     auto step_ptr = [&](int t) -> const char* {
-        if (t < 16) {
-            const int h = 2 * wave + (t >> 3), u = t & 7;
-            return u < 6 ? Wq + ((size_t)h * 48 + u * 8) * 1024 : Wp + ((size_t)h * 16 + (u - 6) * 8) * 1024;
+        if (t < SA) {
+            const int h = 2 * wave + t / (8 * WT), r = t % (8 * WT), u = r / WT, term = r % WT;
+            return u < 6 ? Wq + term * QKV_IMG + ((size_t)h * 48 + u * 8) * 1024 : Wp + term * PROJ_IMG + ((size_t)h * 16 + (u - 6) * 8) * 1024;
         }
-        const int m = t - 16, j = CPW * wave + (m >> 2), u = m & 3;
-        return (u < 2 ? W1 : W2) + ((size_t)j * 16 + (u & 1) * 8) * 1024;
+        const int m = t - SA, j = CPW * wave + m / (4 * WT), r = m % (4 * WT), u = r / WT, term = r % WT;
+        return (u < 2 ? W1 : W2) + term * FC_IMG + ((size_t)j * 16 + (u & 1) * 8) * 1024;
     };
     v8 ring[DEPTH][8];
     constexpr bool in_attention = true;   // shadowed in the MLP phase: steps >= 16 are requested only after the exchange
 #define FVIT_CT_LOAD(t)                                                                                  \
-    if ((t) < NSTEP && !(in_attention && (t) >= 16)) {                                                                                   \
+    if ((t) < NSTEP && !(in_attention && (t) >= SA)) {                                                                                   \
         const char* sp_ = step_ptr(t);                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) ring[(t) % DEPTH][i_] = *(const v8*)(sp_ + i_ * 1024); \
     }                                                                                                    \
@@ -202,18 +206,21 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
         v8 qf, kf, vf[2];
 #pragma unroll
         for (int ub = 0; ub < 6; ++ub) {
-            const int t = hh * 8 + ub;
             // two independent accumulator chains (even / odd k steps): eight dependent MFMAs would wait 32 cycles each on the previous one
             f4 a = (f4){0.f, 0.f, 0.f, 0.f}, ao = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < KK; kk += 2) {
-                a = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a)     // q0 q1 k0 k1: weights are the A operand -> D[dim][token]
-                           : Op16<T>::mfma(xf[kk], ring[t % DEPTH][kk], a);    // v0 v1: activations are A -> D[token][dim]
-                ao = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[kk + 1], ao) : Op16<T>::mfma(xf[kk + 1], ring[t % DEPTH][kk + 1], ao);
+            for (int term = 0; term < WT; ++term) {
+                const int t = (hh * 8 + ub) * WT + term;
+#pragma unroll
+                for (int kk = 0; kk < KK; kk += 2) {
+                    a = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a)     // q0 q1 k0 k1: weights are the A operand -> D[dim][token]
+                               : Op16<T>::mfma(xf[kk], ring[t % DEPTH][kk], a);    // v0 v1: activations are A -> D[token][dim]
+                    ao = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[kk + 1], ao) : Op16<T>::mfma(xf[kk + 1], ring[t % DEPTH][kk + 1], ao);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                FVIT_CT_LOAD(t + DEPTH)
             }
             a += ao;
-            __builtin_amdgcn_sched_barrier(0);
-            FVIT_CT_LOAD(t + DEPTH)
             // the accumulator becomes an operand fragment at once (keeps 4 instead of 24 accumulator registers alive)
             if (ub < 4) {
                 const f4 bb = *(const f4*)(bq + (ub >> 1) * 32 + (ub & 1) * 16 + g * 4);
@@ -264,13 +271,15 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
         }
         // out^T += Wproj[:, head h] . O^T
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int t = hh * 8 + 6 + half;
+        for (int half = 0; half < 2; ++half)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) oacc[half * 8 + i] = Op16<T>::mfma(ring[t % DEPTH][i], of, oacc[half * 8 + i]);
-            __builtin_amdgcn_sched_barrier(0);
-            FVIT_CT_LOAD(t + DEPTH)
-        }
+            for (int term = 0; term < WT; ++term) {
+                const int t = (hh * 8 + 6 + half) * WT + term;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) oacc[half * 8 + i] = Op16<T>::mfma(ring[t % DEPTH][i], of, oacc[half * 8 + i]);
+                __builtin_amdgcn_sched_barrier(0);
+                FVIT_CT_LOAD(t + DEPTH)
+            }
     }
 
     // ---- exchange 1: sum of the four head-pair partials in a fixed order; ct1 = ct0 + gamma1 * (sum + bproj) ----
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
     {
         constexpr bool in_attention = false;
 #pragma unroll
-        for (int t = 16; t < 16 + DEPTH; ++t) { FVIT_CT_LOAD(t) }
+        for (int t = SA; t < SA + DEPTH; ++t) { FVIT_CT_LOAD(t) }
     }
     // ---- MLP: hidden units 32 * (CPW * wave + c) .. + 31 per chunk; fc2 partial over this wave's units in acc2 ----
     f4 acc2[CB];
@@ -321,16 +330,19 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
         f4 a1[2];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
-            const int t = 16 + 4 * c + hb;
             f4 a = (f4){0.f, 0.f, 0.f, 0.f}, ao = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < KK; kk += 2) {
-                a = Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a);
-                ao = Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[kk + 1], ao);
+            for (int term = 0; term < WT; ++term) {
+                const int t = SA + (4 * c + hb) * WT + term;
+#pragma unroll
+                for (int kk = 0; kk < KK; kk += 2) {
+                    a = Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a);
+                    ao = Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[kk + 1], ao);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                FVIT_CT_LOAD(t + DEPTH)
             }
             a1[hb] = a + ao;
-            __builtin_amdgcn_sched_barrier(0);
-            FVIT_CT_LOAD(t + DEPTH)
         }
         const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
         const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
@@ -341,13 +353,15 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
             pf[4 + r] = sat16<T>(gelu_fast(a1[1][r] + bB[r]));
         }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int t = 16 + 4 * c + 2 + half;
+        for (int half = 0; half < 2; ++half)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc2[half * 8 + i] = Op16<T>::mfma(ring[t % DEPTH][i], pf, acc2[half * 8 + i]);
-            __builtin_amdgcn_sched_barrier(0);
-            FVIT_CT_LOAD(t + DEPTH)
-        }
+            for (int term = 0; term < WT; ++term) {
+                const int t = SA + (4 * c + 2 + half) * WT + term;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc2[half * 8 + i] = Op16<T>::mfma(ring[t % DEPTH][i], pf, acc2[half * 8 + i]);
+                __builtin_amdgcn_sched_barrier(0);
+                FVIT_CT_LOAD(t + DEPTH)
+            }
     }
 #undef FVIT_CT_LOAD
 
@@ -392,17 +406,21 @@ int launch_ctblk(const CtBlkCall& c, hipStream_t stream) {
     p.ln2_w = c.ln2_w; p.ln2_b = c.ln2_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma2 = c.gamma2; p.eps = c.eps;
     const double rows = (double)c.batch * c.G;
     const double flops = rows * (2.0 * c.C * 3 * c.C + 4.0 * c.G * c.C + 2.0 * c.C * c.C + 4.0 * c.C * c.hidden);
-    const double bytes = rows * c.C * 8.0 + 2.0 * (4.0 * c.C * c.C + 2.0 * c.C * c.hidden);
+    const double bytes = rows * c.C * 8.0 + c.terms * 2.0 * (4.0 * c.C * c.C + 2.0 * c.C * c.hidden);
     ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
     prof_note("ctblk_kernel<256,G16>", c.batch);
     p.touch = tune_get("ct_touch", 0);
     const int variant = tune_get("ct_variant", 0);
-    if (c.dtype == FVIT_F16) {
+    if (c.terms != 1 && c.terms != 2) { set_error("ct_block: weight terms %d (1 or 2)", c.terms); return FVIT_EINVAL; }
+    if (c.dtype == FVIT_F16 && c.terms == 2) {
+        hipLaunchKernelGGL((ctblk_kernel<_Float16, 3, 1, 2>), dim3(c.batch), dim3(256), 0, stream, p);
+    } else if (c.dtype == FVIT_F16) {
         if (variant == 1) hipLaunchKernelGGL((ctblk_kernel<_Float16, 2, 2>), dim3(c.batch), dim3(256), 0, stream, p);
         else if (variant == 2) hipLaunchKernelGGL((ctblk_kernel<_Float16, 4, 1>), dim3(c.batch), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((ctblk_kernel<_Float16, 3, 1>), dim3(c.batch), dim3(256), 0, stream, p);
     } else if (c.dtype == FVIT_BF16) {
-        hipLaunchKernelGGL((ctblk_kernel<__bf16, 3, 1>), dim3(c.batch), dim3(256), 0, stream, p);
+        if (c.terms == 2) hipLaunchKernelGGL((ctblk_kernel<__bf16, 3, 1, 2>), dim3(c.batch), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((ctblk_kernel<__bf16, 3, 1>), dim3(c.batch), dim3(256), 0, stream, p);
     } else { set_error("ct_block: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
     return check_launch("ctblk_kernel");
 }

@@ -59,14 +59,18 @@ struct WinBlkParams {
 // half of the qkv / bias / proj weights (1.15 MiB instead of 2.3 MiB through one CU's L2 port), computes the proj partial sum over ITS
 // heads for all C channels, and the two partials meet in L2 exactly as in winmlp_kernel (fp32 partial stored, agent-scope release,
 // ticket; the last arriver acquires, adds the partials in split order and applies the residual; nobody waits).
-template <typename T, int CC, int NWV, int NSPLIT = 1>
+// WT = 2 (r03): two-term weights (hi + lo 16-bit images, the lo image after the hi image in the fragment arrays): the qkv and proj k loops run
+// twice over the same activation fragments, once per weight image -- same registers and LDS, twice the weight stream.
+template <typename T, int CC, int NWV, int NSPLIT = 1, int WT = 1>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinBlkParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int C = CC, KK = C / 32, CB = C / 16, HEADS = C / 32, NW = NWV, NRB = 4, SP = 64;
     constexpr int HW = HEADS / NSPLIT;             // heads of this workgroup
     constexpr int NH = HW / NW;                    // heads per wave (2, or 1 when split)
     static_assert(HW == NH * NW && NH >= 1 && CB == 4 * NW, "heads split evenly over the waves; four output channel blocks per wave");
-    constexpr int SPH = KK + 4;                    // steps per head: KK qkv steps + 4 bias-tile steps
+    constexpr int KQ = KK * WT, PW = HW * WT;      // qkv steps per head / proj steps, over the weight terms
+    constexpr int SPH = KQ + 4;                    // steps per head: KQ qkv steps + 4 bias-tile steps
+    constexpr size_t QKV_IMG = (size_t)3 * C * C * 2, PROJ_IMG = (size_t)C * C * 2;   // bytes of one weight image
     constexpr int DEPTH = 2;                       // ring slots of 6 fragments (6 KiB) per wave (3 slots spill at the 256-register budget of 8 waves)
     constexpr int OFF_O = NRB * KK * 1024;         // XN: 64 KiB, then O: 64 KiB (a separate region: each head's O^T fragments leave the
     constexpr int OFF_BQ = OFF_O + NRB * HW * 1024;      // registers at once -- held across the next head they spilled, and a scratch reload
@@ -95,26 +99,30 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
     const char* Bz = (const char*)p.bias + (s * SP + g * 4) * 4;   // tile (qb, kb) of head h: + ((h * 64 + qb * 16) * 64 + kb * 16) * 4
     v8 ring[DEPTH][6];
     // step kinds: QKV(h, kk): 6 fragments; BIAS(h, qb): 4 tiles (kb = 0..3) in slots 0..3; PROJ(h): 4 fragments in slots 0..3
-    auto load_qkv = [&](int slot, int h, int kk) {
+    auto load_qkv = [&](int slot, int h, int u) {   // u = term * KK + kk
+        const char* base = Wq + (u / KK) * QKV_IMG;
+        const int kk = u % KK;
 #pragma unroll
-        for (int ub = 0; ub < 6; ++ub) ring[slot][ub] = *(const v8*)(Wq + (((size_t)h * 6 + ub) * KK + kk) * 1024);
+        for (int ub = 0; ub < 6; ++ub) ring[slot][ub] = *(const v8*)(base + (((size_t)h * 6 + ub) * KK + kk) * 1024);
     };
     auto load_bias = [&](int slot, int h, int qb) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) ring[slot][kb] = *(const v8*)(Bz + ((size_t)(h * SP + qb * 16) * SP + kb * 16) * 4);
     };
-    auto load_proj = [&](int slot, int h) {
+    auto load_proj = [&](int slot, int hp) {        // hp = term * HW + local head
+        const char* base = Wp + (hp / HW) * PROJ_IMG;
+        const int h = h0 + hp % HW;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ring[slot][q] = *(const v8*)(Wp + ((size_t)h * CB + 4 * wave + q) * 1024);
+        for (int q = 0; q < 4; ++q) ring[slot][q] = *(const v8*)(base + ((size_t)h * CB + 4 * wave + q) * 1024);
     };
     // per head KK + 4 steps; two heads; then one proj step per head of the layer.  issue(t) requests step t into slot t % DEPTH.
     auto issue = [&](int t) {
         if (t < NH * SPH) {
             const int hh = t / SPH, u = t - hh * SPH, h = h0 + NH * wave + hh;
-            if (u < KK) load_qkv(t % DEPTH, h, u);
-            else load_bias(t % DEPTH, h, u - KK);
-        } else if (t < NH * SPH + HW) {
-            load_proj(t % DEPTH, h0 + t - NH * SPH);
+            if (u < KQ) load_qkv(t % DEPTH, h, u);
+            else load_bias(t % DEPTH, h, u - KQ);
+        } else if (t < NH * SPH + PW) {
+            load_proj(t % DEPTH, t - NH * SPH);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -195,8 +203,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) acc[ub][rb] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            const int t = hh * SPH + kk;
+        for (int u = 0; u < KQ; ++u) {
+            const int t = hh * SPH + u, kk = u % KK;
             v8 xb[NRB];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) xb[rb] = *(const v8*)(xn + (rb * KK + kk) * 1024);
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
         // scores^T, softmax over keys, O^T, per query row block; the bias tiles of (h, qb) are step hh * SPH + KK + qb
 #pragma unroll
         for (int qb = 0; qb < NRB; ++qb) {
-            const int t = hh * SPH + KK + qb;
+            const int t = hh * SPH + KQ + qb;
             f4 sc[NRB];
             float mx = -3.0e38f;
 #pragma unroll
@@ -296,8 +304,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) oacc[q][rb] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int h = 0; h < HW; ++h) {   // local head index; the ring step holds the proj fragments of head h0 + h
-        const int t = NH * SPH + h;
+    for (int hp = 0; hp < PW; ++hp) {   // local head index (per weight term); the ring step holds the proj fragments of head h0 + h
+        const int t = NH * SPH + hp, h = hp % HW;
         v8 ob[NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) ob[rb] = *(const v8*)(xn + OFF_O + (rb * HW + h) * 1024);
@@ -401,15 +409,22 @@ int launch_winblk(const AttnBlkCall& c, hipStream_t stream) {
     p.wqkv_f = c.wqkv_f; p.bqkv = c.bqkv; p.wproj_f = c.wproj_f; p.bproj = c.bproj; p.gamma = c.gamma; p.bias = c.bias; p.x_out = c.x_out;
     p.nwin = c.nwin; p.S = c.S; p.scale = c.scale;
     p.slab = c.slab; p.counters = c.counters;
-    const bool split = c.C == 512 && c.nsplit == 2 && c.slab && c.counters;
+    if (c.terms != 1 && !(c.terms == 2 && c.C == 512)) {
+        set_error("win_block: weight terms %d with C = %d (two-term weights: C = 512 only)", c.terms, c.C);
+        return FVIT_EINVAL;
+    }
+    const bool split = c.C == 512 && c.terms == 1 && c.nsplit == 2 && c.slab && c.counters;
     const double rows = (double)c.nwin * c.S;
     const double flops = rows * (2.0 * c.C * 3 * c.C + 4.0 * c.S * c.C + 2.0 * c.C * c.C);
-    const double bytes = rows * c.C * 8.0 + 2.0 * 4.0 * c.C * c.C;
+    const double bytes = rows * c.C * 8.0 + c.terms * 2.0 * 4.0 * c.C * c.C;
     ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
     const int grid = split ? (c.nwin + 7) / 8 * 8 * 2 : c.nwin;
     prof_note(c.C == 512 ? (split ? "winblk_kernel<512,S64,split2>" : "winblk_kernel<512,S64>") : "winblk_kernel<256,S64>", grid);
     if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_block: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
-    if (split) {
+    if (c.terms == 2) {
+        if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winblk_kernel<_Float16, 512, 8, 1, 2>), dim3(c.nwin), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((winblk_kernel<__bf16, 512, 8, 1, 2>), dim3(c.nwin), dim3(512), 0, stream, p);
+    } else if (split) {
         if (c.dtype == FVIT_F16) hipLaunchKernelGGL((winblk_kernel<_Float16, 512, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((winblk_kernel<__bf16, 512, 8, 2>), dim3(grid), dim3(512), 0, stream, p);
     } else if (c.C == 512) {

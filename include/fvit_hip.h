@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FVIT_ABI_VERSION 4
+#define FVIT_ABI_VERSION 5
 
 /* error codes */
 #define FVIT_OK 0
@@ -296,6 +296,14 @@ int fvit_win_block_fused_split(int32_t operand_dtype, const float* srcA, int32_t
                                const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
                                int32_t heads, int32_t C, float scale, float* slab, int32_t* counters, int32_t nsplit, fvit_stream_t stream);
 
+/* C = 512 only, two-term weights (terms 1 / 2): w_qkv_frag / w_proj_frag hold `terms` images back to back (hi image, then lo image of
+ * w - hi, each in the single-term fragment order); the k loops run once per image into the same fp32 accumulators. */
+int fvit_win_block_fused_terms(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                               const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
+                               int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
+                               const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
+                               int32_t heads, int32_t C, float scale, int32_t terms, fvit_stream_t stream);
+
 /* The whole carrier-token branch of one HAT block in one kernel (AR:679-686), one workgroup per image:
  *   ct[b][i] = X[b * rowsA + src_idx[i]] (+ add[i]);  ct += gamma1 * attn(LayerNorm1(ct));  ct += gamma2 * mlp(LayerNorm2(ct))  -> R [batch * G][C]
  * attention over the G <= 16 carrier tokens of an image (bias f32 [heads][16][16], mask on padded keys), weights in the fragment-major
@@ -307,6 +315,13 @@ int fvit_ct_block_fused(int32_t operand_dtype, const float* X, int32_t rowsA, co
                         const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag, const float* b_proj, const float* gamma1,
                         const float* bias, float scale, const float* ln2_w, const float* ln2_b, const void* w_fc1_frag, const float* b_fc1,
                         const void* w_fc2_frag, const float* b_fc2, const float* gamma2, float eps, fvit_stream_t stream);
+
+/* fvit_ct_block_fused with `terms` (1 / 2) weight images back to back in each of the four fragment arrays (see fvit_win_block_fused_terms). */
+int fvit_ct_block_fused_terms(int32_t operand_dtype, const float* X, int32_t rowsA, const int32_t* src_idx, const float* add, float* R,
+                              int32_t batch, int32_t G, int32_t heads, int32_t C, int32_t hidden, const float* ln1_w, const float* ln1_b,
+                              const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag, const float* b_proj, const float* gamma1,
+                              const float* bias, float scale, const float* ln2_w, const float* ln2_b, const void* w_fc1_frag, const float* b_fc1,
+                              const void* w_fc2_frag, const float* b_fc2, const float* gamma2, float eps, int32_t terms, fvit_stream_t stream);
 
 /* Fused attention sub-block: x_out[i] = x_in[i] + gamma * proj(softmax(q k^T * scale + bias) v), [q|k|v] = qkv(LayerNorm(x_in)),
  * x_in[i] = gathered source row + optional add row (exactly the row selection of fvit_gather_layernorm), per window of S rows

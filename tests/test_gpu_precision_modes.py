@@ -371,3 +371,139 @@ def test_win_mlp_wide_row_groups(opname, dt, code, M):
     assert torch.isfinite(outs[3][:M]).all() and torch.isnan(outs[3][M:]).all()
     assert (outs[3][:M] - ref).abs().max().item() < tol
     assert torch.equal(outs[3][:M], outs[2][:M])
+
+
+def _attention_ref(xin, lnw, lnb, wqkv, bqkv, wproj, bproj, gamma, bias, heads, dt):
+    n, S, C = xin.shape
+    d = C // heads
+    xn = F.layer_norm(xin, (C,), lnw, lnb, 1e-5).to(dt).float()
+    qkv = (xn @ wqkv.t() + bqkv).view(n, S, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0].to(dt).float(), qkv[1].to(dt).float(), qkv[2].to(dt).float()
+    att = ((q @ k.transpose(-1, -2)) * d ** -0.5 + bias).softmax(-1)
+    o = (att @ v).transpose(1, 2).reshape(n, S, C).to(dt).float()
+    y = o @ wproj.t() + bproj
+    return xin + (gamma * y if gamma is not None else y)
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("S,nwin,use_gamma", [(49, 66, True), (53, 9, False), (64, 3, True)])
+def test_win_block_two_weight_terms(opname, dt, code, S, nwin, use_gamma):
+    """fvit_win_block_fused_terms (C = 512, stage 3 of FasterViT-0): the fused attention sub-block reading [hi image | lo image] weights
+    vs fp32 torch on hi + lo weights; the lo image must matter (bf16: closer to the two-term reference than to the single-term one)."""
+    lib = _lib.lib()
+    C, heads = 512, 16
+    g = torch.Generator(device="cpu").manual_seed(S * 7 + nwin)
+    X = (torch.randn(nwin, S, C, generator=g) * 1.3 + 0.2).cuda()
+    lnw = (torch.rand(C, generator=g) + 0.5).cuda()
+    lnb = (torch.randn(C, generator=g) * 0.2).cuda()
+    wqkv = (torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda()
+    bqkv = (torch.randn(3 * C, generator=g) * 0.3).cuda()
+    wproj = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    bproj = (torch.randn(C, generator=g) * 0.3).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda() if use_gamma else None
+    bias = (torch.randn(heads, S, S, generator=g) * 2).cuda()
+    bp = torch.zeros(heads, 64, 64, device="cuda")
+    bp[:, :S, :S] = bias
+    bp[:, :, S:] = _lib.FVIT_MASK_BIAS
+    keep = hat_runtime._Keep(dt, 2)
+    wqf = keep.frag16(hat_runtime.frag_pack_qkv(wqkv, heads))
+    wpf = keep.frag16(hat_runtime.frag_pack_fc2(wproj))
+    assert wqf.numel() == 2 * wqkv.numel() and wpf.numel() == 2 * wproj.numel()
+    bqh = bqkv.view(3, heads, 32).permute(1, 0, 2).reshape(heads, 96).contiguous()
+    out = torch.full((nwin * S + 2, C), float("nan"), device="cuda")
+    args = (code, X.data_ptr(), S, None, 0, None, None, None, lnw.data_ptr(), lnb.data_ptr(), ctypes.c_float(1e-5), S, wqf.data_ptr(),
+            bqh.data_ptr(), wpf.data_ptr(), bproj.data_ptr(), gamma.data_ptr() if use_gamma else None, bp.data_ptr(), out.data_ptr(), nwin, S,
+            heads, C, ctypes.c_float(32 ** -0.5))
+    _lib.check(lib.fvit_win_block_fused_terms(*args, 2, _stream()), "win_block_fused_terms")
+    torch.cuda.synchronize()
+    hq, lq = _split(wqkv, dt)
+    hp, lp = _split(wproj, dt)
+    ref2 = _attention_ref(X, lnw, lnb, hq.float() + lq.float(), bqkv, hp.float() + lp.float(), bproj, gamma, bias, heads, dt).reshape(-1, C)
+    ref1 = _attention_ref(X, lnw, lnb, hq.float(), bqkv, hp.float(), bproj, gamma, bias, heads, dt).reshape(-1, C)
+    got = out[:nwin * S]
+    assert torch.isfinite(got).all() and torch.isnan(out[nwin * S:]).all()
+    e2, e1 = (got - ref2).abs().max().item(), (got - ref1).abs().max().item()
+    tol = (4e-3 if dt == torch.float16 else 3e-2) * ref2.abs().max().item()
+    assert e2 < tol, f"{e2} vs {tol}"
+    if dt == torch.bfloat16:
+        assert (got - ref2).abs().mean().item() < (got - ref1).abs().mean().item(), (e2, e1)
+    # terms = 1 on the same arrays reads the hi image only: the single-term result
+    out1 = torch.full((nwin * S, C), float("nan"), device="cuda")
+    args1 = args[:18] + (out1.data_ptr(),) + args[19:]
+    _lib.check(lib.fvit_win_block_fused_terms(*args1, 1, _stream()), "win_block_fused_terms(1)")
+    torch.cuda.synchronize()
+    assert (out1 - ref1).abs().max().item() < tol
+    assert lib.fvit_win_block_fused_terms(*args1, 3, _stream()) != 0
+    args256 = args1[:21] + (8, 256) + args1[23:]
+    assert lib.fvit_win_block_fused_terms(*args256, 2, _stream()) != 0   # two-term weights: C = 512 only
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("batch,G,use_add,use_gamma", [(86, 16, True, True), (7, 9, False, False), (2, 1, True, True)])
+def test_ct_block_two_weight_terms(opname, dt, code, batch, G, use_add, use_gamma):
+    """fvit_ct_block_fused_terms: the carrier-token branch in one kernel with [hi image | lo image] weights in all four fragment arrays."""
+    lib = _lib.lib()
+    C, heads, hid = 256, 8, 1024
+    g = torch.Generator(device="cpu").manual_seed(batch * 19 + G)
+    rowsA = 4 * 53
+    X = (torch.randn(batch * rowsA, C, generator=g) * 1.3 + 0.2).cuda()
+    src_idx = torch.randperm(rowsA, generator=g)[:G].int().cuda()
+    add = torch.randn(G, C, generator=g).cuda() if use_add else None
+    ln1w, ln2w = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    ln1b, ln2b = (torch.randn(C, generator=g) * 0.2).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    wqkv = (torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda()
+    bqkv = (torch.randn(3 * C, generator=g) * 0.3).cuda()
+    wproj = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    bproj = (torch.randn(C, generator=g) * 0.3).cuda()
+    w1 = (torch.randn(hid, C, generator=g) / C ** 0.5).cuda()
+    b1 = (torch.randn(hid, generator=g) * 0.3).cuda()
+    w2 = (torch.randn(C, hid, generator=g) / hid ** 0.5).cuda()
+    b2 = (torch.randn(C, generator=g) * 0.3).cuda()
+    g1 = (torch.rand(C, generator=g) + 0.5).cuda() if use_gamma else None
+    g2 = (torch.rand(C, generator=g) + 0.5).cuda() if use_gamma else None
+    bias = (torch.randn(heads, G, G, generator=g) * 2).cuda()
+    bp = torch.zeros(heads, 16, 16, device="cuda")
+    bp[:, :G, :G] = bias
+    bp[:, :, G:] = _lib.FVIT_MASK_BIAS
+    keep = hat_runtime._Keep(dt, 2)
+    wqf = keep.frag16(hat_runtime.frag_pack_qkv(wqkv, heads))
+    wpf = keep.frag16(hat_runtime.frag_pack_fc2(wproj))
+    w1f = keep.frag16(hat_runtime.frag_pack_fc1(w1))
+    w2f = keep.frag16(hat_runtime.frag_pack_fc2(w2))
+    bqh = bqkv.view(3, heads, 32).permute(1, 0, 2).reshape(heads, 96).contiguous()
+    out = torch.full((batch * G + 3, C), float("nan"), device="cuda")
+    p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+
+    def call(terms):
+        out.fill_(float("nan"))
+        return lib.fvit_ct_block_fused_terms(code, X.data_ptr(), rowsA, src_idx.data_ptr(), p(add), out.data_ptr(), batch, G, heads, C, hid,
+                                             ln1w.data_ptr(), ln1b.data_ptr(), wqf.data_ptr(), bqh.data_ptr(), wpf.data_ptr(), bproj.data_ptr(),
+                                             p(g1), bp.data_ptr(), ctypes.c_float(32 ** -0.5), ln2w.data_ptr(), ln2b.data_ptr(), w1f.data_ptr(),
+                                             b1.data_ptr(), w2f.data_ptr(), b2.data_ptr(), p(g2), ctypes.c_float(1e-5), terms, _stream())
+
+    def ref(two):
+        ws = []
+        for w in (wqkv, wproj, w1, w2):
+            hi, lo = _split(w, dt)
+            ws.append(hi.float() + lo.float() if two else hi.float())
+        ct = X.view(batch, rowsA, C)[:, src_idx.long()]
+        if use_add:
+            ct = ct + add[None]
+        ct = _attention_ref(ct, ln1w, ln1b, ws[0], bqkv, ws[1], bproj, g1, bias, heads, dt)
+        xn2 = F.layer_norm(ct, (C,), ln2w, ln2b, 1e-5).to(dt).float()
+        y2 = F.gelu(xn2 @ ws[2].t() + b1).to(dt).float() @ ws[3].t() + b2
+        return (ct + (g2 * y2 if use_gamma else y2)).reshape(batch * G, C)
+
+    _lib.check(call(2), "ct_block_fused_terms")
+    torch.cuda.synchronize()
+    got = out[:batch * G].clone()
+    assert torch.isfinite(got).all() and torch.isnan(out[batch * G:]).all()
+    ref2, ref1 = ref(True), ref(False)
+    tol = (4e-3 if dt == torch.float16 else 3e-2) * ref2.abs().max().item()
+    assert (got - ref2).abs().max().item() < tol
+    if dt == torch.bfloat16:
+        assert (got - ref2).abs().mean().item() < (got - ref1).abs().mean().item()
+    _lib.check(call(1), "ct_block_fused_terms(1)")
+    torch.cuda.synchronize()
+    assert (out[:batch * G] - ref1).abs().max().item() < tol
+    assert call(0) != 0
