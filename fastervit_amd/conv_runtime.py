@@ -55,6 +55,20 @@ def _fold(conv, bn, extra_scale=None):
     return w, b
 
 
+def frag_pack_conv128(w2d: torch.Tensor) -> torch.Tensor:
+    """[128][9 * 128] conv weight (row = output channel, column k = tap * 128 + input channel) -> the fragment-order stream of
+    fvit_conv3x3_c128_band (include/fvit_hip.h): [wave 4][step 36][ni 2][lane 64][8]; element e of lane 16 g + s of fragment
+    (wave, step, ni) = w2d[32 wave + (s >> 2) * 8 + ni * 4 + (s & 3)][step * 32 + 8 g + e]."""
+    assert tuple(w2d.shape) == (128, 1152)
+    dev = w2d.device
+    wave = torch.arange(4, device=dev).view(4, 1, 1)
+    ni = torch.arange(2, device=dev).view(1, 2, 1)
+    sl = torch.arange(16, device=dev).view(1, 1, 16)
+    ch = (32 * wave + (sl >> 2) * 8 + ni * 4 + (sl & 3)).reshape(-1)        # [wave, ni, s]
+    t = w2d[ch].view(4, 2, 16, 36, 4, 8)                                      # wave, ni, s, step, g, e
+    return t.permute(0, 3, 1, 4, 2, 5).contiguous().view(4, 36, 2, 64, 8)    # wave, step, ni, (g, s), e
+
+
 class DeployPlan:
     def __init__(self, model, dtype=torch.float16):
         if dtype not in _CODE:
@@ -65,6 +79,7 @@ class DeployPlan:
         self.sig = None
         self.t = None
         self.zeros = None
+        self._band = {}       # fragment-order images of the 128 -> 128 conv weights (fvit_conv3x3_c128_band), keyed by (pointer, version)
         self.streams = 1      # > 1: run the batch as that many shards on separate HIP streams
         self.side = None
         self.dev = None       # device of the current forward (raw-pointer launches go to torch's current stream on THIS device)
@@ -115,6 +130,16 @@ class DeployPlan:
             wk = wcl.permute(0, 2, 3, 1).contiguous()
         return wcl, wk
 
+    def _band_weight(self, wk):
+        """The fragment-order image of a 128 -> 128 conv weight for fvit_conv3x3_c128_band (built once per weight), or None."""
+        if wk is None or tuple(wk.shape) != (128, 3, 3, 128):
+            return None
+        key = (wk.data_ptr(), wk._version)
+        hit = self._band.get(key)
+        if hit is None:
+            hit = self._band[key] = frag_pack_conv128(wk.reshape(128, 1152))
+        return hit
+
     def _conv(self, x, w, bias, stride, act, residual=None):
         """act(conv3x3(x, w) + bias) (+ residual): one fused HIP kernel when supported, else MIOpen conv + glue passes."""
         wcl, wk = w
@@ -126,6 +151,13 @@ class DeployPlan:
                                                                     memory_format=torch.channels_last)
             if self.zeros is None or self.zeros.device != x.device:
                 self.zeros = torch.zeros(256, dtype=self.dtype, device=x.device)
+            wband = self._band_weight(wk) if stride == 1 and _lib.lib().fvit_conv3x3_c128_band_supported(Hi, Wi) else None
+            if wband is not None:   # level 1 of FasterViT-0: one row band of an image per workgroup, weights streamed in fragment order
+                rc = _lib.lib().fvit_conv3x3_c128_band(self.code, x.data_ptr(), wband.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                       residual.data_ptr() if residual is not None else None, out.data_ptr(), B, Hi, Wi, act,
+                                                       self.zeros.data_ptr(), _stream(self.dev))
+                _lib.check(rc, "fvit_conv3x3_c128_band")
+                return out
             rc = _lib.lib().fvit_conv3x3_nhwc(self.code, x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
                                               residual.data_ptr() if residual is not None else None, out.data_ptr(), B, Hi, Wi,
                                               Ci, Co, stride, act, self.zeros.data_ptr(), _stream(self.dev))

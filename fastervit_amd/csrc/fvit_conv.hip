@@ -566,6 +566,206 @@ int launch_halo_t(const ConvParams& c, hipStream_t stream) {
 
 
 // ------------------------------------------------------------------------------------------------------------
+// Row-band 3x3 convolution for Cin = Cout = 128, stride 1, maps up to 30 pixels wide (ConvBlock convs of level 1 of FasterViT-0:
+// 28 x 28 x 128, FV:502-512), r03.
+//
+// The implicit GEMM above moves ~300 MB from L2 into LDS per launch at 86 images (every input pixel once per tap, the 288-KiB weight
+// matrix once per 128-pixel tile): 6.9 TB/s of L2 -> LDS traffic at 44 us per launch -- it is bound by that traffic, not by its MFMAs (0.18).
+// Here a workgroup owns a BAND of R full-width output rows of one image (R = 7 at 28 x 28: four bands per image):
+//   * the band's input rows plus one halo row above / below and one zero column left / right -- (R + 2) x (W + 2) pixels of 256 B, 68 KiB --
+//     are brought into LDS ONCE by LDS-DMA (16-byte chunks, chunk position c ^ (pixel & 15): the 16 lanes of a ds_read_b128 service
+//     group read 16 consecutive pixels and hit 16 different chunk positions for any tap shift);
+//   * output positions are numbered linearly over the PADDED row pitch, q = r * (W + 2) + x, so the input pixel of tap (ky, kx) is LDS
+//     pixel q + ky * (W + 2) + kx for every q: a 16-position MFMA column group is the same LDS image read at a shifted address, and groups
+//     run across row ends (the two pad positions per row are computed and dropped: 196 of 224 positions are real at 28 x 28);
+//   * the 4 waves split the output channels (32 each) and every wave streams ITS quarter of the weights (72 KiB, pre-packed in MFMA fragment
+//     order, one 1-KiB fragment per global_load_dwordx4 per lane) from L2 straight into a register ring -- no weight staging in LDS, so the
+//     workgroup's LDS is the band alone and two workgroups share a CU.
+// L2 -> CU traffic per launch: 344 x (68 KiB band + 288 KiB weights) = 122 MB instead of 303 MB; per K step a wave issues 14 ds_read_b128 and
+// 2 global loads for 28 MFMAs.
+// ------------------------------------------------------------------------------------------------------------
+struct BandParams {
+    const void* in;      // [B][H][W][128]
+    const void* wf;      // op16 [4 waves][36 steps][2][64 lanes][8]  (fvit_conv3x3_c128_band's w_frag)
+    const float* bias;   // [128] or null
+    const void* res;     // [B][H][W][128] or null (may alias out)
+    void* out;           // [B][H][W][128]
+    const void* zeros;   // >= 256 bytes of zeros
+    int B, H, W, act;
+    int PW, R, bands;    // padded row pitch W + 2, output rows per band, bands per image
+    int npieces;         // 1-KiB pieces (4 pixels) of the band's (R + 2) x PW halo image
+    int magic;           // ceil(65536 / PW): n / PW == (n * magic) >> 16 for n < 2048
+};
+
+constexpr int BD_NG = 14;                                   // 16-position column groups per band (R * PW <= 224)
+constexpr int BD_MAXPW = 32;
+constexpr int BD_PIX = (BD_NG * 16 + 2 * BD_MAXPW + 2 + 3) / 4 * 4;   // LDS pixels a read can touch: 292
+constexpr int BD_LDS = BD_PIX * 256;                        // 74 752 B
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3x3_c128_band_kernel(BandParams p) {
+    typedef typename Op16<T>::v8 v8;
+    constexpr int NG = BD_NG, HB = NG / 2, DEPTH = 6, NSTEP = 36;
+    __shared__ __attribute__((aligned(1024))) char smem[BD_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, s = lane & 15;
+
+    // XCD x owns a contiguous range of (image, band) units: the bands of an image share halo rows in that XCD's L2
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int img = unit / p.bands, band = unit - img * p.bands;
+    const int y0 = band * p.R, PW = p.PW;
+
+    const T* __restrict__ In = (const T*)p.in + (size_t)img * p.H * p.W * 128;
+    const T* __restrict__ Z = (const T*)p.zeros;
+
+    // ---- the band's halo image -> LDS (oldest in the vmcnt queue), then the first DEPTH steps of the wave's weight stream ----
+    {
+        const int lane4 = lane >> 4, j = lane & 15;
+#pragma unroll 1
+        for (int piece = wave; piece < p.npieces; piece += 4) {
+            const int hp = piece * 4 + lane4;
+            const int hy = (hp * p.magic) >> 16, hx = hp - hy * PW;
+            const int y = y0 - 1 + hy, x = hx - 1;
+            const bool ok = hy < p.R + 2 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            const int c = j ^ (hp & 15);
+            const T* src = ok ? In + ((size_t)y * p.W + x) * 128 + c * 8 : Z + c * 8;
+            glds16(src, smem + piece * 1024);
+        }
+    }
+    const char* Wf = (const char*)p.wf + (size_t)wave * (NSTEP * 2 * 1024) + lane * 16;
+    v8 ring[DEPTH][2];
+    auto issue = [&](int t) {
+        if (t < NSTEP) {
+            ring[t % DEPTH][0] = *(const v8*)(Wf + (t * 2 + 0) * 1024);
+            ring[t % DEPTH][1] = *(const v8*)(Wf + (t * 2 + 1) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < DEPTH; ++t) issue(t);
+
+    f4 acc[2][NG];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int i = 0; i < NG; ++i) acc[ni][i] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    // the band has landed when only the 2 * DEPTH weight fragments requested after it are still in flight
+    // (raw barrier: __syncthreads() would drain the weight ring as well)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * DEPTH) : "memory");
+
+    // B fragment of group i at step (tap, kk): pixel 16 i + s + shift(tap), k slots 8 g .. 8 g + 7 of K quarter kk -> chunk kk * 4 + g.
+    // 16 i leaves pixel & 15 alone: one base address per step, the groups at immediate offsets i * 4096.
+    auto xbase = [&](int t) {
+        const int tap = t >> 2, kk = t & 3, ky = tap / 3, kx = tap - ky * 3;
+        const int pix = s + ky * PW + kx;
+        return pix * 256 + (((kk * 4 + g) ^ (pix & 15)) << 4);
+    };
+    // batches of HB = 7 groups, read one batch ahead of the MFMAs that consume them
+    v8 xf[2][HB];
+    {
+        const char* xb = smem + xbase(0);
+#pragma unroll
+        for (int i = 0; i < HB; ++i) xf[0][i] = *(const v8*)(xb + i * 4096);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int qn = 2 * t + half + 1;   // the batch to request now
+            if (qn < 2 * NSTEP) {
+                const char* xb = smem + xbase(qn >> 1) + (qn & 1) * HB * 4096;
+#pragma unroll
+                for (int i = 0; i < HB; ++i) xf[qn & 1][i] = *(const v8*)(xb + i * 4096);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int i = 0; i < HB; ++i)
+                    acc[ni][half * HB + i] = Op16<T>::mfma(ring[t % DEPTH][ni], xf[half][i], acc[ni][half * HB + i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        issue(t + DEPTH);
+    }
+
+    // ---- epilogue: lane holds out[position 16 i + s][32 wave + 8 g .. + 7]; A-row slot 4 g + r of fragment ni is channel 32 wave + 8 g + 4 ni + r ----
+    const int nb = wave * 32 + g * 8;
+    float bias[8];
+    {
+        const f4 t0 = p.bias ? *(const f4*)(p.bias + nb) : (f4){0.f, 0.f, 0.f, 0.f};
+        const f4 t1 = p.bias ? *(const f4*)(p.bias + nb + 4) : (f4){0.f, 0.f, 0.f, 0.f};
+        bias[0] = t0[0]; bias[1] = t0[1]; bias[2] = t0[2]; bias[3] = t0[3];
+        bias[4] = t1[0]; bias[5] = t1[1]; bias[6] = t1[2]; bias[7] = t1[3];
+    }
+    T* O = (T*)p.out + (size_t)img * p.H * p.W * 128 + nb;
+    const T* Rs = p.res ? (const T*)p.res + (size_t)img * p.H * p.W * 128 + nb : nullptr;
+    dispatch_epilogue(p.act, Rs != nullptr, [&](auto act_tag, auto res_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        constexpr bool RES = decltype(res_tag)::value != 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int off[HB];      // element offset of the position's pixel, or -1
+            v8 rv[HB];
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                const int q = (h * HB + i) * 16 + s;
+                const int r = (q * p.magic) >> 16, x = q - r * PW, y = y0 + r;
+                const bool ok = r < p.R && y < p.H && x < p.W;
+                off[i] = ok ? (y * p.W + x) * 128 : -1;
+                if (RES) rv[i] = *(const v8*)(Rs + (ok ? off[i] : 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                v8 ov;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const f4 a = acc[ni][h * HB + i];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float yv = a[r] + bias[ni * 4 + r];
+                        if (ACT == 1) yv = fmaxf(yv, 0.f);
+                        else if (ACT == 2) yv = gelu_fast(yv);
+                        if (RES) yv += (float)rv[i][ni * 4 + r];
+                        ov[ni * 4 + r] = (T)yv;
+                    }
+                }
+                if (off[i] >= 0) *(v8*)(O + off[i]) = ov;
+            }
+        }
+    });
+}
+
+bool band_supported(int H, int W) { return H >= 1 && W >= 1 && W + 2 <= BD_MAXPW; }
+
+template <typename T>
+int launch_band_t(const void* in, const void* wf, const float* bias, const void* res, void* out, const void* zeros, int B, int H, int W, int act,
+                  hipStream_t stream) {
+    BandParams p;
+    p.in = in; p.wf = wf; p.bias = bias; p.res = res; p.out = out; p.zeros = zeros; p.B = B; p.H = H; p.W = W; p.act = act;
+    p.PW = W + 2;
+    p.R = (BD_NG * 16) / p.PW;
+    if (p.R > H) p.R = H;
+    p.bands = (H + p.R - 1) / p.R;
+    p.npieces = ((p.R + 2) * p.PW + 3) / 4;
+    p.magic = (65536 + p.PW - 1) / p.PW;
+    const double M = (double)B * H * W;
+    ProfScope prof(FVIT_K_CONV, 2.0 * M * 128.0 * 1152.0, 2.0 * (M * 128 * (res ? 3.0 : 2.0) + 1152.0 * 128), stream);
+    prof_note("conv3x3_c128_band_kernel", B * p.bands);
+    hipLaunchKernelGGL((conv3x3_c128_band_kernel<T>), dim3(B * p.bands), dim3(256), 0, stream, p);
+    return check_launch("conv3x3_c128_band_kernel");
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
 // Fused two-conv stem of PatchEmbed (FV:458-464) for in_dim = dim = 64 (FasterViT-0):
 //     out = ReLU(conv2_s2(ReLU(conv1_s2(image) + b1)) + b2),  conv1: 3 -> 64, conv2: 64 -> 64, both 3x3 / stride 2 / pad 1.
 // The 112x112x64 map between the two convs is the largest tensor of the network (1.6 MB per image in fp16): written and read
@@ -991,4 +1191,19 @@ static int stem_fused_impl(int32_t dtype, const FvitMapView* in, const void* w1,
 #undef FVIT_STEM_IN
 #undef FVIT_STEM_LAUNCH
     return check_launch("stem_fused_kernel");
+}
+
+extern "C" int fvit_conv3x3_c128_band_supported(int32_t H, int32_t W) { return band_supported(H, W) && tune_get("conv_band", 1) ? 1 : 0; }
+
+extern "C" int fvit_conv3x3_c128_band(int32_t dtype, const void* in, const void* w_frag, const float* bias, const void* residual, void* out,
+                                      int32_t B, int32_t H, int32_t W, int32_t act, const void* zeros, fvit_stream_t stream) {
+    if (!in || !w_frag || !out || !zeros || B <= 0 || !band_supported(H, W) || act < 0 || act > 2 || (int64_t)B * H * W * 128 > 0x7fffffff) {
+        set_error("conv3x3_c128_band: unsupported arguments B=%d H=%d W=%d act=%d (need W <= %d)", B, H, W, act, BD_MAXPW - 2);
+        return FVIT_EINVAL;
+    }
+    if (ablate_skip(32)) return FVIT_OK;
+    if (dtype == FVIT_F16) return launch_band_t<_Float16>(in, w_frag, bias, residual, out, zeros, B, H, W, act, (hipStream_t)stream);
+    if (dtype == FVIT_BF16) return launch_band_t<__bf16>(in, w_frag, bias, residual, out, zeros, B, H, W, act, (hipStream_t)stream);
+    set_error("conv3x3_c128_band: dtype %d not supported (16-bit maps only)", dtype);
+    return FVIT_EINVAL;
 }

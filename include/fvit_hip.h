@@ -370,6 +370,16 @@ int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weight, const f
                       void* out, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride,
                       int32_t act, const void* zeros, fvit_stream_t stream);
 
+/* The same convolution for Cin = Cout = 128, stride 1, maps up to 30 pixels wide (level 1 of FasterViT-0: 28 x 28), one ROW BAND of an
+ * image per workgroup: the band's input rows + halo go to LDS once, the weights stream from L2 into registers in MFMA fragment order.
+ *   w_frag  op16 [4][36][2][64][8]: element e of lane 16 g + s of fragment (wave, step, ni) =
+ *           weight[32 wave + (s >> 2) * 8 + ni * 4 + (s & 3)][step * 32 + 8 g + e], weight = the [128][3][3][128] matrix of fvit_conv3x3_nhwc
+ *   zeros   >= 256 bytes of zeros.  Other arguments as fvit_conv3x3_nhwc.  fvit_conv3x3_c128_band_supported: 1 when W <= 30 (and the
+ *   "conv_band" tuning knob is not 0). */
+int fvit_conv3x3_c128_band_supported(int32_t H, int32_t W);
+int fvit_conv3x3_c128_band(int32_t dtype, const void* in, const void* w_frag, const float* bias, const void* residual, void* out,
+                           int32_t B, int32_t H, int32_t W, int32_t act, const void* zeros, fvit_stream_t stream);
+
 /* Stem convolution of PatchEmbed (FV:458-460): 3x3, stride 2, pad 1, 3 -> 64 channels, + bias (folded BatchNorm) + ReLU.
  * in: strided view of the (B, 3, Hi, Wi) image in fp32 / fp16 / bf16 (the model's NCHW fp32 input needs no conversion);
  * weight: op16 [64][32], column k = ky*9 + kx*3 + c, zero for k >= 27; out: op16 [B][Ho][Wo][64] channels-last. */

@@ -394,6 +394,50 @@ def test_conv3x3_fused(dt, code, B, Ci, Co, H, W, stride, act, res):
         assert torch.equal(r2, out)
 
 
+@pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
+@pytest.mark.parametrize("B,H,W,act,res", [(86, 28, 28, 2, False), (86, 28, 28, 0, True), (3, 28, 28, 1, True), (2, 30, 30, 0, False), (5, 1, 1, 2, True),
+                                           (2, 9, 14, 0, True), (3, 33, 7, 2, False), (1, 14, 14, 0, True), (4, 5, 30, 1, False)])
+def test_conv3x3_c128_band(dt, code, B, H, W, act, res):
+    """Row-band 128 -> 128 conv (level 1 of FasterViT-0) vs F.conv2d in fp32 and vs the implicit-GEMM kernel; ragged last bands, single
+    band images, the widest supported map, in-place residual."""
+    from fastervit_amd.conv_runtime import frag_pack_conv128
+    lib = _lib.lib()
+    assert lib.fvit_conv3x3_c128_band_supported(H, W) == 1 and lib.fvit_conv3x3_c128_band_supported(28, 31) == 0
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + H * 31 + W)
+    x = torch.randn(B, 128, H, W, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 128, 3, 3, generator=g) / (9 * 128) ** 0.5).to(dt).cuda()
+    bias = torch.randn(128, generator=g).cuda()
+    r = torch.randn(B, 128, H, W, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last) if res else None
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    wf = frag_pack_conv128(wk.reshape(128, 1152))
+    zeros = torch.zeros(256, dtype=dt, device="cuda")
+    out = torch.full((B, 128, H, W), float("nan"), dtype=dt, device="cuda").contiguous(memory_format=torch.channels_last)
+    _lib.check(lib.fvit_conv3x3_c128_band(code, x.data_ptr(), wf.data_ptr(), bias.data_ptr(), r.data_ptr() if res else None, out.data_ptr(), B, H, W,
+                                          act, zeros.data_ptr(), _stream()), "conv3x3_c128_band")
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float(), w.float(), bias, 1, 1)
+    ref = [lambda t: t, torch.relu, F.gelu][act](ref)
+    if res:
+        ref = ref + r.float()
+    assert torch.isfinite(out.float()).all()
+    tol = (5e-3 if dt == torch.float16 else 3e-2) * max(ref.abs().max().item(), 1.0)
+    assert (out.float() - ref).abs().max().item() < tol
+    # the implicit-GEMM kernel accumulates the same products in fp32 (other order): equal to 16-bit rounding
+    out2 = torch.empty_like(out)
+    _lib.check(lib.fvit_conv3x3_nhwc(code, x.data_ptr(), wk.data_ptr(), bias.data_ptr(), r.data_ptr() if res else None, out2.data_ptr(), B, H, W,
+                                     128, 128, 1, act, zeros.data_ptr(), _stream()), "conv3x3")
+    torch.cuda.synchronize()
+    assert (out.float() - out2.float()).abs().max().item() <= (2e-3 if dt == torch.float16 else 1.6e-2) * max(ref.abs().max().item(), 1.0)
+    if res:  # in place into the residual buffer, and bitwise repeatable
+        r2 = r.clone()
+        _lib.check(lib.fvit_conv3x3_c128_band(code, x.data_ptr(), wf.data_ptr(), bias.data_ptr(), r2.data_ptr(), r2.data_ptr(), B, H, W, act,
+                                              zeros.data_ptr(), _stream()), "conv3x3_c128_band in place")
+        torch.cuda.synchronize()
+        assert torch.equal(r2, out)
+    assert lib.fvit_conv3x3_c128_band(code, x.data_ptr(), wf.data_ptr(), bias.data_ptr(), None, out.data_ptr(), B, H, 31, act, zeros.data_ptr(),
+                                      _stream()) != 0
+
+
 @pytest.mark.parametrize("B,H,W,grid", [(3, 56, 56, 512), (2, 24, 50, 8), (9, 9, 17, 16), (1, 40, 40, 1)])
 def test_conv3x3_halo_matches_implicit_gemm_kernel(B, H, W, grid):
     """The halo-tiled 64->64 kernel and the implicit-GEMM kernel accumulate the same products in fp32: outputs agree to 16-bit rounding,

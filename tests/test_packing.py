@@ -77,3 +77,18 @@ def test_operand_modes_table():
     assert set(hat_runtime.OPERAND_MODES) == {"f16", "bf16", "f16x2", "bf16x2"}
     assert hat_runtime._OP["bf16x2"][0] == _lib.FVIT_BF16 and hat_runtime._OP["bf16x2"][2] == 2
     assert hat_runtime._OP["f16"][2] == 1
+
+
+def test_conv128_fragment_stream_follows_its_documented_element_mapping():
+    """frag_pack_conv128 (fvit_conv3x3_c128_band's w_frag, include/fvit_hip.h): element e of lane 16 g + s of fragment (wave, step, ni) is
+    weight[32 wave + (s >> 2) * 8 + ni * 4 + (s & 3)][step * 32 + 8 g + e]; every weight element appears exactly once."""
+    from fastervit_amd.conv_runtime import frag_pack_conv128
+    w = torch.arange(128 * 1152, dtype=torch.float32).view(128, 1152)
+    f = frag_pack_conv128(w)
+    assert tuple(f.shape) == (4, 36, 2, 64, 8)
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(200):
+        wave, step, ni, lane, e = (int(torch.randint(0, n, (1,), generator=gen)) for n in (4, 36, 2, 64, 8))
+        g, s = lane >> 4, lane & 15
+        assert f[wave, step, ni, lane, e].item() == w[32 * wave + (s >> 2) * 8 + ni * 4 + (s & 3), step * 32 + 8 * g + e].item()
+    assert torch.equal(torch.sort(f.reshape(-1)).values, w.reshape(-1))
