@@ -595,17 +595,28 @@ struct BandParams {
     int PW, R, bands;    // padded row pitch W + 2, output rows per band, bands per image
     int npieces;         // 1-KiB pieces (4 pixels) of the band's (R + 2) x PW halo image
     int magic;           // ceil(65536 / PW): n / PW == (n * magic) >> 16 for n < 2048
+    unsigned long long* ts;   // TS instance only (fvit_debug_conv_band_timeline): s_memtime stamps [workgroup][wave][8]: 0 start, 1 band DMA and
+                              // first weight steps requested, 2 band landed (barrier passed), 3 K loop done, 4 residual rows landed, 5 end
 };
 
+#ifndef FVIT_BD_DEPTH
+#define FVIT_BD_DEPTH 6   // weight steps (2 fragments each) in flight per wave (4 .. 8 and PD 2 .. 5 time the same: profiles/r03_conv_band_*.log)
+#endif
+#ifndef FVIT_BD_PD
+#define FVIT_BD_PD 3      // B-fragment batches requested ahead of the MFMAs
+#endif
 constexpr int BD_NG = 14;                                   // 16-position column groups per band (R * PW <= 224)
 constexpr int BD_MAXPW = 32;
 constexpr int BD_PIX = (BD_NG * 16 + 2 * BD_MAXPW + 2 + 3) / 4 * 4;   // LDS pixels a read can touch: 292
 constexpr int BD_LDS = BD_PIX * 256;                        // 74 752 B
 
-template <typename T>
+template <typename T, bool TS = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c128_band_kernel(BandParams p) {
     typedef typename Op16<T>::v8 v8;
-    constexpr int NG = BD_NG, HB = NG / 2, DEPTH = 6, NSTEP = 36;
+#define FVIT_BD_STAMP(k) if constexpr (TS) { if ((threadIdx.x & 63) == 0) p.ts[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); }
+    FVIT_BD_STAMP(0)
+    constexpr int NG = BD_NG, HB = NG / 2, DEPTH = FVIT_BD_DEPTH, NSTEP = 36;
+    constexpr int BG = 2, NBATCH = NG / BG, PD = FVIT_BD_PD, XR = PD + 1;   // B fragments: batches of BG groups, requested PD batches ahead
     __shared__ __attribute__((aligned(1024))) char smem[BD_LDS];
 
     const int tid = threadIdx.x;
@@ -649,6 +660,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c128_band_kernel(BandParams p)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < DEPTH; ++t) issue(t);
+    FVIT_BD_STAMP(1)
 
     f4 acc[2][NG];
 #pragma unroll
@@ -659,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c128_band_kernel(BandParams p)
     // the band has landed when only the 2 * DEPTH weight fragments requested after it are still in flight
     // (raw barrier: __syncthreads() would drain the weight ring as well)
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * DEPTH) : "memory");
+    FVIT_BD_STAMP(2)
 
     // B fragment of group i at step (tap, kk): pixel 16 i + s + shift(tap), k slots 8 g .. 8 g + 7 of K quarter kk -> chunk kk * 4 + g.
     // 16 i leaves pixel & 15 alone: one base address per step, the groups at immediate offsets i * 4096.
@@ -667,34 +680,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c128_band_kernel(BandParams p)
         const int pix = s + ky * PW + kx;
         return pix * 256 + (((kk * 4 + g) ^ (pix & 15)) << 4);
     };
-    // batches of HB = 7 groups, read one batch ahead of the MFMAs that consume them
-    v8 xf[2][HB];
-    {
-        const char* xb = smem + xbase(0);
+    // The four waves read the same B fragments: a K step costs the workgroup 56 KiB of LDS reads (~300 cycles at 256 B / cycle incl. the
+    // 2-way conflict of the odd tap shifts, SQ_LDS_BANK_CONFLICT = 25 % of SQ_LDS_IDX_ACTIVE) against 448 MFMA cycles per wave.  Batches of
+    // BG = 2 groups (4 MFMAs) are requested PD batches ahead.  Measured: the K loop runs at ~0.65 of the MFMA rate whatever the batching
+    // (two batches of 7 one ahead, or 2 / 3 / 5 batches of 2 ahead) and whatever the weight ring depth (6 / 8).
+    v8 xf[XR][BG];
+    auto load_batch = [&](int b) {
+        if (b < NSTEP * NBATCH) {
+            const char* xb = smem + xbase(b / NBATCH) + (b % NBATCH) * BG * 4096;
 #pragma unroll
-        for (int i = 0; i < HB; ++i) xf[0][i] = *(const v8*)(xb + i * 4096);
-    }
+            for (int i = 0; i < BG; ++i) xf[b % XR][i] = *(const v8*)(xb + i * 4096);
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < PD; ++b) load_batch(b);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NSTEP; ++t) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int qn = 2 * t + half + 1;   // the batch to request now
-            if (qn < 2 * NSTEP) {
-                const char* xb = smem + xbase(qn >> 1) + (qn & 1) * HB * 4096;
-#pragma unroll
-                for (int i = 0; i < HB; ++i) xf[qn & 1][i] = *(const v8*)(xb + i * 4096);
-            }
+        for (int j = 0; j < NBATCH; ++j) {
+            const int b = t * NBATCH + j;
+            load_batch(b + PD);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int i = 0; i < HB; ++i)
-                    acc[ni][half * HB + i] = Op16<T>::mfma(ring[t % DEPTH][ni], xf[half][i], acc[ni][half * HB + i]);
+                for (int i = 0; i < BG; ++i)
+                    acc[ni][j * BG + i] = Op16<T>::mfma(ring[t % DEPTH][ni], xf[b % XR][i], acc[ni][j * BG + i]);
             __builtin_amdgcn_sched_barrier(0);
         }
         issue(t + DEPTH);
     }
+    if constexpr (TS) {   // the stamp must not pass the last MFMAs: make it depend on an accumulator
+        asm volatile("s_nop 0" ::"v"(acc[1][NG - 1]) : "memory");
+    }
+    FVIT_BD_STAMP(3)
 
     // ---- epilogue: lane holds out[position 16 i + s][32 wave + 8 g .. + 7]; A-row slot 4 g + r of fragment ni is channel 32 wave + 8 g + 4 ni + r ----
     const int nb = wave * 32 + g * 8;
@@ -740,15 +760,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c128_band_kernel(BandParams p)
                 }
                 if (off[i] >= 0) *(v8*)(O + off[i]) = ov;
             }
+            if (h == 0) { FVIT_BD_STAMP(4) }
         }
     });
+    if constexpr (TS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    FVIT_BD_STAMP(5)
+#undef FVIT_BD_STAMP
 }
 
 bool band_supported(int H, int W) { return H >= 1 && W >= 1 && W + 2 <= BD_MAXPW; }
 
 template <typename T>
 int launch_band_t(const void* in, const void* wf, const float* bias, const void* res, void* out, const void* zeros, int B, int H, int W, int act,
-                  hipStream_t stream) {
+                  hipStream_t stream, void* stamps = nullptr) {
     BandParams p;
     p.in = in; p.wf = wf; p.bias = bias; p.res = res; p.out = out; p.zeros = zeros; p.B = B; p.H = H; p.W = W; p.act = act;
     p.PW = W + 2;
@@ -760,6 +784,13 @@ int launch_band_t(const void* in, const void* wf, const float* bias, const void*
     const double M = (double)B * H * W;
     ProfScope prof(FVIT_K_CONV, 2.0 * M * 128.0 * 1152.0, 2.0 * (M * 128 * (res ? 3.0 : 2.0) + 1152.0 * 128), stream);
     prof_note("conv3x3_c128_band_kernel", B * p.bands);
+    p.ts = (unsigned long long*)stamps;
+    if constexpr (std::is_same<T, _Float16>::value) {
+        if (stamps) {
+            hipLaunchKernelGGL((conv3x3_c128_band_kernel<T, true>), dim3(B * p.bands), dim3(256), 0, stream, p);
+            return check_launch("conv3x3_c128_band_kernel");
+        }
+    }
     hipLaunchKernelGGL((conv3x3_c128_band_kernel<T>), dim3(B * p.bands), dim3(256), 0, stream, p);
     return check_launch("conv3x3_c128_band_kernel");
 }
@@ -1206,4 +1237,14 @@ extern "C" int fvit_conv3x3_c128_band(int32_t dtype, const void* in, const void*
     if (dtype == FVIT_BF16) return launch_band_t<__bf16>(in, w_frag, bias, residual, out, zeros, B, H, W, act, (hipStream_t)stream);
     set_error("conv3x3_c128_band: dtype %d not supported (16-bit maps only)", dtype);
     return FVIT_EINVAL;
+}
+
+// diagnosis: the fp16 kernel with s_memtime stamps, u64 [B * bands][4 waves][8] (see BandParams.ts); bands = ceil(H / (224 / (W + 2)))
+extern "C" int fvit_debug_conv_band_timeline(const void* in, const void* w_frag, const float* bias, const void* residual, void* out, int32_t B,
+                                             int32_t H, int32_t W, int32_t act, const void* zeros, void* stamps, fvit_stream_t stream) {
+    if (!in || !w_frag || !out || !zeros || !stamps || B <= 0 || !band_supported(H, W) || act < 0 || act > 2) {
+        set_error("debug_conv_band_timeline: unsupported arguments");
+        return FVIT_EINVAL;
+    }
+    return launch_band_t<_Float16>(in, w_frag, bias, residual, out, zeros, B, H, W, act, (hipStream_t)stream, stamps);
 }

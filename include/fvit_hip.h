@@ -447,6 +447,10 @@ int fvit_debug_rowhash_dump(int32_t record, void* dst, int64_t capacity_bytes);
  * fragments; per hidden chunk: the W1 fragments as read from LDS, the pre-GELU accumulators, the GELU output fragment, the W2 fragments as
  * read, the output accumulators) to consecutive slices of buf: [workgroup * 4 + wave][1 + 5 * hidden / 32][64 lanes] words.  _end returns
  * the number of traced launches (<= 64) with their slice offsets (words) and row counts.  Single host thread only. */
+/* fvit_conv3x3_c128_band (fp16) with s_memtime stamps per wave: stamps u64 [B * bands][4][8], bands = ceil(H / (224 / (W + 2))):
+ * 0 start, 1 band DMA + first weight steps requested, 2 band landed, 3 K loop done, 4 first half of the epilogue done, 5 end. */
+int fvit_debug_conv_band_timeline(const void* in, const void* w_frag, const float* bias, const void* residual, void* out, int32_t B,
+                                  int32_t H, int32_t W, int32_t act, const void* zeros, void* stamps, fvit_stream_t stream);
 /* Phase accounting of the fused stem kernel (fp16): the same launch as fvit_stem_fused with every wave accumulating s_memtime ticks per phase,
  * u64 [workgroups (<= 512)][4 waves][8]: 0 phase A (gathers + conv1 + LDS writes), 1 barrier after A, 2 phase B (conv2), 3 epilogue,
  * 4 barrier before A, 5 tiles processed, 6 kernel entry -> exit. */
