@@ -316,6 +316,216 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
     }
 }
 
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+
+// ------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, two wave groups in PING-PONG (r03): while the four waves of one group issue the 16 MFMAs of a phase, the four waves
+// of the other group read their next fragments from LDS and request the next operand half-tile, and the barriers swap the roles.
+//
+//   waves   8 = 2 (M halves: the GROUP) x 4 (N quarters); wave tile 128 rows x 64 columns = 8 x 4 accumulator fragments (128 registers)
+//   LDS     2 buffers x {X0, X1, W0, W1} half-tiles of 128 rows x 64 k (16 KiB each, the piece / swizzle layout of stage_tile) = 128 KiB
+//   K tile  4 phases of 16 MFMAs: (a0, b0), (a0, b1), (a1, b1), (a1, b0) -- a = 64-row half of the wave's rows (8 fragment reads), b = 32-column
+//           half of its columns (4 reads, both halves stay in registers); reads per phase 12 / 4 / 8 / 0
+//   a phase reads + one half-tile request (2 LDS-DMA instructions per wave) | s_barrier | lgkmcnt(0), 16 MFMAs at raised priority | s_barrier
+//           group 1 runs one barrier behind group 0, so a group's MFMA section coincides with the other group's read section
+//   requests in phase 1 .. 4 of K tile t: X0(t+1), X1(t+1) into the other buffer, W0(t+2), W1(t+2) into THIS buffer (its W halves were read for
+//           the last time in phase 2, and phase 2 retires its reads BEFORE its barrier).  Every destination was last read, and those reads
+//           retired, at least one barrier before the first wave requests into it.
+//   waits   ONE counted vmcnt per K tile, at the end of phase 4's read section: everything but the two W requests just issued has landed
+//           (own pieces; the youngest needed request, X1(t+1), is two phases old); group 1 executes that wait one barrier after group 0 and
+//           still one barrier before group 0 reads K tile t+1.
+// The loads are never drained inside the loop and there is no point where all eight waves wait for memory at once.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
+    typedef typename Op16<T>::v8 v8;
+    constexpr int HT = 128 * BK * 2;            // half-tile bytes
+    constexpr int BUF = 4 * HT;                 // X0 X1 W0 W1
+    __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;    // wm = group
+    const int g = lane >> 4, s = lane & 15;
+
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, rr = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const int v = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ W = (const T*)p.W;
+    const int nk = p.K / BK;
+    auto acol = [&](int kt) { const int k = kt * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1 or 2 x ka
+    auto req_x = [&](int h, int kt, char* buf) { stage_tile<T, false, 128, 8>(A, p.lda, m0 + 128 * h, acol(kt), buf + h * HT, wave, lane, p.arow_max); };
+    auto req_w = [&](int h, int kt, char* buf) { stage_tile<T, true, 128, 8>(W, p.ldw, n0 + 128 * h, kt * BK, buf + (2 + h) * HT, wave, lane, p.wrow_max); };
+
+    f4 acc[4][8];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment byte offsets inside this wave's X half-tile / W half-tile (kk = 0; kk = 1 flips chunk bit 2): fragment i adds 2048 (X) / 512 (W)
+    const int xo = wm * HT + s * 128, xs = (s >> 1) & 7;
+    const int wr0 = (wn & 1) * 64 + (s >> 2) * 16 + (s & 3);
+    const int wo = (2 + (wn >> 1)) * HT + wr0 * 128, ws = swz_w(wr0);
+    const int xoff0 = xo + ((g ^ xs) << 4), xoff1 = xo + (((4 + g) ^ xs) << 4);
+    const int woff0 = wo + ((g ^ ws) << 4), woff1 = wo + (((4 + g) ^ ws) << 4);
+
+    // prologue: K tile 0 complete, the W halves of K tile 1 in flight
+    req_x(0, 0, smem); req_x(1, 0, smem); req_w(0, 0, smem); req_w(1, 0, smem);
+    if (nk > 1) {
+        req_w(0, 1, smem + BUF); req_w(1, 1, smem + BUF);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");
+    if (wm == 1) asm volatile("s_barrier" ::: "memory");   // group 1 runs one barrier behind
+
+    v8 xf[2][4], wb0[2][2], wb1[2][2];
+#define FVIT_PP_LOADX(a_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+        xf[0][i] = *(const v8*)(cb + xoff0 + ((a_) * 4 + i) * 2048);                                               \
+        xf[1][i] = *(const v8*)(cb + xoff1 + ((a_) * 4 + i) * 2048);                                               \
+    }
+#define FVIT_PP_LOADW(dst_, b_)                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+        dst_[0][i] = *(const v8*)(cb + woff0 + ((b_) * 2 + i) * 512);                                              \
+        dst_[1][i] = *(const v8*)(cb + woff1 + ((b_) * 2 + i) * 512);                                              \
+    }
+#define FVIT_PP_MFMA(a_, b_, wsrc_)                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    if ((a_) == 0 && (b_) == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   /* phase 2: the W reads retire before the barrier */ \
+    else asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                               \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                           \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                       \
+                acc[(b_) * 2 + ni][(a_) * 4 + mi] = Op16<T>::mfma(wsrc_[kk][ni], xf[kk][mi], acc[(b_) * 2 + ni][(a_) * 4 + mi]); \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    asm volatile("s_barrier" ::: "memory");                                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        char* const cb = smem + (kt & 1) * BUF;          // this K tile
+        char* const ob = smem + ((kt & 1) ^ 1) * BUF;    // the next one
+        const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
+        // phase 1
+        FVIT_PP_LOADW(wb0, 0)
+        FVIT_PP_LOADX(0)
+        if (more) req_x(0, kt + 1, ob);
+        FVIT_PP_MFMA(0, 0, wb0)
+        // phase 2
+        FVIT_PP_LOADW(wb1, 1)
+        if (more) req_x(1, kt + 1, ob);
+        FVIT_PP_MFMA(0, 1, wb1)
+        // phase 3
+        FVIT_PP_LOADX(1)
+        if (more2) req_w(0, kt + 2, cb);
+        FVIT_PP_MFMA(1, 1, wb1)
+        // phase 4
+        if (more2) {
+            req_w(1, kt + 2, cb);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        FVIT_PP_MFMA(1, 0, wb0)
+    }
+#undef FVIT_PP_LOADX
+#undef FVIT_PP_LOADW
+#undef FVIT_PP_MFMA
+    if (wm == 0) asm volatile("s_barrier" ::: "memory");   // group 0 meets group 1's last barrier
+
+    // ---- epilogue (the layout of gemm_kernel: lane holds out[m][nb .. nb + 15] for one row m per mi), four row fragments at a time.
+    //      Wave tiles that lie inside M take a branch-free path: behind a per-lane `if (m < M)` the compiler cannot count the stores in
+    //      flight and drains them (vmcnt(0)) before every row fragment -- eight write round trips per wave. ----
+    const int nb = n0 + wn * 64 + g * 16;
+    if (nb >= p.N) return;  // N is a multiple of 16
+    float bias[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f4 t = p.bias ? *(const f4*)(p.bias + nb + j * 4) : (f4){0.f, 0.f, 0.f, 0.f};
+        bias[j * 4 + 0] = t[0]; bias[j * 4 + 1] = t[1]; bias[j * 4 + 2] = t[2]; bias[j * 4 + 3] = t[3];
+    }
+    const int mw = m0 + wm * 128 + s;
+    auto finish = [&](auto full_tag, auto add_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, ADD = decltype(add_tag)::value;
+        if constexpr (EPI == 2) {
+            float gam[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f4 t = p.gamma ? *(const f4*)(p.gamma + nb + j * 4) : (f4){1.f, 1.f, 1.f, 1.f};
+                gam[j * 4 + 0] = t[0]; gam[j * 4 + 1] = t[1]; gam[j * 4 + 2] = t[2]; gam[j * 4 + 3] = t[3];
+            }
+            float* X = (float*)p.out;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+                f4 xr[4][4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int m = FULL ? mw + (mh * 4 + mi) * 16 : min(mw + (mh * 4 + mi) * 16, p.M - 1);   // clamped for the load
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) xr[mi][ni] = *(const f4*)(X + (size_t)m * p.ldo + nb + ni * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int m = mw + (mh * 4 + mi) * 16;
+                    if (FULL || m < p.M) {
+                        const float* pa = nullptr;
+                        if constexpr (ADD) {
+                            const int pr = m % p.rpi;
+                            const int ai = p.add_idx ? p.add_idx[pr] : pr;
+                            if (ai >= 0) pa = p.add + (size_t)ai * p.N + nb;
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) {
+                            f4 x = xr[mi][ni];
+                            const f4 a = acc[ni][mh * 4 + mi];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) x[r] += gam[ni * 4 + r] * (a[r] + bias[ni * 4 + r]);
+                            if constexpr (ADD) { if (pa) x += *(const f4*)(pa + ni * 4); }
+                            *(f4*)(X + (size_t)m * p.ldo + nb + ni * 4) = x;
+                        }
+                    }
+                }
+            }
+        } else {
+            T* O = (T*)p.out;
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = mw + mi * 16;
+                if (FULL || m < p.M) {
+                    v8 o0, o1;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const f4 a = acc[ni][mi];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float y = a[r] + bias[ni * 4 + r];
+                            if (EPI == 1) y = gelu_fast(y);
+                            if (ni < 2) o0[ni * 4 + r] = sat16<T>(y); else o1[(ni - 2) * 4 + r] = sat16<T>(y);
+                        }
+                    }
+                    T* po = O + (size_t)m * p.ldo + nb;
+                    *(v8*)po = o0;
+                    *(v8*)(po + 8) = o1;
+                }
+            }
+        }
+    };
+    const bool full = m0 + wm * 128 + 128 <= p.M;
+    if (EPI == 2 && p.add) { if (full) finish(BoolTag<true>{}, BoolTag<true>{}); else finish(BoolTag<false>{}, BoolTag<true>{}); }
+    else if (full) finish(BoolTag<true>{}, BoolTag<false>{});
+    else finish(BoolTag<false>{}, BoolTag<false>{});
+}
+
 template <typename T>
 int launch_t(const GemmCall& c, hipStream_t stream) {
     GemmParams p;
@@ -367,7 +577,16 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
 #define FVIT_GEMM256(E) hipLaunchKernelGGL((gemm_kernel<T, E, 2, 4, 8, 8>), dim3(grid), dim3(512), 0, stream, p)
 #define FVIT_GEMM_E(NS, MI_, NW_) \
     switch (c.epilogue) { case 0: FVIT_GEMM(0, NS, MI_, NW_); break; case 1: FVIT_GEMM(1, NS, MI_, NW_); break; default: FVIT_GEMM(2, NS, MI_, NW_); break; }
-    if (big) { switch (c.epilogue) { case 0: FVIT_GEMM256(0); break; case 1: FVIT_GEMM256(1); break; default: FVIT_GEMM256(2); break; } }
+    // the ping-pong form of the 256 x 256 tile (default since r03: 8-25 % faster than the 2-stage form on every shape that selects the tile,
+    // bitwise the same result; FasterViT-4 batch 128 + 0.7 %, any-res + 0.6 % end to end -- profiles/r03_gemm_ping_pong_256_tile.log)
+    if (big && tune_get("gemm_pp", 1)) {
+        switch (c.epilogue) {
+            case 0: hipLaunchKernelGGL((gemm_pp_kernel<T, 0>), dim3(grid), dim3(512), 0, stream, p); break;
+            case 1: hipLaunchKernelGGL((gemm_pp_kernel<T, 1>), dim3(grid), dim3(512), 0, stream, p); break;
+            default: hipLaunchKernelGGL((gemm_pp_kernel<T, 2>), dim3(grid), dim3(512), 0, stream, p); break;
+        }
+    }
+    else if (big) { switch (c.epilogue) { case 0: FVIT_GEMM256(0); break; case 1: FVIT_GEMM256(1); break; default: FVIT_GEMM256(2); break; } }
     else if (nw8 && small) { FVIT_GEMM_E(2, 1, 8) }        // 64 rows = 4 waves along M x 16 rows
     else if (nw8) { FVIT_GEMM_E(2, 2, 8) }            // 128 rows = 4 waves x 32 rows
     else if (small && ring == 4) { FVIT_GEMM_E(4, 2, 4) }

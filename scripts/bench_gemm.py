@@ -30,7 +30,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "old":   # r01 sweep: waves per workgrou
                 ("4 waves, 64-row", dict(gemm_nw8_max_grid=0, gemm_bm64_max_grid=400)),
                 ("4 waves, 128-row", dict(gemm_nw8_max_grid=0, gemm_bm64_max_grid=0))]
 if len(sys.argv) > 1 and sys.argv[1] == "fv4":   # r03: the Linear layers of FasterViT-4 (bs 128 / 3 shards and whole batch), 128 x 128 vs 256 x 256 tiles
-    VARIANTS = [("128x128", dict(gemm256_min_tiles=0)), ("256x256", dict(gemm256_min_tiles=1))]
+    VARIANTS = [("128x128", dict(gemm256_min_tiles=0, gemm_pp=0)), ("256x256", dict(gemm256_min_tiles=1, gemm_pp=0)),
+                ("256x256 ping-pong", dict(gemm256_min_tiles=1, gemm_pp=1))]
     SHAPES = [("fv4 s2 qkv shard", 9116, 3072, 832, 0), ("fv4 s2 proj shard", 9116, 784, 1024, 2), ("fv4 s2 fc1 shard", 9116, 3136, 832, 1),
               ("fv4 s2 fc2 shard", 9116, 784, 3136, 2), ("fv4 s3 qkv shard", 2107, 6144, 1600, 0), ("fv4 s3 proj shard", 2107, 1568, 2048, 2),
               ("fv4 s3 fc1 shard", 2107, 6272, 1600, 1), ("fv4 s3 fc2 shard", 2107, 1568, 6272, 2),

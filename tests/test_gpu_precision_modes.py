@@ -19,6 +19,7 @@ from tests.util import build_product_model, case_input, load_golden, max_abs
 pytestmark = pytest.mark.gpu
 
 OPS = [("f16", torch.float16, 1), ("bf16", torch.bfloat16, 2)]
+GEMM_PP_DEFAULT = 1   # default of the "gemm_pp" tuning knob (fvit_gemm.hip)
 
 
 def _rup(x, m):
@@ -238,10 +239,13 @@ def test_large_activation_scales_stay_finite(mode):
 @pytest.mark.parametrize("opname,dt,code", OPS)
 @pytest.mark.parametrize("M,N,K,epi", [(300, 768, 256, 0), (1000, 784, 832, 1), (257, 3136, 832, 0), (4214, 512, 2048, 2), (9116, 784, 3136, 2),
                                        (2107, 6272, 1600, 1), (6272, 1568, 6272, 2), (511, 272, 256, 2)])
-def test_gemm_256x256_tile(opname, dt, code, M, N, K, epi):
+@pytest.mark.parametrize("pp", [0, 1])
+def test_gemm_256x256_tile(opname, dt, code, M, N, K, epi, pp):
     """The 256 x 256 x 64 tile of gemm_kernel (8 waves, r03) forced on through its knob, on ragged shapes (M, N not multiples of 256,
-    N not a multiple of 64) and the FasterViT-4 layer shapes: same contract as the 128 x 128 tile, compared against it and fp32 torch."""
+    N not a multiple of 64) and the FasterViT-4 layer shapes: same contract as the 128 x 128 tile, compared against it and fp32 torch.
+    pp = 1: the ping-pong form of that tile (gemm_pp_kernel: two wave groups alternate between MFMA and LDS / request sections)."""
     lib = _lib.lib()
+    _lib.tune("gemm_pp", pp)
     g = torch.Generator(device="cpu").manual_seed(M + N + K + epi)
     A = torch.randn(M, K, generator=g).to(dt).cuda()
     W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda()
@@ -266,6 +270,7 @@ def test_gemm_256x256_tile(opname, dt, code, M, N, K, epi):
             outs.append(out)
     finally:
         _lib.tune("gemm256_min_tiles", 192)
+        _lib.tune("gemm_pp", GEMM_PP_DEFAULT)
     y = A.float() @ W.float().t() + bias
     if epi == 1:
         y = F.gelu(y)
