@@ -79,7 +79,6 @@ class DeployPlan:
         self.sig = None
         self.t = None
         self.zeros = None
-        self._band = {}       # fragment-order images of the 128 -> 128 conv weights (fvit_conv3x3_c128_band), keyed by (pointer, version)
         self.streams = 1      # > 1: run the batch as that many shards on separate HIP streams
         self.side = None
         self.dev = None       # device of the current forward (raw-pointer launches go to torch's current stream on THIS device)
@@ -114,8 +113,9 @@ class DeployPlan:
         return out
 
     def _cw(self, w):
-        """(MIOpen weight, HIP-kernel weight): the channels_last 16-bit tensor for F.conv2d, and -- when the fused
-        implicit-GEMM kernel supports the shape (3x3, Cin and Cout multiples of 64) -- its [Cout][3][3][Cin] matrix view.
+        """(MIOpen weight, HIP-kernel weight, band-kernel weight): the channels_last 16-bit tensor for F.conv2d, -- when the fused
+        implicit-GEMM kernel supports the shape (3x3, Cin and Cout multiples of 64) -- its [Cout][3][3][Cin] matrix view, and for
+        128 -> 128 channels the fragment-order stream of the row-band kernel.
         Both channel counts are zero-padded to the map layout (``_cp``)."""
         co0, ci0 = w.shape[:2]
         cop, cip = self._cp(co0), self._cp(ci0)
@@ -125,24 +125,16 @@ class DeployPlan:
             w = wp
         wcl = w.to(self.dtype).contiguous(memory_format=torch.channels_last)
         co, ci, kh, kw = w.shape
-        wk = None
+        wk = wband = None
         if self.use_hip_conv and kh == 3 and kw == 3 and ci % 64 == 0 and co % 64 == 0:
             wk = wcl.permute(0, 2, 3, 1).contiguous()
-        return wcl, wk
-
-    def _band_weight(self, wk):
-        """The fragment-order image of a 128 -> 128 conv weight for fvit_conv3x3_c128_band (built once per weight), or None."""
-        if wk is None or tuple(wk.shape) != (128, 3, 3, 128):
-            return None
-        key = (wk.data_ptr(), wk._version)
-        hit = self._band.get(key)
-        if hit is None:
-            hit = self._band[key] = frag_pack_conv128(wk.reshape(128, 1152))
-        return hit
+            if (co, ci) == (128, 128):   # the fragment-order image fvit_conv3x3_c128_band streams (level 1 of FasterViT-0)
+                wband = frag_pack_conv128(wk.reshape(128, 1152))
+        return wcl, wk, wband
 
     def _conv(self, x, w, bias, stride, act, residual=None):
         """act(conv3x3(x, w) + bias) (+ residual): one fused HIP kernel when supported, else MIOpen conv + glue passes."""
-        wcl, wk = w
+        wcl, wk, wband = w
         B, Ci, Hi, Wi = x.shape
         if wk is not None and x.is_contiguous(memory_format=torch.channels_last):
             Co = wk.shape[0]
@@ -151,8 +143,7 @@ class DeployPlan:
                                                                     memory_format=torch.channels_last)
             if self.zeros is None or self.zeros.device != x.device:
                 self.zeros = torch.zeros(256, dtype=self.dtype, device=x.device)
-            wband = self._band_weight(wk) if stride == 1 and _lib.lib().fvit_conv3x3_c128_band_supported(Hi, Wi) else None
-            if wband is not None:   # level 1 of FasterViT-0: one row band of an image per workgroup, weights streamed in fragment order
+            if wband is not None and stride == 1 and _lib.lib().fvit_conv3x3_c128_band_supported(Hi, Wi):   # level 1 of FasterViT-0: one row band of an image per workgroup, weights streamed in fragment order
                 rc = _lib.lib().fvit_conv3x3_c128_band(self.code, x.data_ptr(), wband.data_ptr(), bias.data_ptr() if bias is not None else None,
                                                        residual.data_ptr() if residual is not None else None, out.data_ptr(), B, Hi, Wi, act,
                                                        self.zeros.data_ptr(), _stream(self.dev))
