@@ -601,6 +601,18 @@ int fvit_attn_block_fused(int32_t operand_dtype, const float* srcA, int32_t rows
     return launch_attnblk(ab, (hipStream_t)stream);
 }
 
+int fvit_debug_attn_block_timeline(const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                                   const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
+                                   int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
+                                   const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
+                                   int32_t heads, int32_t C, float scale, void* stamps, fvit_stream_t stream) {
+    if (!stamps) { set_error("debug_attn_block_timeline: null stamp buffer"); return FVIT_EINVAL; }
+    AttnBlkCall ab = {FVIT_F16, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, ln_w, ln_b, eps, rows_per_image, w_qkv_frag,
+                      b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
+    ab.ts = stamps;
+    return launch_attnblk(ab, (hipStream_t)stream);
+}
+
 int fvit_win_mlp_supported(int32_t C, int32_t hidden) { return winmlp_supported(C, hidden) ? 1 : 0; }
 
 int fvit_win_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,

@@ -51,6 +51,8 @@ struct AttnBlkParams {
     float scale;
     int ablate;  // timing experiments only (wrong results): 1 = no weight DMA inside the head loop (bits 2 / 4 / 8 -- skip P1 / P2 / P3 --
                  // were removed in r02: runtime branches around the phases kept the compiler from scheduling across them)
+    unsigned long long* ts;   // TS instance only (fvit_debug_attn_block_timeline): s_memtime stamps [workgroup][wave][16]: 0 entry, 1 first weight
+                              // slice requested + rows gathered, 2 LayerNorm done, 3 .. 10 end of head 0 .. 7, 14 head loop done, 15 end
     int stagger; // 1: workgroup b walks the heads starting at head (b / 8) % heads (b % 8 = XCD, observed): the workgroups of an XCD
                  // stream different weight slices at any time, so a slice is fetched from the memory side once per XCD and found in
                  // L2 by the other workgroups (in lockstep they all wait on the same outstanding miss)
@@ -69,9 +71,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 //      proj / bias pieces) and has the whole head to land; barrier B then waits with a COUNTED vmcnt for the proj / bias pieces only.
 //      Without it the next slice is requested after barrier B and needed ~0.3 us later (P2 + P3), i.e. one exposed LDS-DMA round trip
 //      per head.  Costs 48 KiB of LDS => one workgroup per CU: used with 8-wave workgroups (two windows, two waves per SIMD).
-template <typename T, int CC, int NRB, int NW, bool BIAS_LDS, bool DBQ = false>
+template <typename T, int CC, int NRB, int NW, bool BIAS_LDS, bool DBQ = false, bool TS = false>
 __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(AttnBlkParams p) {
     typedef typename Op16<T>::v8 v8;
+#define FVIT_AB_STAMP(k) if constexpr (TS) { if ((threadIdx.x & 63) == 0) p.ts[((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); }
+    FVIT_AB_STAMP(0)
     typedef typename Op16<T>::v4 v4;
     constexpr int C = CC, KK = C / 32, CB = C / 16;
     constexpr int SP = NRB * 16;              // padded window length
@@ -173,6 +177,8 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
                 sum += (t[0] + t[1]) + (t[2] + t[3]);
             }
         sum = sum_xor32(sum_xor16(sum));
+        if constexpr (TS) { asm volatile("s_nop 0" ::"v"(sum) : "memory"); }
+        FVIT_AB_STAMP(1)
         const float mean = sum / (float)C;
         float sq = 0.f;
 #pragma unroll
@@ -202,6 +208,8 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
     f4 oacc[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) oacc[cb] = (f4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (TS) { asm volatile("s_nop 0" ::"v"(xf[KK - 1]) : "memory"); }
+    FVIT_AB_STAMP(2)
 
     const char* wq_base = smem + lane16;              // qkv fragments: + (ub * KK + kk) * 1024 (+ the buffer of this head with DBQ)
     const char* wp_l = smem + OFF_PROJ + lane16;      // proj fragments: + cb * 1024
@@ -365,7 +373,12 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
                 for (int i = 0; i < PB; ++i) oacc[c0 + PB + i] = Op16<T>::mfma(pb[i], of, oacc[c0 + PB + i]);
             }
         }
+        if constexpr (TS) {
+            asm volatile("s_nop 0" ::"v"(oacc[CB - 1]) : "memory");
+            if (hit < 8) { FVIT_AB_STAMP(3 + hit) }
+        }
     }
+    FVIT_AB_STAMP(14)
 
     // ---- epilogue: x_out[row] = x_in + gamma * (out + bproj); fragment cb, slot 4g + r <-> channel (cb>>2)*64 + 16g + (cb&3)*4 + r ----
     if (row_ok) {
@@ -391,6 +404,9 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
             }
         }
     }
+    if constexpr (TS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    FVIT_AB_STAMP(15)
+#undef FVIT_AB_STAMP
 }
 
 }  // namespace
@@ -414,6 +430,7 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
     p.x_out = c.x_out; p.nwin = c.nwin; p.S = c.S; p.heads = c.heads; p.scale = c.scale;
     p.ablate = tune_get("ab_ablate", 0);
     p.stagger = tune_get("ab_stagger", 0);
+    p.ts = (unsigned long long*)c.ts;
     const double rows = (double)c.nwin * c.S;
     const double flops = 2.0 * rows * c.C * 4.0 * c.C + 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * 32.0;
     const double bytes = 8.0 * rows * c.C + 8.0 * c.C * c.C;
@@ -432,6 +449,11 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
 #define FVIT_AB_DBQ(T) hipLaunchKernelGGL((attnblk_kernel<T, 256, 4, 8, true, true>), dim3((c.nwin + 1) / 2), dim3(512), 0, stream, p)
     // variant 2: 8 waves / 2 windows, bias in LDS, double-buffered qkv slices (one 149-KiB workgroup per CU)
     const bool dbq = variant == 2 && c.C == 256 && !small;
+    if (c.ts) {   // timeline instance: the default fp16 form only
+        if (c.dtype != FVIT_F16 || c.C != 256 || small) { set_error("attn_block timeline: fp16, C = 256, 48 < S <= 64 only"); return FVIT_EINVAL; }
+        hipLaunchKernelGGL((attnblk_kernel<_Float16, 256, 4, 4, false, false, true>), dim3(c.nwin), dim3(256), 0, stream, p);
+        return check_launch("attnblk_kernel");
+    }
     if (c.dtype == FVIT_F16) {
         if (small) FVIT_AB(_Float16, 1, 8, true);
         else if (dbq) FVIT_AB_DBQ(_Float16);

@@ -255,6 +255,7 @@ struct AttnBlkCall {
     int* counters = nullptr;   // int32 [nwin], zero before the first launch (the kernel leaves them zero)
     int nsplit = 1;
     int terms = 1;             // weight terms of the fragment arrays (fvit_winblk.hip, C = 512: 1 or 2; fvit_attnblk.hip: 1)
+    void* ts = nullptr;        // fvit_attnblk.hip: stamp buffer of the timeline instance (fvit_debug_attn_block_timeline)
 };
 bool attnblk_supported(int C, int heads, int S);
 int launch_attnblk(const AttnBlkCall& c, hipStream_t stream);

@@ -447,6 +447,13 @@ int fvit_debug_rowhash_dump(int32_t record, void* dst, int64_t capacity_bytes);
  * fragments; per hidden chunk: the W1 fragments as read from LDS, the pre-GELU accumulators, the GELU output fragment, the W2 fragments as
  * read, the output accumulators) to consecutive slices of buf: [workgroup * 4 + wave][1 + 5 * hidden / 32][64 lanes] words.  _end returns
  * the number of traced launches (<= 64) with their slice offsets (words) and row counts.  Single host thread only. */
+/* fvit_attn_block_fused (fp16, C = 256, 48 < S <= 64: the default 4-wave form) with s_memtime stamps per wave: stamps u64 [nwin][4][16]:
+ * 0 entry, 1 first weight slice requested + rows gathered, 2 LayerNorm done, 3 .. 10 end of head 0 .. 7, 14 head loop done, 15 end. */
+int fvit_debug_attn_block_timeline(const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                                   const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
+                                   int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
+                                   const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
+                                   int32_t heads, int32_t C, float scale, void* stamps, fvit_stream_t stream);
 /* fvit_conv3x3_c128_band (fp16) with s_memtime stamps per wave: stamps u64 [B * bands][4][8], bands = ceil(H / (224 / (W + 2))):
  * 0 start, 1 band DMA + first weight steps requested, 2 band landed, 3 K loop done, 4 first half of the epilogue done, 5 end. */
 int fvit_debug_conv_band_timeline(const void* in, const void* w_frag, const float* bias, const void* residual, void* out, int32_t B,
