@@ -712,6 +712,18 @@ int fvit_ct_block_fused_terms(int32_t operand_dtype, const float* X, int32_t row
     return launch_ctblk(cb, (hipStream_t)stream);
 }
 
+int fvit_debug_ct_block_timeline(const float* X, int32_t rowsA, const int32_t* src_idx, const float* add, float* R,
+                                 int32_t batch, int32_t G, int32_t heads, int32_t C, int32_t hidden, const float* ln1_w, const float* ln1_b,
+                                 const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag, const float* b_proj, const float* gamma1,
+                                 const float* bias, float scale, const float* ln2_w, const float* ln2_b, const void* w_fc1_frag, const float* b_fc1,
+                                 const void* w_fc2_frag, const float* b_fc2, const float* gamma2, float eps, void* stamps, fvit_stream_t stream) {
+    if (!stamps) { set_error("debug_ct_block_timeline: null stamp buffer"); return FVIT_EINVAL; }
+    CtBlkCall cb = {FVIT_F16, X, rowsA, src_idx, add, R, batch, G, heads, C, hidden, ln1_w, ln1_b, w_qkv_frag, b_qkv_heads, w_proj_frag,
+                    b_proj, gamma1, bias, scale, ln2_w, ln2_b, w_fc1_frag, b_fc1, w_fc2_frag, b_fc2, gamma2, eps, 1};
+    cb.ts = stamps;
+    return launch_ctblk(cb, (hipStream_t)stream);
+}
+
 int fvit_mlp_fused_supported(int32_t C, int32_t hidden) { return mlp_fused_supported(C, hidden) ? 1 : 0; }
 
 int fvit_mlp_fused(int32_t operand_dtype, float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b,

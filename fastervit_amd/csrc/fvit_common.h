@@ -314,6 +314,7 @@ struct CtBlkCall {
     const float* ln2_w; const float* ln2_b; const void* w1f; const float* b1; const void* w2f; const float* b2; const float* gamma2;
     float eps;
     int terms = 1;   // weight terms of the four fragment arrays (1 or 2)
+    void* ts = nullptr;   // stamp buffer of the timeline instance (fvit_debug_ct_block_timeline)
 };
 bool ctblk_supported(int C, int heads, int G, int hidden);
 int launch_ctblk(const CtBlkCall& c, hipStream_t stream);

@@ -44,6 +44,7 @@ struct CtBlkParams {
     const float* b2; const float* gamma2;
     float eps;
     int touch;
+    unsigned long long* ts;   // ctblk8_kernel TS instance (fvit_debug_ct_block_timeline): s_memtime stamps [image][wave][16]
 };
 
 // DEPTH: steps of the register ring in flight; MINB: workgroups per CU the register budget is sized for (1: one wave per SIMD, 512
@@ -388,6 +389,360 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// The 8-wave form (r03, fvit_tune "ct_variant" = 3): the same branch, one image per workgroup, with the waves splitting OUTPUT channels
+// instead of the reduction dimension:
+//   attention  wave w = head w (q^T, k^T, v of its head: 48 weight fragments; scores, softmax, O^T in registers); O^T (1 KiB) goes to LDS
+//   proj       wave w = channel fragments 2w, 2w + 1 over ALL heads (16 fragments of w_proj_frag), O^T fragments of the eight heads from LDS
+//   fc1        wave w = hidden chunks 4w .. 4w + 3 (64 fragments); GELU(H^T) fragments (1 KiB per chunk) go to LDS
+//   fc2        wave w = channel fragments 2w, 2w + 1 over all 32 chunks (64 fragments), H^T fragments from LDS
+// No fp32 partial sums are exchanged (ctblk_kernel: 2 x 64 KiB through LDS, added in wave order): what crosses waves is the 16-bit operand
+// the next GEMM reads anyway, plus the 16-KiB fp32 carrier rows for the second LayerNorm, which every wave recomputes for itself (as it
+// does the first one: the gather is 16 KiB per wave out of L2).  Every wave streams 192 KiB of weights instead of 384 (the same arrays, other
+// fragment addresses), eight rings of three 8-fragment steps are in flight per CU instead of four.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int WT, int DEPTH, bool TS = false>
+__global__ __launch_bounds__(512, 1) void ctblk8_kernel(CtBlkParams p) {
+    typedef typename Op16<T>::v8 v8;
+    // stamps: 0 entry, 1 rows + constants landed (constants in LDS), first ring steps requested, 3 barrier passed, 2 LayerNorm 1 done, 4 attention done, 5 barrier,
+    // 6 proj + residual done, 7 barrier, 8 LayerNorm 2 done, 9 fc1 + GELU done, 10 barrier, 11 fc2 done, 12 end (stores drained)
+#define FVIT_CT8_STAMP(k, dep) if constexpr (TS) { asm volatile("s_nop 0" ::"v"(dep) : "memory"); if ((threadIdx.x & 63) == 0) p.ts[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); }
+    FVIT_CT8_STAMP(0, threadIdx.x)
+    constexpr int C = 256, KK = 8, CB = 16, NW = 8, HID = 1024;
+    constexpr int S_QKV = 6 * WT, S_PROJ = 2 * WT, S_FC1 = 8 * WT, S_FC2 = 8 * WT;
+    constexpr int T_PROJ = S_QKV, T_FC1 = T_PROJ + S_PROJ, T_FC2 = T_FC1 + S_FC1, NSTEP = T_FC2 + S_FC2;
+    constexpr size_t QKV_IMG = (size_t)3 * C * C * 2, PROJ_IMG = (size_t)C * C * 2, FC_IMG = (size_t)C * HID * 2;
+    constexpr int OFF_OT = 0, OFF_H = OFF_OT + 8 * 1024, OFF_CT = OFF_H + 32 * 1024, OFF_B1 = OFF_CT + CB * 1024;
+    constexpr int OFF_BQ = OFF_B1 + HID * 4, OFF_BZ = OFF_BQ + 8 * 96 * 4, OFF_VEC = OFF_BZ + 8 * 256 * 4;
+    // the eight per-channel vectors of the branch (ln1 w / b, proj bias, gamma1, ln2 w / b, fc2 bias, gamma2; a missing gamma is stored as ones):
+    // read from global inside the phases they would queue behind the ring's prefetches in the in-order vmcnt counter and drain it
+    // (timeline of the first version: proj + residual 2.9 us for 16 MFMAs, LayerNorm 2 2.5 us)
+    __shared__ __attribute__((aligned(16))) char smem[OFF_VEC + 8 * C * 4];
+    float* b1s = (float*)(smem + OFF_B1);
+    float* bqs = (float*)(smem + OFF_BQ);
+    float* bzs = (float*)(smem + OFF_BZ);
+    float* vecs = (float*)(smem + OFF_VEC);   // [8][256]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, s = lane & 15;
+    const int lane16 = lane * 16;
+    const int img = blockIdx.x;
+    const int tok = s < p.G ? s : p.G - 1;
+    const bool row_ok = s < p.G;
+
+    // ---- the rows first (the longest round trip: they come from the memory side), every wave for itself: lane (g, s) holds token s,
+    //      channels (cb>>2)*64 + 16g + (cb&3)*4 .. +3 in v[cb] ----
+    const float* src = p.X + ((size_t)img * p.rowsA + p.src_idx[tok]) * C + g * 16;
+    const bool has_add = p.add != nullptr;
+    const float* addp = has_add ? p.add + (size_t)tok * C + g * 16 : src;
+    f4 v[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) v[cb] = *(const f4*)(src + (cb >> 2) * 64 + (cb & 3) * 4);
+    if (has_add) {   // hat_pos_embed rows (L2): requested here too -- after the barrier they would queue behind the first ring steps
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) v[cb] += *(const f4*)(addp + (cb >> 2) * 64 + (cb & 3) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    const char* Wq = (const char*)p.wqkv_f + lane16;
+    const char* Wp = (const char*)p.wproj_f + lane16;
+    const char* W1 = (const char*)p.w1f + lane16;
+    const char* W2 = (const char*)p.w2f + lane16;
+    v8 ring[DEPTH][8];
+    // fragment i of stream step t (compile-time t): the term is the fastest index inside each GEMM's step list
+    auto frag_ptr = [&](int t, int i) -> const char* {
+        if (t < T_PROJ) {            // qkv: step = (ub, term): the 8 k fragments of (head = wave, ub)
+            const int ub = t / WT, term = t % WT;
+            return Wq + term * QKV_IMG + ((size_t)wave * 48 + ub * 8 + i) * 1024;
+        }
+        if (t < T_FC1) {             // proj: step = (half, term): heads 4 half .. 4 half + 3 x channel fragments 2w, 2w + 1
+            const int u = t - T_PROJ, half = u / WT, term = u % WT;
+            const int h = 4 * half + (i >> 1), cb = 2 * wave + (i & 1);
+            return Wp + term * PROJ_IMG + ((size_t)h * CB + cb) * 1024;
+        }
+        if (t < T_FC2) {             // fc1: step = (chunk c, hb, term): the 8 k fragments of (j = 4w + c, hb)
+            const int u = t - T_FC1, ch = u / WT, term = u % WT;
+            const int j = 4 * wave + (ch >> 1), hb = ch & 1;
+            return W1 + term * FC_IMG + ((size_t)j * 16 + hb * 8 + i) * 1024;
+        }
+        {                            // fc2: step = (quad q, term): chunks 4q .. 4q + 3 x channel fragments 2w, 2w + 1
+            const int u = t - T_FC2, q = u / WT, term = u % WT;
+            const int j = 4 * q + (i >> 1), cb = 2 * wave + (i & 1);
+            return W2 + term * FC_IMG + ((size_t)j * CB + cb) * 1024;
+        }
+    };
+#define FVIT_CT8_LOAD(t)                                                                                              \
+    if ((t) < NSTEP) {                                                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) ring[(t) % DEPTH][i_] = *(const v8*)frag_ptr((t), i_);      \
+    }                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+
+    {   // constants (behind the rows in the vmcnt queue), then the first DEPTH steps of the weight stream
+        float c1[2], c3[4], c4[4];
+        float c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) c1[i] = p.b1[tid + 512 * i];
+        if (tid < 8 * 96 - 512) c2 = p.bqkv[tid + 512];
+        const float c2a = p.bqkv[tid];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c3[i] = p.bias[tid + 512 * i];
+        {
+            const float* vp[8] = {p.ln1_w, p.ln1_b, p.bproj, p.gamma1, p.ln2_w, p.ln2_b, p.b2, p.gamma2};
+            const int hi = tid >> 8, ch = tid & 255;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* q = hi ? vp[2 * i + 1] : vp[2 * i];
+                c4[i] = q ? q[ch] : 1.0f;   // only the gammas can be null
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < DEPTH; ++t) { FVIT_CT8_LOAD(t) }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b1s[tid + 512 * i] = c1[i];
+        bqs[tid] = c2a;
+        if (tid < 8 * 96 - 512) bqs[tid + 512] = c2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bzs[tid + 512 * i] = c3[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vecs[(2 * i + (tid >> 8)) * C + (tid & 255)] = c4[i];
+        FVIT_CT8_STAMP(1, c3[3])
+    }
+    __syncthreads();   // constants visible (plain loads in flight survive the barrier)
+    FVIT_CT8_STAMP(3, v[0])
+
+    auto layernorm = [&](const f4 (&v)[CB], const float* lw, const float* lb, v8 (&xf)[KK]) {
+        float sum = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) sum += (v[cb][0] + v[cb][1]) + (v[cb][2] + v[cb][3]);
+        sum = sum_xor32(sum_xor16(sum));
+        const float mean = sum / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const f4 d = v[cb] - mean;
+            sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        sq = sum_xor32(sum_xor16(sq));
+        const float rstd = rsqrtf(sq / (float)C + p.eps);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            v8 o;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int cb = 2 * kk + h2;
+                const int co = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
+                const f4 w = *(const f4*)(lw + co);
+                const f4 b = *(const f4*)(lb + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = sat16<T>((v[cb][r] - mean) * rstd * w[r] + b[r]);
+            }
+            xf[kk] = o;
+        }
+    };
+
+    v8 xf[KK];
+    f4 ct0[2];   // this wave's two channel fragments (2w, 2w + 1) of the gathered rows, for the first residual
+    {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {   // cb = 2 * wave + q without dynamic register indexing
+            f4 t = v[q];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) t = wave == w ? v[2 * w + q] : t;
+            ct0[q] = t;
+        }
+        layernorm(v, vecs + 0 * C, vecs + 1 * C, xf);
+    }
+    FVIT_CT8_STAMP(2, xf[KK - 1])
+
+    // ---- attention of head = wave ----
+    {
+        const int h = wave;
+        const float* bq = bqs + h * 96;
+        v8 qf, kf, vf[2];
+#pragma unroll
+        for (int ub = 0; ub < 6; ++ub) {
+            f4 a = (f4){0.f, 0.f, 0.f, 0.f}, ao = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int term = 0; term < WT; ++term) {
+                const int t = ub * WT + term;
+#pragma unroll
+                for (int kk = 0; kk < KK; kk += 2) {
+                    a = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a) : Op16<T>::mfma(xf[kk], ring[t % DEPTH][kk], a);
+                    ao = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[kk + 1], ao) : Op16<T>::mfma(xf[kk + 1], ring[t % DEPTH][kk + 1], ao);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                FVIT_CT8_LOAD(t + DEPTH)
+            }
+            a += ao;
+            if (ub < 4) {
+                const f4 bb = *(const f4*)(bq + (ub >> 1) * 32 + (ub & 1) * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (ub < 2) qf[(ub & 1) * 4 + r] = sat16<T>(a[r] + bb[r]);
+                    else kf[(ub & 1) * 4 + r] = sat16<T>(a[r] + bb[r]);
+                }
+            } else {
+                const float bv = bq[64 + (ub - 4) * 16 + s];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vf[ub - 4][r] = sat16<T>(a[r] + bv);
+                    vf[ub - 4][4 + r] = (T)0.f;
+                }
+            }
+        }
+        f4 sc = Op16<T>::mfma(kf, qf, (f4){0.f, 0.f, 0.f, 0.f});
+        const f4 bz = *(const f4*)(bzs + (h * 16 + tok) * 16 + g * 4);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = sc[r] * p.scale + bz[r];
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = max_xor32(max_xor16(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = __expf(sc[r] - mx);
+            sum += sc[r];
+        }
+        sum = sum_xor32(sum_xor16(sum));
+        const float inv = 1.0f / sum;
+        v8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf[r] = (T)sc[r];
+            pf[4 + r] = (T)0.f;
+        }
+        v8 of;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const f4 o = Op16<T>::mfma(vf[db], pf, (f4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) of[db * 4 + r] = sat16<T>(o[r] * inv);
+        }
+        *(v8*)(smem + OFF_OT + h * 1024 + lane16) = of;
+        FVIT_CT8_STAMP(4, of)
+    }
+    __syncthreads();   // O^T of all heads visible
+    FVIT_CT8_STAMP(5, xf[0])
+
+    // ---- proj over all heads for channel fragments 2w, 2w + 1; ct1 = ct0 + gamma1 * (out + bproj) -> LDS (fp32, lane-linear per fragment) ----
+    {
+        f4 oacc[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            v8 ob[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ob[i] = *(const v8*)(smem + OFF_OT + (4 * half + i) * 1024 + lane16);
+#pragma unroll
+            for (int term = 0; term < WT; ++term) {
+                const int t = T_PROJ + half * WT + term;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) oacc[i & 1] = Op16<T>::mfma(ring[t % DEPTH][i], ob[i >> 1], oacc[i & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                FVIT_CT8_LOAD(t + DEPTH)
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cb = 2 * wave + q;
+            const int co = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
+            const f4 bv = *(const f4*)(vecs + 2 * C + co);
+            const f4 gl = *(const f4*)(vecs + 3 * C + co);
+            f4 o = ct0[q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] += gl[r] * (oacc[q][r] + bv[r]);
+            *(f4*)(smem + OFF_CT + cb * 1024 + lane16) = o;
+        }
+        FVIT_CT8_STAMP(6, oacc[1])
+    }
+    __syncthreads();   // ct1 of all channel fragments visible
+    FVIT_CT8_STAMP(7, xf[0])
+
+    // ---- second LayerNorm (every wave for itself), fc1 + GELU of hidden chunks 4w .. 4w + 3 -> LDS ----
+    {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) v[cb] = *(const f4*)(smem + OFF_CT + cb * 1024 + lane16);
+        layernorm(v, vecs + 4 * C, vecs + 5 * C, xf);
+    }
+    FVIT_CT8_STAMP(8, xf[KK - 1])
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int j = 4 * wave + c;
+        f4 a1[2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            f4 a = (f4){0.f, 0.f, 0.f, 0.f}, ao = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int term = 0; term < WT; ++term) {
+                const int t = T_FC1 + (2 * c + hb) * WT + term;
+#pragma unroll
+                for (int kk = 0; kk < KK; kk += 2) {
+                    a = Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a);
+                    ao = Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[kk + 1], ao);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                FVIT_CT8_LOAD(t + DEPTH)
+            }
+            a1[hb] = a + ao;
+        }
+        const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
+        const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
+        v8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf[r] = sat16<T>(gelu_fast(a1[0][r] + bA[r]));
+            pf[4 + r] = sat16<T>(gelu_fast(a1[1][r] + bB[r]));
+        }
+        *(v8*)(smem + OFF_H + j * 1024 + lane16) = pf;
+        if (c == 3) { FVIT_CT8_STAMP(9, pf) }
+    }
+    __syncthreads();   // H^T of all 32 chunks visible
+    FVIT_CT8_STAMP(10, xf[0])
+
+    // ---- fc2 over all chunks for channel fragments 2w, 2w + 1; ct2 = ct1 + gamma2 * (out + b2) -> R ----
+    {
+        f4 acc2[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v8 hb4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hb4[i] = *(const v8*)(smem + OFF_H + (4 * q + i) * 1024 + lane16);
+#pragma unroll
+            for (int term = 0; term < WT; ++term) {
+                const int t = T_FC2 + q * WT + term;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc2[i & 1] = Op16<T>::mfma(ring[t % DEPTH][i], hb4[i >> 1], acc2[i & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                FVIT_CT8_LOAD(t + DEPTH)
+            }
+        }
+        FVIT_CT8_STAMP(11, acc2[1])
+        if (row_ok) {
+            float* pr = p.R + ((size_t)img * p.G + s) * C;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cb = 2 * wave + q;
+                const int co = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
+                const f4 bv = *(const f4*)(vecs + 6 * C + co);
+                const f4 gl = *(const f4*)(vecs + 7 * C + co);
+                f4 o = *(const f4*)(smem + OFF_CT + cb * 1024 + lane16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += gl[r] * (acc2[q][r] + bv[r]);
+                *(f4*)(pr + co) = o;
+            }
+        }
+    }
+    if constexpr (TS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    FVIT_CT8_STAMP(12, threadIdx.x)
+#undef FVIT_CT8_STAMP
+#undef FVIT_CT8_LOAD
+}
+
 }  // namespace
 
 bool ctblk_supported(int C, int heads, int G, int hidden) { return C == 256 && heads == 8 && hidden == 1024 && G >= 1 && G <= 16; }
@@ -410,8 +765,29 @@ int launch_ctblk(const CtBlkCall& c, hipStream_t stream) {
     ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
     prof_note("ctblk_kernel<256,G16>", c.batch);
     p.touch = tune_get("ct_touch", 0);
-    const int variant = tune_get("ct_variant", 0);
+    p.ts = (unsigned long long*)c.ts;
+    if (c.ts) {   // timeline instance: the 8-wave fp16 form, single-term weights
+        if (c.dtype != FVIT_F16 || c.terms != 1) { set_error("ct_block timeline: fp16, one weight term only"); return FVIT_EINVAL; }
+        hipLaunchKernelGGL((ctblk8_kernel<_Float16, 1, 2, true>), dim3(c.batch), dim3(512), 0, stream, p);
+        return check_launch("ctblk8_kernel");
+    }
+    // 3 (default since r03): the 8-wave form; 0 / 1 / 2: the 4-wave form with ring depth 3 / 2 (256 registers) / 4
+    const int variant = tune_get("ct_variant", 3);
     if (c.terms != 1 && c.terms != 2) { set_error("ct_block: weight terms %d (1 or 2)", c.terms); return FVIT_EINVAL; }
+    if (variant == 3) {   // the 8-wave form: waves split output channels, no fp32 partial exchange
+        const int depth = tune_get("ct8_depth", 3);   // ring steps of 8 fragments in flight per wave (2 / 3 / 4)
+#define FVIT_CT8(T_, WT_) do { \
+            if (depth == 2) hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 2>), dim3(c.batch), dim3(512), 0, stream, p); \
+            else if (depth == 4) hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 4>), dim3(c.batch), dim3(512), 0, stream, p); \
+            else hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 3>), dim3(c.batch), dim3(512), 0, stream, p); } while (0)
+        if (c.dtype == FVIT_F16) {
+            if (c.terms == 2) FVIT_CT8(_Float16, 2); else FVIT_CT8(_Float16, 1);
+        } else if (c.dtype == FVIT_BF16) {
+            if (c.terms == 2) FVIT_CT8(__bf16, 2); else FVIT_CT8(__bf16, 1);
+#undef FVIT_CT8
+        } else { set_error("ct_block: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
+        return check_launch("ctblk8_kernel");
+    }
     if (c.dtype == FVIT_F16 && c.terms == 2) {
         hipLaunchKernelGGL((ctblk_kernel<_Float16, 3, 1, 2>), dim3(c.batch), dim3(256), 0, stream, p);
     } else if (c.dtype == FVIT_F16) {

@@ -447,6 +447,14 @@ int fvit_debug_rowhash_dump(int32_t record, void* dst, int64_t capacity_bytes);
  * fragments; per hidden chunk: the W1 fragments as read from LDS, the pre-GELU accumulators, the GELU output fragment, the W2 fragments as
  * read, the output accumulators) to consecutive slices of buf: [workgroup * 4 + wave][1 + 5 * hidden / 32][64 lanes] words.  _end returns
  * the number of traced launches (<= 64) with their slice offsets (words) and row counts.  Single host thread only. */
+/* The 8-wave form of fvit_ct_block_fused (fp16) with s_memtime stamps per wave: stamps u64 [batch][8][16]: 0 entry, 1 constants in LDS + first
+ * weight steps and rows requested, 2 LayerNorm 1, 3 barrier, 4 attention, 5 barrier, 6 proj + residual, 7 barrier, 8 LayerNorm 2, 9 fc1 + GELU,
+ * 10 barrier, 11 fc2, 12 end. */
+int fvit_debug_ct_block_timeline(const float* X, int32_t rowsA, const int32_t* src_idx, const float* add, float* R,
+                                 int32_t batch, int32_t G, int32_t heads, int32_t C, int32_t hidden, const float* ln1_w, const float* ln1_b,
+                                 const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag, const float* b_proj, const float* gamma1,
+                                 const float* bias, float scale, const float* ln2_w, const float* ln2_b, const void* w_fc1_frag, const float* b_fc1,
+                                 const void* w_fc2_frag, const float* b_fc2, const float* gamma2, float eps, void* stamps, fvit_stream_t stream);
 /* fvit_attn_block_fused (fp16, C = 256, 48 < S <= 64: the default 4-wave form) with s_memtime stamps per wave: stamps u64 [nwin][4][16]:
  * 0 entry, 1 first weight slice requested + rows gathered, 2 LayerNorm done, 3 .. 10 end of head 0 .. 7, 14 head loop done, 15 end. */
 int fvit_debug_attn_block_timeline(const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,

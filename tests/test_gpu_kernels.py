@@ -690,14 +690,14 @@ def test_ct_block_fused(opname, dt, code, batch, G, use_add, use_gamma):
     out = torch.full((batch * G + 3, C), float("nan"), device="cuda")
     scale = d ** -0.5
     p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):   # 3: the 8-wave form (waves split output channels)
         _lib.tune("ct_variant", variant)
         out.fill_(float("nan"))
         rc = lib.fvit_ct_block_fused(code, X.data_ptr(), rowsA, src_idx.data_ptr(), p(add), out.data_ptr(), batch, G, heads, C, hid,
                                      ln1w.data_ptr(), ln1b.data_ptr(), wqf.data_ptr(), bqh.data_ptr(), wpf.data_ptr(), bproj.data_ptr(), p(g1),
                                      bp.data_ptr(), ctypes.c_float(scale), ln2w.data_ptr(), ln2b.data_ptr(), w1f.data_ptr(), b1.data_ptr(),
                                      w2f.data_ptr(), b2.data_ptr(), p(g2), ctypes.c_float(1e-5), _stream())
-        _lib.tune("ct_variant", 0)
+        _lib.tune("ct_variant", 3)   # the default
         _lib.check(rc, "ct_block_fused")
         torch.cuda.synchronize()
         ct = X.view(batch, rowsA, C)[:, src_idx.long()]

@@ -19,7 +19,8 @@ from tests.util import build_product_model, case_input, load_golden, max_abs
 pytestmark = pytest.mark.gpu
 
 OPS = [("f16", torch.float16, 1), ("bf16", torch.bfloat16, 2)]
-GEMM_PP_DEFAULT = 1   # default of the "gemm_pp" tuning knob (fvit_gemm.hip)
+GEMM_PP_DEFAULT = 1      # default of the "gemm_pp" tuning knob (fvit_gemm.hip)
+CT_VARIANT_DEFAULT = 3   # default of the "ct_variant" knob (fvit_ctblk.hip)
 
 
 def _rup(x, m):
@@ -445,9 +446,12 @@ def test_win_block_two_weight_terms(opname, dt, code, S, nwin, use_gamma):
 
 @pytest.mark.parametrize("opname,dt,code", OPS)
 @pytest.mark.parametrize("batch,G,use_add,use_gamma", [(86, 16, True, True), (7, 9, False, False), (2, 1, True, True)])
-def test_ct_block_two_weight_terms(opname, dt, code, batch, G, use_add, use_gamma):
-    """fvit_ct_block_fused_terms: the carrier-token branch in one kernel with [hi image | lo image] weights in all four fragment arrays."""
+@pytest.mark.parametrize("variant", [0, 3])
+def test_ct_block_two_weight_terms(opname, dt, code, batch, G, use_add, use_gamma, variant):
+    """fvit_ct_block_fused_terms: the carrier-token branch in one kernel with [hi image | lo image] weights in all four fragment arrays
+    (variant 0: the 4-wave form, 3: the 8-wave form)."""
     lib = _lib.lib()
+    _lib.tune("ct_variant", variant)
     C, heads, hid = 256, 8, 1024
     g = torch.Generator(device="cpu").manual_seed(batch * 19 + G)
     rowsA = 4 * 53
@@ -512,3 +516,4 @@ def test_ct_block_two_weight_terms(opname, dt, code, batch, G, use_add, use_gamm
     torch.cuda.synchronize()
     assert (out[:batch * G] - ref1).abs().max().item() < tol
     assert call(0) != 0
+    _lib.tune("ct_variant", CT_VARIANT_DEFAULT)
