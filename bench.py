@@ -260,9 +260,9 @@ def pmc_row(kernel, workgroups, pmc_file=None):
     best = None
     for r in json.load(open(path)).get("kernels", []):
         if r["kernel"].startswith(fam) and int(r.get("workgroups", -1)) == int(workgroups):
-            if kernel.startswith("gemm_kernel<"):   # epilogue id is the 2nd template argument of gemm_kernel<T,EPI,...>
+            if kernel.startswith(("gemm_kernel<", "gemm_pp_kernel<")):   # epilogue id is the 2nd template argument of gemm[_pp]_kernel<T,EPI,...>
                 targs = r["kernel"].split("<", 1)[1].split(",")
-                if len(targs) < 2 or targs[1].strip() != kernel[12]:
+                if len(targs) < 2 or targs[1].strip().rstrip(">") != kernel.split("<", 1)[1][0]:
                     continue
             if best is None or r["total_us"] > best["total_us"]:
                 best = r

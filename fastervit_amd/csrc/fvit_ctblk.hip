@@ -763,7 +763,7 @@ int launch_ctblk(const CtBlkCall& c, hipStream_t stream) {
     const double flops = rows * (2.0 * c.C * 3 * c.C + 4.0 * c.G * c.C + 2.0 * c.C * c.C + 4.0 * c.C * c.hidden);
     const double bytes = rows * c.C * 8.0 + c.terms * 2.0 * (4.0 * c.C * c.C + 2.0 * c.C * c.hidden);
     ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
-    prof_note("ctblk_kernel<256,G16>", c.batch);
+    prof_note(tune_get("ct_variant", 3) == 3 ? "ctblk8_kernel<256,G16>" : "ctblk_kernel<256,G16>", c.batch);
     p.touch = tune_get("ct_touch", 0);
     p.ts = (unsigned long long*)c.ts;
     if (c.ts) {   // timeline instance: the 8-wave fp16 form, single-term weights

@@ -566,9 +566,10 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
         kind = c.epilogue == 1 ? FVIT_K_GEMM_GELU : FVIT_K_GEMM_BIAS;
     }
     ProfScope prof(kind, flops, bytes, stream);
-    prof_note(c.epilogue == 2 ? (big ? "gemm_kernel<2> 256x256" : small ? "gemm_kernel<2> 64-row" : "gemm_kernel<2> 128-row")
-                              : c.epilogue == 1 ? (big ? "gemm_kernel<1> 256x256" : small ? "gemm_kernel<1> 64-row" : "gemm_kernel<1> 128-row")
-                                                : (big ? "gemm_kernel<0> 256x256" : small ? "gemm_kernel<0> 64-row" : "gemm_kernel<0> 128-row"), grid);
+    const bool pp = big && tune_get("gemm_pp", 1);
+    prof_note(c.epilogue == 2 ? (pp ? "gemm_pp_kernel<2> 256x256" : big ? "gemm_kernel<2> 256x256" : small ? "gemm_kernel<2> 64-row" : "gemm_kernel<2> 128-row")
+                              : c.epilogue == 1 ? (pp ? "gemm_pp_kernel<1> 256x256" : big ? "gemm_kernel<1> 256x256" : small ? "gemm_kernel<1> 64-row" : "gemm_kernel<1> 128-row")
+                                                : (pp ? "gemm_pp_kernel<0> 256x256" : big ? "gemm_kernel<0> 256x256" : small ? "gemm_kernel<0> 64-row" : "gemm_kernel<0> 128-row"), grid);
     // measured r01: a 3-stage ring with counted vmcnt gave no gain over 2 stages at 64..392 workgroups => opt-in only
     const bool deep = !small && !nw8 && grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
     // ring depth of the 64-row tiles (small grids): 2 (48 KiB, three workgroups per CU), 3 (72 KiB, two) or 4 (96 KiB, one)
@@ -579,7 +580,7 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     switch (c.epilogue) { case 0: FVIT_GEMM(0, NS, MI_, NW_); break; case 1: FVIT_GEMM(1, NS, MI_, NW_); break; default: FVIT_GEMM(2, NS, MI_, NW_); break; }
     // the ping-pong form of the 256 x 256 tile (default since r03: 8-25 % faster than the 2-stage form on every shape that selects the tile,
     // bitwise the same result; FasterViT-4 batch 128 + 0.7 %, any-res + 0.6 % end to end -- profiles/r03_gemm_ping_pong_256_tile.log)
-    if (big && tune_get("gemm_pp", 1)) {
+    if (pp) {
         switch (c.epilogue) {
             case 0: hipLaunchKernelGGL((gemm_pp_kernel<T, 0>), dim3(grid), dim3(512), 0, stream, p); break;
             case 1: hipLaunchKernelGGL((gemm_pp_kernel<T, 1>), dim3(grid), dim3(512), 0, stream, p); break;
