@@ -392,6 +392,27 @@ int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const void* weight
 int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2,
                     void* out, int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream);
 
+/* ---- backward of the MLP sub-block  y = x + gamma * fc2(GELU(fc1(LayerNorm(x))))  (Mlp.forward FV:398-407 inside HAT.forward FV:691; the reference
+ * differentiates it with autograd, train.py:820-951) -- SURVEY.md section 8 row f-4, the slice VERDICT r02 item 9 scopes (csrc/fvit_bwd.hip).
+ * The four GEMMs of the backward run through fvit_gemm_bias_act / fvit_gemm_residual (fp32 results through the residual epilogue into zeroed or
+ * accumulating buffers); these are the memory-bound pieces between them.  Host sequence: fastervit_amd/hat_backward.py.  No atomics: column sums
+ * are per-block partials (fvit_bwd_blocks(M) blocks of 64 rows) added in block order by fvit_bwd_colsum_finish.  op16 = operand_dtype. */
+int32_t fvit_bwd_blocks(int32_t M);
+/* out[n][m] = in[m][n] for m < M, n < N; columns M .. ld_out - 1 of the N written rows are zeroed (ld_out: a multiple of 64 >= M). */
+int fvit_bwd_transpose16(int32_t operand_dtype, const void* in, int32_t ld_in, void* out, int32_t ld_out, int32_t M, int32_t N, fvit_stream_t stream);
+/* dz[m][c] (op16) = gamma[c] * dy[m][c] (gamma NULL = 1); part f32 [blocks][2][C]: [0] column sums of dy * z (-> dgamma), [1] of gamma * dy (-> db2). */
+int fvit_bwd_scale_cols(int32_t operand_dtype, const float* dy, const void* z, int32_t ldz, const float* gamma, void* dz, int32_t lddz, float* part,
+                        int32_t M, int32_t C, fvit_stream_t stream);
+/* dh NULL: out = GELU(a) (erf form).  dh given: out = dh * GELU'(a), part f32 [blocks][H] = column sums of out (-> db1). */
+int fvit_bwd_gelu(int32_t operand_dtype, const void* a, int32_t lda, const void* dh, int32_t lddh, void* out, int32_t ldo, float* part, int32_t M,
+                  int32_t H, fvit_stream_t stream);
+/* LayerNorm backward: dx[m] = (dy ? dy[m] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dxn[m] * ln_w; stats f32 [M][2] = (mean, rstd);
+ * part f32 [blocks][2][C]: [0] column sums of dxn * xhat (-> d ln_w), [1] of dxn (-> d ln_b).  All tensors f32 [M][C]. */
+int fvit_bwd_layernorm(const float* x, const float* dxn, const float* dy, const float* ln_w, float eps, float* dx, float* stats, float* part,
+                       int32_t M, int32_t C, fvit_stream_t stream);
+/* out[i] (+)= sum over b < blocks of part[b * stride + i], i < n, in block order. */
+int fvit_bwd_colsum_finish(const float* part, int32_t blocks, int32_t stride, float* out, int32_t n, int32_t accumulate, fvit_stream_t stream);
+
 /* ---- head-only training step (north_star's training clause; csrc/fvit_head.hip) ----
  * The classifier FasterViT.head = nn.Linear(F, N) (FV:927, 959) is trained on the pooled features of the frozen HIP backbone; the
  * reference wraps the WHOLE model in DistributedDataParallel (train.py:542-551) and reduces the loss for logging (train.py:910).
