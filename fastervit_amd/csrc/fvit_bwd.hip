@@ -126,6 +126,90 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const float* __
     }
 }
 
+// column partial sums of an op16 matrix: part f32 [blocks][N] (-> the qkv bias gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum16_kernel(const T* __restrict__ in, int ld, float* __restrict__ part, int M, int N) {
+    const int m0 = blockIdx.x * BWD_ROWS, m1 = min(m0 + BWD_ROWS, M);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float s = 0.f;
+        for (int m = m0; m < m1; ++m) s += (float)in[(size_t)m * ld + n];
+        part[(size_t)blockIdx.x * N + n] = s;
+    }
+}
+
+// Backward of the windowed attention core (WindowAttention.forward FV:557-568 between the qkv and proj Linears), one workgroup per (window, head):
+//   S = q k^T * scale + bias, P = softmax(S), O = P v;  given dO:
+//   dV = P^T dO;  dP = dO v^T;  dS = P * (dP - rowsum(dP * P));  dq = scale * dS k;  dk = scale * dS^T q;  dbias = dS
+// qkv / dqkv: op16 [rows][ld], columns [q|k|v][head][D]; dO: op16 [rows][ldo], columns [head][D]; bias f32 [heads][spad][spad];
+// dbias_part f32 [nwin][heads][S][S] (summed over windows afterwards, in window order).  fp32 arithmetic on values staged in LDS: this is the
+// training path's correctness reference, not a tuned kernel (2 MFLOP per workgroup).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, int ld, const T* __restrict__ dO, int ldo, const float* __restrict__ bias,
+                                                        int spad, float scale, T* __restrict__ dqkv, float* __restrict__ dbias_part, int S, int heads) {
+    constexpr int SM = 64;
+    __shared__ float q[SM][D + 1], k[SM][D + 1], v[SM][D + 1], g[SM][D + 1];   // g = dO
+    __shared__ float P[SM][SM + 1], dS[SM][SM + 1];
+    __shared__ float rsum[SM];
+    const int win = blockIdx.x / heads, h = blockIdx.x - win * heads;
+    const int tid = threadIdx.x;
+    const size_t row0 = (size_t)win * S;
+    const int HD = heads * D;
+    for (int i = tid; i < S * D; i += 256) {
+        const int r = i / D, d = i - r * D;
+        const T* pr = qkv + (row0 + r) * ld + h * D + d;
+        q[r][d] = (float)pr[0];
+        k[r][d] = (float)pr[HD];
+        v[r][d] = (float)pr[2 * HD];
+        g[r][d] = (float)dO[(row0 + r) * ldo + h * D + d];
+    }
+    __syncthreads();
+    // scores and dP
+    for (int e = tid; e < S * S; e += 256) {
+        const int i = e / S, j = e - i * S;
+        float sc = 0.f, dp = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) {
+            sc += q[i][d] * k[j][d];
+            dp += g[i][d] * v[j][d];
+        }
+        P[i][j] = sc * scale + (bias ? bias[((size_t)h * spad + i) * spad + j] : 0.f);
+        dS[i][j] = dp;
+    }
+    __syncthreads();
+    // softmax per row (thread per row), then rowsum(dP * P)
+    if (tid < S) {
+        float mx = -3.0e38f;
+        for (int j = 0; j < S; ++j) mx = fmaxf(mx, P[tid][j]);
+        float sum = 0.f;
+        for (int j = 0; j < S; ++j) { const float ev = expf(P[tid][j] - mx); P[tid][j] = ev; sum += ev; }
+        const float inv = 1.0f / sum;
+        float r = 0.f;
+        for (int j = 0; j < S; ++j) { const float pv = P[tid][j] * inv; P[tid][j] = pv; r += pv * dS[tid][j]; }
+        rsum[tid] = r;
+    }
+    __syncthreads();
+    for (int e = tid; e < S * S; e += 256) {
+        const int i = e / S, j = e - i * S;
+        const float ds = P[i][j] * (dS[i][j] - rsum[i]);
+        dS[i][j] = ds;
+        if (dbias_part) dbias_part[(((size_t)win * heads + h) * S + i) * S + j] = ds;
+    }
+    __syncthreads();
+    for (int e = tid; e < S * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j < S; ++j) {
+            dq += dS[r][j] * k[j][d];
+            dk += dS[j][r] * q[j][d];
+            dv += P[j][r] * g[j][d];
+        }
+        T* pw = dqkv + (row0 + r) * ld + h * D + d;
+        pw[0] = (T)(dq * scale);
+        pw[HD] = (T)(dk * scale);
+        pw[2 * HD] = (T)dv;
+    }
+}
+
 // out[i] (+)= sum_b part[b * stride + i], b in block order (fixed order: bit-reproducible)
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int blocks, int stride, float* __restrict__ out, int n, int accumulate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -186,6 +270,28 @@ int fvit_bwd_layernorm(const float* x, const float* dxn, const float* dy, const 
     hipLaunchKernelGGL(layernorm_bwd_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, dxn, dy, ln_w, eps, dx, stats, M, C);
     hipLaunchKernelGGL(layernorm_bwd_cols_kernel, dim3((M + BWD_ROWS - 1) / BWD_ROWS), dim3(256), 0, (hipStream_t)stream, x, dxn, (const float*)stats, part, M, C);
     return check_launch("layernorm_bwd_kernel");
+}
+
+int fvit_bwd_colsum16(int32_t dtype, const void* in, int32_t ld, float* part, int32_t M, int32_t N, fvit_stream_t stream) {
+    if (!in || !part || M <= 0 || N <= 0 || ld < N) { set_error("bwd_colsum16: bad arguments"); return FVIT_EINVAL; }
+    const int blocks = (M + BWD_ROWS - 1) / BWD_ROWS;
+    if (dtype == FVIT_F16) hipLaunchKernelGGL((colsum16_kernel<_Float16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in, ld, part, M, N);
+    else if (dtype == FVIT_BF16) hipLaunchKernelGGL((colsum16_kernel<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)in, ld, part, M, N);
+    else { set_error("bwd_colsum16: dtype %d", dtype); return FVIT_EINVAL; }
+    return check_launch("colsum16_kernel");
+}
+
+int fvit_bwd_window_attention(int32_t dtype, const void* qkv, int32_t ld, const void* dO, int32_t ldo, const float* bias, int32_t spad, float scale,
+                              void* dqkv, float* dbias_part, int32_t nwin, int32_t S, int32_t heads, int32_t D, fvit_stream_t stream) {
+    if (!qkv || !dO || !dqkv || nwin <= 0 || S < 1 || S > 64 || heads <= 0 || D != 32 || ld < 3 * heads * D || ldo < heads * D || (bias && spad < S)) {
+        set_error("bwd_window_attention: unsupported arguments nwin=%d S=%d heads=%d D=%d (need S <= 64, head_dim 32)", nwin, S, heads, D);
+        return FVIT_EINVAL;
+    }
+    const dim3 grid(nwin * heads);
+    if (dtype == FVIT_F16) hipLaunchKernelGGL((attn_bwd_kernel<_Float16, 32>), grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)qkv, ld, (const _Float16*)dO, ldo, bias, spad, scale, (_Float16*)dqkv, dbias_part, S, heads);
+    else if (dtype == FVIT_BF16) hipLaunchKernelGGL((attn_bwd_kernel<__bf16, 32>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv, ld, (const __bf16*)dO, ldo, bias, spad, scale, (__bf16*)dqkv, dbias_part, S, heads);
+    else { set_error("bwd_window_attention: dtype %d", dtype); return FVIT_EINVAL; }
+    return check_launch("attn_bwd_kernel");
 }
 
 int fvit_bwd_colsum_finish(const float* part, int32_t blocks, int32_t stride, float* out, int32_t n, int32_t accumulate, fvit_stream_t stream) {

@@ -410,6 +410,13 @@ int fvit_bwd_gelu(int32_t operand_dtype, const void* a, int32_t lda, const void*
  * part f32 [blocks][2][C]: [0] column sums of dxn * xhat (-> d ln_w), [1] of dxn (-> d ln_b).  All tensors f32 [M][C]. */
 int fvit_bwd_layernorm(const float* x, const float* dxn, const float* dy, const float* ln_w, float eps, float* dx, float* stats, float* part,
                        int32_t M, int32_t C, fvit_stream_t stream);
+/* part f32 [blocks][N] = column sums of an op16 [M][ld] matrix over the block's rows (-> the qkv bias gradient). */
+int fvit_bwd_colsum16(int32_t operand_dtype, const void* in, int32_t ld, float* part, int32_t M, int32_t N, fvit_stream_t stream);
+/* Backward of the windowed attention core (WindowAttention.forward FV:557-568 between the two Linears; fvit_window_attention's layouts): per
+ * (window, head)  dv = P^T dO, dS = P * (dO v^T - rowsum(dO v^T * P)), dq = scale * dS k, dk = scale * dS^T q  -> dqkv (op16, qkv's layout);
+ * dbias_part f32 [nwin][heads][S][S] = dS (sum over windows with fvit_bwd_colsum_finish) or NULL.  S <= 64, head_dim D == 32. */
+int fvit_bwd_window_attention(int32_t operand_dtype, const void* qkv, int32_t ld, const void* dO, int32_t ldo, const float* bias, int32_t spad,
+                              float scale, void* dqkv, float* dbias_part, int32_t nwin, int32_t S, int32_t heads, int32_t D, fvit_stream_t stream);
 /* out[i] (+)= sum over b < blocks of part[b * stride + i], i < n, in block order. */
 int fvit_bwd_colsum_finish(const float* part, int32_t blocks, int32_t stride, float* out, int32_t n, int32_t accumulate, fvit_stream_t stream);
 

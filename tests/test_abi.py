@@ -168,3 +168,13 @@ def test_committed_pmc_traffic_file_covers_the_default_kernels():
         assert fam in fams, f"{bench.PMC_FILE} has no row of {fam}: re-run scripts/gpu_r2_evidence.sh and copy the new file"
     dom = [r for r in rows if r["kernel"].startswith("winmlp_kernel<f16,256") and r["workgroups"] == 285]
     assert dom and dom[0]["hbm_traffic_mb"] > 0
+
+
+def test_hat_backward_has_no_cpu_path():
+    """fastervit_amd.hat_backward (sub-block backward on the HIP kernels) raises on CPU tensors instead of falling back."""
+    from fastervit_amd import hat_backward
+    x = torch.zeros(4, 256)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        hat_backward.mlp_block_backward(x, x, x[0], x[0], torch.zeros(1024, 256), torch.zeros(1024), torch.zeros(256, 1024), torch.zeros(256), None, None)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        hat_backward.attn_block_backward(x, x, x[0], x[0], torch.zeros(768, 256), None, torch.zeros(256, 256), torch.zeros(256), None, None, 8, 4, None)

@@ -53,11 +53,90 @@ def test_mlp_block_backward_vs_autograd(dt, tol, M, C, hid, use_gamma):
     assert torch.equal(grads.fc1_w, grads_b.fc1_w) and torch.equal(grads.fc2_w, grads_b.fc2_w) and torch.equal(grads.ln_w, grads_b.ln_w)
 
 
-def test_mlp_block_backward_rejects_cpu_and_bad_shapes():
-    x = torch.zeros(4, 256)
-    grads = None
-    with pytest.raises(RuntimeError):
-        hat_backward.mlp_block_backward(x, x, x[0], x[0], torch.zeros(1024, 256), torch.zeros(1024), torch.zeros(256, 1024), torch.zeros(256), None, grads)
+def test_backward_primitives_reject_bad_arguments():
     lib = _lib.lib()
     assert lib.fvit_bwd_blocks(65) == 2
     assert lib.fvit_bwd_transpose16(1, None, 0, None, 0, 1, 1, None) != 0
+    assert lib.fvit_bwd_window_attention(1, None, 0, None, 0, None, 0, 1.0, None, None, 1, 65, 8, 32, None) != 0
+
+
+def _attn_reference(x, dy, lnw, lnb, wq, bq, wp, bp, gamma, bias, heads, S):
+    leaves = [t.clone().requires_grad_(True) for t in (x, lnw, lnb, wq, bq, wp, bp)]
+    gl = gamma.clone().requires_grad_(True) if gamma is not None else None
+    bl = bias.clone().requires_grad_(True) if bias is not None else None
+    xr, lw, lb, Wq, Bq, Wp, Bp = leaves
+    M, C = xr.shape
+    n, d = M // S, C // heads
+    xn = F.layer_norm(xr, (C,), lw, lb, 1e-5)
+    qkv = F.linear(xn, Wq, Bq).view(n, S, 3, heads, d).permute(2, 0, 3, 1, 4)
+    att = (qkv[0] @ qkv[1].transpose(-1, -2)) * d ** -0.5
+    if bl is not None:
+        att = att + bl
+    o = (att.softmax(-1) @ qkv[2]).transpose(1, 2).reshape(M, C)
+    y = F.linear(o, Wp, Bp)
+    (xr + (gl * y if gl is not None else y)).backward(dy)
+    return [t.grad for t in leaves], (gl.grad if gl is not None else None), (bl.grad if bl is not None else None)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 5e-3), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("nwin,S,C,use_gamma,use_bias", [(86, 49, 512, True, True), (7, 50, 256, True, True), (3, 64, 256, False, True), (5, 16, 256, True, False)])
+def test_attn_block_backward_vs_autograd(dt, tol, nwin, S, C, use_gamma, use_bias):
+    heads = C // 32
+    g = torch.Generator(device="cpu").manual_seed(nwin * 100 + S)
+    M = nwin * S
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.2).cuda()
+    dy = torch.randn(M, C, generator=g).cuda()
+    lnw, lnb = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    wq, bq = (torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda(), (torch.randn(3 * C, generator=g) * 0.3).cuda()
+    wp, bp = (torch.randn(C, C, generator=g) / C ** 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda() if use_gamma else None
+    bias = torch.randn(heads, S, S, generator=g).cuda() if use_bias else None
+    ref, dgam, dbias = _attn_reference(x, dy, lnw, lnb, wq, bq, wp, bp, gamma, bias, heads, S)
+    grads = hat_backward.AttnGrads.zeros(C, heads, S, x.device, with_gamma=use_gamma, with_bias=use_bias)
+    dx = hat_backward.attn_block_backward(x, dy, lnw, lnb, wq, bq, wp, bp, gamma, bias, heads, S, grads, operand_dtype=dt)
+    torch.cuda.synchronize()
+    pairs = [("dx", dx, ref[0]), ("d ln_w", grads.ln_w, ref[1]), ("d ln_b", grads.ln_b, ref[2]), ("dWqkv", grads.qkv_w, ref[3]),
+             ("dbqkv", grads.qkv_b, ref[4]), ("dWproj", grads.proj_w, ref[5]), ("dbproj", grads.proj_b, ref[6])]
+    if use_gamma:
+        pairs.append(("dgamma", grads.gamma, dgam))
+    if use_bias:
+        pairs.append(("dbias", grads.bias, dbias))
+    for name, a, b in pairs:
+        assert torch.isfinite(a).all(), name
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert err < tol * scale, f"{name}: max-abs err {err:.3e} vs scale {scale:.3e}"
+    grads2 = hat_backward.AttnGrads.zeros(C, heads, S, x.device, with_gamma=use_gamma, with_bias=use_bias)
+    dx2 = hat_backward.attn_block_backward(x, dy, lnw, lnb, wq, bq, wp, bp, gamma, bias, heads, S, grads2, operand_dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2) and torch.equal(grads.qkv_w, grads2.qkv_w) and torch.equal(grads.proj_w, grads2.proj_w)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 6e-3), (torch.bfloat16, 5e-2)])
+def test_local_hat_block_backward_vs_autograd(dt, tol):
+    """One HAT block without carrier tokens (stage 3 of FasterViT-0: 7 x 7 windows, C = 512, 16 heads): x1 = x + g3 attn(LN(x)), y = x1 + g4 mlp(LN(x1));
+    dx and all 15 parameter gradients against torch.autograd."""
+    nwin, S, C, hid = 12, 49, 512, 2048
+    heads, M = C // 32, nwin * S
+    g = torch.Generator(device="cpu").manual_seed(11)
+    rnd = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).cuda()   # noqa: E731
+    x, dy = rnd(M, C, k=1.3), rnd(M, C)
+    attn = dict(ln_w=(torch.rand(C, generator=g) + 0.5).cuda(), ln_b=rnd(C, k=0.2), qkv_w=rnd(3 * C, C, k=C ** -0.5), qkv_b=rnd(3 * C, k=0.3),
+                proj_w=rnd(C, C, k=C ** -0.5), proj_b=rnd(C, k=0.3), gamma=(torch.rand(C, generator=g) + 0.5).cuda(), bias=rnd(heads, S, S))
+    mlp = dict(ln_w=(torch.rand(C, generator=g) + 0.5).cuda(), ln_b=rnd(C, k=0.2), fc1_w=rnd(hid, C, k=C ** -0.5), fc1_b=rnd(hid, k=0.3),
+               fc2_w=rnd(C, hid, k=hid ** -0.5), fc2_b=rnd(C, k=0.3), gamma=(torch.rand(C, generator=g) + 0.5).cuda())
+    xr = x.clone().requires_grad_(True)
+    A = {k: v.clone().requires_grad_(True) for k, v in attn.items()}
+    Mm = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
+    xn = F.layer_norm(xr, (C,), A["ln_w"], A["ln_b"], 1e-5)
+    qkv = F.linear(xn, A["qkv_w"], A["qkv_b"]).view(nwin, S, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    o = (((qkv[0] @ qkv[1].transpose(-1, -2)) * 32 ** -0.5 + A["bias"]).softmax(-1) @ qkv[2]).transpose(1, 2).reshape(M, C)
+    x1 = xr + A["gamma"] * F.linear(o, A["proj_w"], A["proj_b"])
+    y = x1 + Mm["gamma"] * F.linear(F.gelu(F.linear(F.layer_norm(x1, (C,), Mm["ln_w"], Mm["ln_b"], 1e-5), Mm["fc1_w"], Mm["fc1_b"])), Mm["fc2_w"], Mm["fc2_b"])
+    y.backward(dy)
+    ag, mg = hat_backward.AttnGrads.zeros(C, heads, S, x.device), hat_backward.MlpGrads.zeros(C, hid, x.device)
+    dx = hat_backward.local_block_backward(x, dy, attn, mlp, heads, S, ag, mg, operand_dtype=dt)
+    torch.cuda.synchronize()
+    pairs = [("dx", dx, xr.grad)] + [(f"attn.{k}", getattr(ag, k), A[k].grad) for k in attn] + [(f"mlp.{k}", getattr(mg, k), Mm[k].grad) for k in mlp]
+    for name, a, b in pairs:
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert torch.isfinite(a).all() and err < tol * scale, f"{name}: max-abs err {err:.3e} vs scale {scale:.3e}"
