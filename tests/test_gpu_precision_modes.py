@@ -290,6 +290,46 @@ def test_gemm_256x256_tile(opname, dt, code, M, N, K, epi, pp):
     assert torch.equal(got, got128)   # same K order, same fp32 accumulation chain per output: bitwise the same as the 128 x 128 tile
 
 
+def test_gemm_ping_pong_repeatable_with_other_streams_on_the_chip():
+    """The ping-pong tile's LDS hand-offs are ordered by counted vmcnt + barriers only: the same GEMM, repeated while two other streams keep the CUs
+    busy with different kernels (other LDS-DMA traffic, other timing), must return the same bits every time and match the 128 x 128 tile."""
+    lib = _lib.lib()
+    dt, code = torch.float16, 1
+    g = torch.Generator(device="cpu").manual_seed(99)
+    M, N, K = 9116, 3072, 832
+    A = _padded(torch.randn(M, K, generator=g).to(dt).cuda(), _rup(M, 256), K)
+    W = _padded((torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda(), _rup(N, 256), K)
+    bias = torch.randn(N, generator=g).cuda()
+    A2 = torch.randn(4096, 2048, generator=g).to(dt).cuda()
+    W2 = torch.randn(4096, 2048, generator=g).to(dt).cuda()
+    side = [torch.cuda.Stream() for _ in range(2)]
+
+    def run():
+        out = torch.empty(_rup(M, 256), N, dtype=dt, device="cuda")
+        _lib.check(lib.fvit_gemm_bias_act(code, A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), out.data_ptr(), N, M, N, K, 1, _stream()), "gemm")
+        return out
+
+    try:
+        _lib.tune("gemm_pp", 0)
+        _lib.tune("gemm256_min_tiles", 0)
+        ref = run()[:M].clone()
+        _lib.tune("gemm_pp", 1)
+        _lib.tune("gemm256_min_tiles", 192)
+        torch.cuda.synchronize()
+        for it in range(24):
+            for i, s2 in enumerate(side):
+                with torch.cuda.stream(s2):
+                    o2 = torch.empty(4096, 4096, dtype=dt, device="cuda")
+                    _lib.check(lib.fvit_gemm_bias_act(code, A2.data_ptr(), 2048, W2.data_ptr(), 2048, None, o2.data_ptr(), 4096, 4096 - 128 * i, 4096, 2048, 0,
+                                                      s2.cuda_stream), "side gemm")
+            got = run()[:M]
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), f"iteration {it}: {(got.float() - ref.float()).abs().max().item()}"
+    finally:
+        _lib.tune("gemm_pp", GEMM_PP_DEFAULT)
+        _lib.tune("gemm256_min_tiles", 192)
+
+
 @pytest.mark.parametrize("opname,dt,code", OPS)
 @pytest.mark.parametrize("M,nsplit,terms", [(4214, 2, 1), (70, 2, 1), (12544, 2, 1), (513, 2, 2), (4165, 2, 2)])
 def test_win_mlp_split_hidden(opname, dt, code, M, nsplit, terms):
