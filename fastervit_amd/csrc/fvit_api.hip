@@ -466,8 +466,28 @@ int fvit_hat_stage_forward(const FvitStageDesc* desc, const FvitBlockWeights* bl
     PartitionCall pc = {*in, d.batch, d.C, d.Hp, d.Wp, d.ws, X, L.S, L.ncw, d.hier ? ct_init : nullptr, L.ncw};
     FVIT_TRY(launch_partition(pc, st));
     dbg_rowhash("partition", X, L.Mx, d.C * 4, st);
+    // a non-hierarchical C = 512 stage whose blocks all take the per-window kernels: ONE launch of persistent per-window workgroups (fvit_stage3.hip)
+    bool one_launch = !d.hier && d.weight_terms == 1 && d.depth >= 1 && tune_get("win_stage3", 0) && win_stage3_supported(d.C, d.heads, d.hidden, L.S, d.depth) &&
+                      d.dpad == 32;
+    for (int i = 0; one_launch && i < d.depth; ++i) one_launch = win_fused_ok(d, blocks[i].attn, L.S) && win_mlp_ok(d, blocks[i].mlp, L.Mx);
+    if (one_launch) {
+        AttnBlkCall ab[8];
+        MlpFusedCall mc[8];
+        const int rpi = L.nW * L.S;
+        const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
+        for (int i = 0; i < d.depth; ++i) {
+            const FvitBlockWeights& w = blocks[i];
+            ab[i] = AttnBlkCall{d.operand_dtype, X, rpi, nullptr, 0, nullptr, tables->ln1_add, w.pe_x, w.attn.ln_w, w.attn.ln_b, 1e-5f, rpi,
+                                w.attn.w_qkv_frag, w.attn.b_qkv_heads, w.attn.w_proj_frag, w.attn.b_proj, w.attn.gamma, w.attn.bias, X,
+                                d.batch * L.nW, L.S, d.heads, d.C, scale};
+            mc[i] = MlpFusedCall{d.operand_dtype, X, (int)L.Mx, d.C, d.hidden, w.mlp.ln_w, w.mlp.ln_b, 1e-5f, w.mlp.w_fc1_frag, w.mlp.b_fc1, w.mlp.w_fc2_frag,
+                                 w.mlp.b_fc2, w.mlp.gamma, 1};
+        }
+        FVIT_TRY(launch_win_stage3(ab, mc, d.depth, st));
+        dbg_rowhash("win.stage3", X, L.Mx, d.C * 4, st);
+    }
     bool pre = false;   // does X already include block i's position embedding?
-    for (int i = 0; i < d.depth; ++i) {
+    for (int i = 0; !one_launch && i < d.depth; ++i) {
         NextPe np;
         const bool chain = i + 1 < d.depth && pe_preadd_chain(d, L, blocks[i]) && pe_preadd_chain(d, L, blocks[i + 1]) && blocks[i + 1].pe_x;
         if (chain) { np.add = blocks[i + 1].pe_x; np.add_idx = tables->ln1_add; np.rows_per_image = L.nW * L.S; }

@@ -262,6 +262,10 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream);
 // same contract for C = 512 / 16 heads, one 49..64-token window per workgroup, waves split heads / output channels (fvit_winblk.hip)
 bool winblk_supported(int C, int heads, int S);
 int launch_winblk(const AttnBlkCall& c, hipStream_t stream);
+// a whole non-hierarchical C = 512 stage (depth x [winblk, winmlp]) as one launch of persistent per-window workgroups (fvit_stage3.hip);
+// attn[b].x_out == mlp[b].x == the stage's row buffer, attn[b].nwin * S == mlp[b].M
+bool win_stage3_supported(int C, int heads, int hidden, int S, int depth);
+int launch_win_stage3(const AttnBlkCall* attn, const MlpFusedCall* mlp, int depth, hipStream_t stream);
 
 struct AttnCall {
     int dtype;

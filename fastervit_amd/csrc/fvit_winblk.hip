@@ -61,8 +61,13 @@ struct WinBlkParams {
 // ticket; the last arriver acquires, adds the partials in split order and applies the residual; nobody waits).
 // WT = 2 (r03): two-term weights (hi + lo 16-bit images, the lo image after the hi image in the fragment arrays): the qkv and proj k loops run
 // twice over the same activation fragments, once per weight image -- same registers and LDS, twice the weight stream.
+// LDS bytes of a workgroup: XN (4 row blocks x C / 32 k steps), O^T (4 x heads of this workgroup), the qkv bias copy
+template <int CC, int NSPLIT>
+constexpr int winblk_lds_bytes() { return 4 * (CC / 32) * 1024 + 4 * (CC / 32 / NSPLIT) * 1024 + (CC / 32) * 96 * 4; }
+
+// The kernel body as a device function (blk = blockIdx.x of a stand-alone launch): fvit_stage3.hip runs it as one phase of a persistent workgroup.
 template <typename T, int CC, int NWV, int NSPLIT = 1, int WT = 1>
-__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinBlkParams p) {
+__device__ __forceinline__ void winblk_body(const WinBlkParams& p, char* const smem, const int blk) {
     typedef typename Op16<T>::v8 v8;
     constexpr int C = CC, KK = C / 32, CB = C / 16, HEADS = C / 32, NW = NWV, NRB = 4, SP = 64;
     constexpr int HW = HEADS / NSPLIT;             // heads of this workgroup
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
     constexpr int OFF_O = NRB * KK * 1024;         // XN: 64 KiB, then O: 64 KiB (a separate region: each head's O^T fragments leave the
     constexpr int OFF_BQ = OFF_O + NRB * HW * 1024;      // registers at once -- held across the next head they spilled, and a scratch reload
                                                          // inside the loop queues behind the ring's prefetches and drains it)
-    __shared__ __attribute__((aligned(16))) char smem[OFF_BQ + HEADS * 96 * 4];
+    static_assert(OFF_BQ + HEADS * 96 * 4 == winblk_lds_bytes<CC, NSPLIT>(), "LDS layout");
     float* bqs = (float*)(smem + OFF_BQ);
 
     const int tid = threadIdx.x;
@@ -83,9 +88,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, s = lane & 15;
     const int lane16 = lane * 16;
-    int win = blockIdx.x, sp = 0;
+    int win = blk, sp = 0;
     if constexpr (NSPLIT > 1) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;   // siblings: block ids that differ by a multiple of 8 (same XCD, speed only)
+        const int xcd = blk & 7, j = blk >> 3;   // siblings: block ids that differ by a multiple of 8 (same XCD, speed only)
         win = (j / NSPLIT) * 8 + xcd;
         sp = j % NSPLIT;
         if (win >= p.nwin) return;
@@ -393,8 +398,25 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinB
     }
 }
 
+template <typename T, int CC, int NWV, int NSPLIT = 1, int WT = 1>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winblk_kernel(WinBlkParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[winblk_lds_bytes<CC, NSPLIT>()];
+    winblk_body<T, CC, NWV, NSPLIT, WT>(p, smem, blockIdx.x);
+}
+
+inline WinBlkParams make_winblk_params(const AttnBlkCall& c) {
+    WinBlkParams p;
+    p.srcA = c.srcA; p.srcB = c.srcB; p.src_idx = c.src_idx; p.add_idx = c.add_idx; p.add = c.add; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.eps = c.eps;
+    p.rowsA = c.rowsA; p.rowsB = c.rowsB; p.rows_per_image = c.rows_per_image > 0 ? c.rows_per_image : 1;
+    p.wqkv_f = c.wqkv_f; p.bqkv = c.bqkv; p.wproj_f = c.wproj_f; p.bproj = c.bproj; p.gamma = c.gamma; p.bias = c.bias; p.x_out = c.x_out;
+    p.nwin = c.nwin; p.S = c.S; p.scale = c.scale;
+    p.slab = c.slab; p.counters = c.counters;
+    return p;
+}
+
 }  // namespace
 
+#ifndef FVIT_BODIES_ONLY
 bool winblk_supported(int C, int heads, int S) { return ((C == 512 && heads == 16) || (C == 256 && heads == 8)) && S > 48 && S <= 64; }
 
 int launch_winblk(const AttnBlkCall& c, hipStream_t stream) {
@@ -403,12 +425,7 @@ int launch_winblk(const AttnBlkCall& c, hipStream_t stream) {
         return FVIT_EINVAL;
     }
     if (ablate_skip(4)) return FVIT_OK;
-    WinBlkParams p;
-    p.srcA = c.srcA; p.srcB = c.srcB; p.src_idx = c.src_idx; p.add_idx = c.add_idx; p.add = c.add; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.eps = c.eps;
-    p.rowsA = c.rowsA; p.rowsB = c.rowsB; p.rows_per_image = c.rows_per_image > 0 ? c.rows_per_image : 1;
-    p.wqkv_f = c.wqkv_f; p.bqkv = c.bqkv; p.wproj_f = c.wproj_f; p.bproj = c.bproj; p.gamma = c.gamma; p.bias = c.bias; p.x_out = c.x_out;
-    p.nwin = c.nwin; p.S = c.S; p.scale = c.scale;
-    p.slab = c.slab; p.counters = c.counters;
+    const WinBlkParams p = make_winblk_params(c);
     if (c.terms != 1 && !(c.terms == 2 && c.C == 512)) {
         set_error("win_block: weight terms %d with C = %d (two-term weights: C = 512 only)", c.terms, c.C);
         return FVIT_EINVAL;
@@ -436,5 +453,7 @@ int launch_winblk(const AttnBlkCall& c, hipStream_t stream) {
     }
     return check_launch("winblk_kernel");
 }
+
+#endif  // FVIT_BODIES_ONLY
 
 }  // namespace fvit

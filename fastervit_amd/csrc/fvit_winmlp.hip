@@ -68,8 +68,17 @@ __device__ __forceinline__ void stamp(const WinMlpParams& p, int wave, int lane,
 // split 0, 1, .. (bitwise repeatable whoever arrives last), applies bias / gamma / residual and resets the counter.  Nobody waits for
 // anybody (no spin: placement- and residency-independent).  Sibling workgroups get block ids that differ by a multiple of 8 (same XCD
 // under the observed round-robin dispatch): their partials and the rows they all read stay in one L2 (speed only, never correctness).
+// LDS bytes of a workgroup: XN (NRB x C / 32 KiB), H (single or double buffered, see HBUF below), the fc1 bias
+template <int CC, int HID, int NRB, int NWV>
+constexpr int winmlp_lds_bytes() {
+    constexpr int hbuf = (NRB * (CC / 32) + 2 * NWV * NRB) * 1024 + HID * 4 <= (NWV == 8 ? 150 : 72) * 1024 ? 2 : 1;
+    return NRB * (CC / 32) * 1024 + hbuf * NWV * NRB * 1024 + HID * 4;
+}
+
+// The kernel body as a device function (blk = blockIdx.x of a stand-alone launch): fvit_stage3.hip runs it as one phase of a persistent workgroup
+// (the timeline stamps index by blockIdx.x: stand-alone launches only).
 template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1, int NSPLIT = 1, bool TS = false>
-__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinMlpParams p) {
+__device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const smem, const int blk) {
     typedef typename Op16<T>::v8 v8;
     constexpr int C = CC, KK = C / 32, CB = C / 16, NW = NWV;
     constexpr int CBW = CB / NW;                   // output channel blocks per wave (4 / 2)
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
     constexpr int HBUF = (NRB * KK + 2 * NW * NRB) * 1024 + HID * 4 <= (NW == 8 ? 150 : 72) * 1024 ? 2 : 1;   // H double-buffered when it fits
     constexpr int OFF_H = NRB * KK * 1024;         // XN: 64 KiB; H: HBUF x NW x NRB KiB; fc1 bias
     constexpr int OFF_B1 = OFF_H + HBUF * NW * NRB * 1024;
-    __shared__ __attribute__((aligned(16))) char smem[OFF_B1 + HID * 4];
+    static_assert(OFF_B1 + HID * 4 == winmlp_lds_bytes<CC, HID, NRB, NWV>(), "LDS layout");
     float* b1s = (float*)(smem + OFF_B1);
 
     const int tid = threadIdx.x;
@@ -95,9 +104,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, s = lane & 15;
     const int lane16 = lane * 16;
-    int rg = blockIdx.x, sp = 0;
+    int rg = blk, sp = 0;
     if constexpr (NSPLIT > 1) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int xcd = blk & 7, j = blk >> 3;
         rg = (j / NSPLIT) * 8 + xcd;
         sp = j % NSPLIT;
         if (rg * (16 * NRB) >= p.M) return;   // the whole sibling group is out of range (grid padded to 8 x NSPLIT)
@@ -350,8 +359,22 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinM
     }
 }
 
+template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1, int NSPLIT = 1, bool TS = false>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinMlpParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[winmlp_lds_bytes<CC, HID, NRB, NWV>()];
+    winmlp_body<T, CC, HID, NRB, DEPTH, NWV, SP, NSPLIT, TS>(p, smem, blockIdx.x);
+}
+
+inline WinMlpParams make_winmlp_params(const MlpFusedCall& c) {
+    WinMlpParams p;
+    p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma; p.eps = c.eps; p.M = c.M;
+    p.slab = c.slab; p.counters = c.counters; p.ts = (unsigned long long*)c.ts;
+    return p;
+}
+
 }  // namespace
 
+#ifndef FVIT_BODIES_ONLY
 size_t winmlp_split_slab_bytes(int64_t M, int C, int nsplit) { return (size_t)((M + 63) / 64) * (size_t)nsplit * 64 * C * 4; }
 
 bool winmlp_supported(int C, int hidden) { return (C == 512 && hidden == 2048) || (C == 256 && hidden == 1024); }
@@ -362,9 +385,7 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
         return FVIT_EINVAL;
     }
     if (ablate_skip(c.C == 512 ? 2 : 1)) return FVIT_OK;
-    WinMlpParams p;
-    p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma; p.eps = c.eps; p.M = c.M;
-    p.slab = c.slab; p.counters = c.counters; p.ts = (unsigned long long*)c.ts;
+    const WinMlpParams p = make_winmlp_params(c);
     // (the 4-way split measured in profiles/r03_stage3_split_over_sibling_workgroups_ab.log -- 288 workgroups, two rounds, 90 us -- is no longer
     // instantiated: git history, commit "split-hidden form of the C = 512 MLP kernel")
     const int nsplit = (c.C == 512 && c.slab && c.counters && c.nsplit == 2) ? 2 : 1;
@@ -421,5 +442,7 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
 #undef FVIT_WINMLP
     return check_launch("winmlp_kernel");
 }
+
+#endif  // FVIT_BODIES_ONLY
 
 }  // namespace fvit

@@ -133,3 +133,26 @@ def test_order_stagger_knobs_keep_the_result(knobs):
     finally:
         for k in knobs:
             _lib.tune(k, _DEFAULTS[k])
+
+
+@pytest.mark.parametrize("batch", [4, 33, 86])
+def test_stage3_as_one_launch_is_bitwise_the_two_kernel_path(batch):
+    """fvit_tune "win_stage3" (opt-in, fvit_stage3.hip): stage 3 of FasterViT-0 as ONE launch of persistent per-window workgroups that run the window-attention
+    and MLP kernel bodies alternately for all five blocks.  Same arithmetic per row: bitwise the stand-alone kernels' result -- including at 86 windows, where
+    the first version (no L1 invalidate between the phases of a workgroup) read stale rows."""
+    model = _model("faster_vit_0_224")
+    lvl = model.levels[3]
+    g = torch.Generator(device="cpu").manual_seed(batch)
+    x = torch.randn(batch, 512, 7, 7, generator=g).cuda()
+    try:
+        with torch.no_grad():
+            _lib.tune("win_stage3", 0)
+            ref = hat_runtime.stage_forward(lvl, x.clone()).clone()
+            _lib.tune("win_stage3", 1)
+            outs = [hat_runtime.stage_forward(lvl, x.clone()).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+    finally:
+        _lib.tune("win_stage3", 0)
+    assert torch.isfinite(ref).all()
+    for o in outs:
+        assert torch.equal(o, ref)
