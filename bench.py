@@ -22,7 +22,7 @@ timings into one whole-job figure.  Rank 0 prints ONE JSON line:
   parity / parity_<op>    logits max-abs error vs the fp32 CPU oracle, 8 images from EACH stream shard, on synthetic weights of the
                           'init' family of tests/synth.py (reference init + gamma ~ U(0.5, 1.5), BN statistics, biases: with the
                           reference's plain init FasterViT-4's layer-scale gamma = 1e-5 would hide the HAT stages).  The timed
-                          operand type first; every other operand mode (bf16, and the split-operand bf16x2 / bf16x3 routes) is
+                          operand type first; every other operand mode (bf16, and the two-term-weight modes f16x2 / bf16x2) is
                           reported beside it with its own error AND its own images/s
   secondary               BASELINE configs 3 and 5 (faster_vit_4_224 bs 128; faster_vit_4_any_res 576x960 bs 8): a few timed steps
                           each + parity on 2 images, same synthetic weights (N = 1 only)
@@ -490,7 +490,7 @@ def main():
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent shards, no data-path collective)",
                    "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
                    "hat_operands": args.operand,
-                   "conv_side": (f"deploy plan: BN folded, {args.conv_dtype} channels_last, HIP conv3x3 (halo-tiled / implicit-GEMM) + fused stem + LayerNorm2d kernels"
+                   "conv_side": (f"deploy plan: BN folded, {args.conv_dtype} channels_last, HIP conv3x3 (halo-tiled / row-band / implicit-GEMM) + fused stem + LayerNorm2d kernels"
                                  if cfg.deploy else (f"model(x) under autocast {args.conv_dtype}: automatic deploy plan" if args.mode == "auto"
                                                      else f"PyTorch-ROCm nn.Module forward, channels_last, autocast {args.conv_dtype}")),
                    "launch": cfg.launch_desc()},
