@@ -2,7 +2,7 @@
 
     y = x + gamma * fc2(GELU(fc1(LayerNorm(x))))            Mlp.forward FV:398-407 inside HAT.forward FV:691 / AR:697        mlp_block_backward
     y = x + gamma * proj(attention(qkv(LayerNorm(x))))      WindowAttention.forward FV:557-568 inside HAT.forward FV:690      attn_block_backward
-                                                            (rows already in window order: the carrier-token gathers have no backward here)
+    a whole HAT block, without (stage 3) and WITH carrier tokens (stage 2: FV:662-701 / AR:668-707)       local_block_backward / hier_block_backward
 
 The reference differentiates this with autograd (train.py:820-951, the model wrapped in DDP at train.py:542-551).  Here the backward of ONE
 sub-block is a fixed kernel sequence behind the C ABI, checked against torch.autograd (tests/test_gpu_backward.py):
@@ -285,3 +285,94 @@ def local_block_backward(x: torch.Tensor, dy: torch.Tensor, attn: dict, mlp: dic
                              operand_dtype)
     return attn_block_backward(x, dx1, attn["ln_w"], attn["ln_b"], attn["qkv_w"], attn.get("qkv_b"), attn["proj_w"], attn["proj_b"], attn.get("gamma"),
                                attn.get("bias"), heads, S, attn_grads, eps, None, operand_dtype)
+
+
+def mlp_block_forward(x: torch.Tensor, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, gamma, eps: float = 1e-5, operand_dtype=torch.float16) -> torch.Tensor:
+    """y = x + gamma * fc2(GELU(fc1(LayerNorm(x)))) through the unit kernels of the forward path (activation recompute for the block-level backwards)."""
+    if not x.is_cuda:
+        raise RuntimeError("mlp_block_forward runs only on a HIP device (libfvit_hip.so kernels); there is no CPU fallback")
+    M, C_ = x.shape
+    hid = fc1_w.shape[0]
+    dev, dt, code = x.device, operand_dtype, _CODE[operand_dtype]
+    lib = _lib.lib()
+    Mp = _rup(M, 128)
+    f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731
+    W1, W2 = _pad_rows(f32(fc1_w), dt), _pad_rows(f32(fc2_w), dt)
+    xn, h = torch.zeros(Mp, C_, dtype=dt, device=dev), torch.zeros(Mp, hid, dtype=dt, device=dev)
+    y = x.clone()
+    lw, lb, b1, b2 = f32(ln_w), f32(ln_b), f32(fc1_b), f32(fc2_b)
+    g = f32(gamma) if gamma is not None else None
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        ck = _lib.check
+        ck(lib.fvit_gather_layernorm(code, x.data_ptr(), M, None, 0, None, None, None, None, xn.data_ptr(), C_, lw.data_ptr(), lb.data_ptr(),
+                                     C.c_float(eps), M, M, C_, st), "layernorm")
+        ck(lib.fvit_gemm_bias_act(code, xn.data_ptr(), C_, W1.data_ptr(), C_, b1.data_ptr(), h.data_ptr(), hid, M, hid, C_, 1, st), "fc1 + GELU")
+        ck(lib.fvit_gemm_residual(code, h.data_ptr(), hid, W2.data_ptr(), hid, b2.data_ptr(), None if g is None else g.data_ptr(), y.data_ptr(), C_,
+                                  M, C_, hid, st), "fc2")
+    return y
+
+
+def _carrier_permutations(sr0: int, sr1: int, cw: int, device):
+    """Index form of the reference's carrier-token reshuffles for G = cw^2 * sr0 * sr1 tokens per image (the view / permute chains of ct_dewindow
+    AR:97-102 and ct_window AR:105-110 applied to an arange; the two are inverses only on square grids, which is reproduced):
+    dewindowed[:, r] = ct[:, dew[r]];  windowed[:, p] = ct2[:, win[p]]."""
+    G = cw * cw * sr0 * sr1
+    ar = torch.arange(G, device=device)
+    dew = ar.view(sr0, sr1, cw, cw).permute(0, 2, 1, 3).reshape(G)
+    win = ar.view(sr1, cw, sr0, cw).permute(0, 2, 1, 3).reshape(G)
+    return dew, win
+
+
+def hier_block_backward(x: torch.Tensor, ct: torch.Tensor, dx_out: torch.Tensor, dct_out: torch.Tensor, hat_attn: dict, hat_mlp: dict, attn: dict, mlp: dict,
+                        heads: int, ws: int, cw: int, sr, pe_x: Optional[torch.Tensor], pe_ct: Optional[torch.Tensor], grads: dict, eps: float = 1e-5,
+                        operand_dtype=torch.float16):
+    """Backward of one HAT block WITH carrier tokens (HAT.forward FV:662-701 / AR:668-707, no last-block propagation):
+         x (B nW, ws^2, C), ct (B, G, C)  ->  x_out, ct_out  with the carrier branch (ct_dewindow, hat_pos_embed, hat_attn, hat_mlp, ct_window), the
+         concatenation [carrier | window] per window, the window attention and MLP sub-blocks, and the final split.
+    ``hat_attn`` / ``attn`` / ``hat_mlp`` / ``mlp``: parameter dicts as in ``local_block_backward`` (bias = the folded relative-position table of that attention);
+    ``pe_x`` (ws^2, C) / ``pe_ct`` (G, C or None): the constant-folded 1-D position embeddings (PosEmbMLPSwinv1D, input independent).
+    ``grads`` = dict(hat_attn=AttnGrads, hat_mlp=MlpGrads, attn=AttnGrads, mlp=MlpGrads).  Returns (dx, dct).
+    The sub-block backwards run on the kernels; the carrier reshuffles and the concatenation / split are row permutations applied with torch indexing."""
+    if not x.is_cuda:
+        raise RuntimeError("hier_block_backward runs only on a HIP device (libfvit_hip.so kernels); there is no CPU fallback")
+    Bw, nloc, C_ = x.shape
+    B, G, _ = ct.shape
+    sr0, sr1 = int(sr[0]), int(sr[1])
+    nW, ncw = sr0 * sr1, cw * cw
+    if nloc != ws * ws or Bw != B * nW or G != ncw * nW:
+        raise RuntimeError(f"hier_block_backward: x {tuple(x.shape)} / ct {tuple(ct.shape)} do not match ws={ws} cw={cw} sr={sr}")
+    S = ncw + nloc
+    dev = x.device
+    dew, win = _carrier_permutations(sr0, sr1, cw, dev)
+    od = operand_dtype
+    # ---- forward recompute (kernels) ----
+    x0 = (x + pe_x.to(dev)) if pe_x is not None else x
+    ct0 = ct[:, dew]
+    if pe_ct is not None:
+        ct0 = ct0 + pe_ct.to(dev)
+    ct0 = ct0.reshape(B * G, C_).contiguous()
+    ha, hm = hat_attn, hat_mlp
+    ct1 = attn_block_forward(ct0, ha["ln_w"], ha["ln_b"], ha["qkv_w"], ha.get("qkv_b"), ha["proj_w"], ha["proj_b"], ha.get("gamma"), ha.get("bias"), heads, G, eps,
+                             None, od)
+    ct2 = mlp_block_forward(ct1, hm["ln_w"], hm["ln_b"], hm["fc1_w"], hm["fc1_b"], hm["fc2_w"], hm["fc2_b"], hm.get("gamma"), eps, od)
+    ctw = ct2.view(B, G, C_)[:, win].reshape(Bw, ncw, C_)
+    xin = torch.cat((ctw, x0), dim=1).reshape(Bw * S, C_).contiguous()
+    y1 = attn_block_forward(xin, attn["ln_w"], attn["ln_b"], attn["qkv_w"], attn.get("qkv_b"), attn["proj_w"], attn["proj_b"], attn.get("gamma"), attn.get("bias"),
+                            heads, S, eps, None, od)
+    # ---- backward ----
+    dy2 = torch.cat((dct_out.reshape(Bw, ncw, C_), dx_out), dim=1).reshape(Bw * S, C_).contiguous()
+    dy1 = mlp_block_backward(y1, dy2, mlp["ln_w"], mlp["ln_b"], mlp["fc1_w"], mlp["fc1_b"], mlp["fc2_w"], mlp["fc2_b"], mlp.get("gamma"), grads["mlp"], eps, od)
+    dxin = attn_block_backward(xin, dy1, attn["ln_w"], attn["ln_b"], attn["qkv_w"], attn.get("qkv_b"), attn["proj_w"], attn["proj_b"], attn.get("gamma"),
+                               attn.get("bias"), heads, S, grads["attn"], eps, None, od).view(Bw, S, C_)
+    dx = dxin[:, ncw:].contiguous()
+    dctw = dxin[:, :ncw].reshape(B, G, C_)
+    dct2 = torch.empty_like(dctw)
+    dct2[:, win] = dctw                                   # adjoint of windowed[:, p] = ct2[:, win[p]]
+    dct2 = dct2.reshape(B * G, C_).contiguous()
+    dct1 = mlp_block_backward(ct1, dct2, hm["ln_w"], hm["ln_b"], hm["fc1_w"], hm["fc1_b"], hm["fc2_w"], hm["fc2_b"], hm.get("gamma"), grads["hat_mlp"], eps, od)
+    dct0 = attn_block_backward(ct0, dct1, ha["ln_w"], ha["ln_b"], ha["qkv_w"], ha.get("qkv_b"), ha["proj_w"], ha["proj_b"], ha.get("gamma"), ha.get("bias"), heads, G,
+                               grads["hat_attn"], eps, None, od).view(B, G, C_)
+    dct = torch.empty_like(dct0)
+    dct[:, dew] = dct0                                    # adjoint of dewindowed[:, r] = ct[:, dew[r]]
+    return dx, dct

@@ -140,3 +140,65 @@ def test_local_hat_block_backward_vs_autograd(dt, tol):
     for name, a, b in pairs:
         err, scale = (a - b).abs().max().item(), b.abs().max().item()
         assert torch.isfinite(a).all() and err < tol * scale, f"{name}: max-abs err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("sr,dt,tol", [((2, 2), torch.float16, 8e-3), ((2, 2), torch.bfloat16, 6e-2), ((1, 2), torch.float16, 8e-3)])
+def test_hier_hat_block_backward_vs_autograd(sr, dt, tol):
+    """One HAT block WITH carrier tokens (stage 2 of FasterViT-0: 7 x 7 windows, 2 x 2 carrier tokens per window, C = 256; also a non-square 1 x 2 window
+    grid, where ct_window is not the inverse of ct_dewindow): dx, dct and the parameter gradients of all four sub-blocks against torch.autograd on a
+    functional restatement that uses the oracle's carrier reshuffles (oracle.hat_reference.ct_dewindow / ct_window)."""
+    from oracle import hat_reference as hr
+    B, ws, cw, C, hid = 6, 7, 2, 256, 1024
+    heads = C // 32
+    nW, ncw, nloc = sr[0] * sr[1], cw * cw, ws * ws
+    G, S, Bw = ncw * nW, ncw + nloc, B * nW
+    g = torch.Generator(device="cpu").manual_seed(sr[0] * 10 + sr[1])
+    rnd = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).cuda()   # noqa: E731
+    pos = lambda n: (torch.rand(n, generator=g) + 0.5).cuda()   # noqa: E731
+
+    def attn_params(Sa):
+        return dict(ln_w=pos(C), ln_b=rnd(C, k=0.2), qkv_w=rnd(3 * C, C, k=C ** -0.5), qkv_b=rnd(3 * C, k=0.3), proj_w=rnd(C, C, k=C ** -0.5), proj_b=rnd(C, k=0.3),
+                    gamma=pos(C), bias=rnd(heads, Sa, Sa))
+
+    def mlp_params():
+        return dict(ln_w=pos(C), ln_b=rnd(C, k=0.2), fc1_w=rnd(hid, C, k=C ** -0.5), fc1_b=rnd(hid, k=0.3), fc2_w=rnd(C, hid, k=hid ** -0.5), fc2_b=rnd(C, k=0.3),
+                    gamma=pos(C))
+
+    P = dict(hat_attn=attn_params(G), hat_mlp=mlp_params(), attn=attn_params(S), mlp=mlp_params())
+    x, ct = rnd(Bw, nloc, C, k=1.3), rnd(B, G, C, k=1.3)
+    dx_out, dct_out = rnd(Bw, nloc, C), rnd(B, G, C)
+    pe_x, pe_ct = rnd(nloc, C, k=0.5), (rnd(G, C, k=0.5) if sr[0] == sr[1] else None)
+
+    # ---- reference: autograd over the functional form (AR:668-707) ----
+    L = {k: {n: t.clone().requires_grad_(True) for n, t in d.items()} for k, d in P.items()}
+    xr, ctr = x.clone().requires_grad_(True), ct.clone().requires_grad_(True)
+
+    def attn_f(t, p, Sa):
+        n = t.shape[0] // Sa
+        q = F.linear(F.layer_norm(t, (C,), p["ln_w"], p["ln_b"], 1e-5), p["qkv_w"], p["qkv_b"]).view(n, Sa, 3, heads, 32).permute(2, 0, 3, 1, 4)
+        o = (((q[0] @ q[1].transpose(-1, -2)) * 32 ** -0.5 + p["bias"]).softmax(-1) @ q[2]).transpose(1, 2).reshape(n * Sa, C)
+        return t + p["gamma"] * F.linear(o, p["proj_w"], p["proj_b"])
+
+    def mlp_f(t, p):
+        return t + p["gamma"] * F.linear(F.gelu(F.linear(F.layer_norm(t, (C,), p["ln_w"], p["ln_b"], 1e-5), p["fc1_w"], p["fc1_b"])), p["fc2_w"], p["fc2_b"])
+
+    c0 = hr.ct_dewindow(ctr, cw * sr[0], cw * sr[1], cw)
+    if pe_ct is not None:
+        c0 = c0 + pe_ct
+    c2 = mlp_f(attn_f(c0.reshape(B * G, C), L["hat_attn"], G), L["hat_mlp"]).view(B, G, C)
+    cwn = hr.ct_window(c2, cw * sr[0], cw * sr[1], cw).reshape(Bw, -1, C)
+    xin = torch.cat((cwn, xr + pe_x), dim=1).reshape(Bw * S, C)
+    y2 = mlp_f(attn_f(xin, L["attn"], S), L["mlp"]).view(Bw, S, C)
+    ((y2[:, ncw:] * dx_out).sum() + (y2[:, :ncw].reshape(B, G, C) * dct_out).sum()).backward()
+
+    grads = dict(hat_attn=hat_backward.AttnGrads.zeros(C, heads, G, x.device), hat_mlp=hat_backward.MlpGrads.zeros(C, hid, x.device),
+                 attn=hat_backward.AttnGrads.zeros(C, heads, S, x.device), mlp=hat_backward.MlpGrads.zeros(C, hid, x.device))
+    dx, dct = hat_backward.hier_block_backward(x, ct, dx_out, dct_out, P["hat_attn"], P["hat_mlp"], P["attn"], P["mlp"], heads, ws, cw, sr, pe_x, pe_ct, grads,
+                                               operand_dtype=dt)
+    torch.cuda.synchronize()
+    pairs = [("dx", dx, xr.grad), ("dct", dct, ctr.grad)]
+    for k in P:
+        pairs += [(f"{k}.{n}", getattr(grads[k], n), L[k][n].grad) for n in P[k]]
+    for name, a, b in pairs:
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert torch.isfinite(a).all() and err < tol * scale, f"{name}: max-abs err {err:.3e} vs scale {scale:.3e}"
