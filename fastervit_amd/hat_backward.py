@@ -376,3 +376,83 @@ def hier_block_backward(x: torch.Tensor, ct: torch.Tensor, dx_out: torch.Tensor,
     dct = torch.empty_like(dct0)
     dct[:, dew] = dct0                                    # adjoint of dewindowed[:, r] = ct[:, dew[r]]
     return dx, dct
+
+
+def _table_with_grad(mod, *args):
+    """The module's folded-table function (PosEmbMLPSwinv1D.table / PosEmbMLPSwinv2D.table: inference code under @torch.no_grad) run WITH autograd, so
+    that a table gradient can continue into the small MLP behind it."""
+    fn = type(mod).table
+    fn = getattr(fn, "__wrapped__", fn)
+    with torch.enable_grad():
+        return fn(mod, *args)
+
+
+def _acc_grad(param, g: torch.Tensor) -> None:
+    if isinstance(param, torch.nn.Parameter) and param.requires_grad:
+        g = g.to(param.dtype).reshape(param.shape)
+        param.grad = g.clone() if param.grad is None else param.grad + g
+
+
+def local_stage_backward(layer, x: torch.Tensor, dy: torch.Tensor, operand_dtype=torch.float16) -> torch.Tensor:
+    """Backward of the transformer branch of a FasterViTLayer WITHOUT carrier tokens (FasterViTLayer.forward FV:832-841 with only-local HAT blocks: stage 3
+    of FasterViT-0) -- window_partition, depth x HAT block, window_reverse -- for the module's own parameters:
+
+      x, dy: (B, C, H, W) fp32 maps (H, W multiples of the window size);  returns dx and ADDS every parameter gradient of ``layer.blocks`` into ``.grad``
+      (norm1 / norm2, attn.qkv / attn.proj, mlp.fc1 / fc2, gamma3 / gamma4 when they are parameters, and -- through the modules' differentiable ``table()``
+      functions on the host -- the cpb_mlp of the relative-position bias and of the 1-D position embedding, from the table gradients the kernels return).
+
+    Forward activations are recomputed block by block with the unit kernels (one fp32 row checkpoint per block boundary); the block backwards are
+    ``local_block_backward``.  The downsample conv of the layer is not part of this path."""
+    if not x.is_cuda:
+        raise RuntimeError("local_stage_backward runs only on a HIP device (libfvit_hip.so kernels); there is no CPU fallback")
+    B, C_, H, W = x.shape
+    blocks = list(layer.blocks)
+    if not blocks or any(b.do_sr_hat for b in blocks):
+        raise RuntimeError("local_stage_backward: the stage must consist of HAT blocks without carrier tokens")
+    ws = blocks[0].window_size
+    if H % ws or W % ws:
+        raise RuntimeError(f"local_stage_backward: map {H}x{W} is not a multiple of the window size {ws} (padded stages are not covered)")
+    heads, S = blocks[0].attn.num_heads, ws * ws
+    nh, nw = H // ws, W // ws
+
+    def partition(t):   # (B, C, H, W) -> (B nW S, C) rows in window order (window_partition FV:83-87)
+        return t.view(B, C_, nh, ws, nw, ws).permute(0, 2, 4, 3, 5, 1).reshape(B * nh * nw * S, C_).contiguous()
+
+    def reverse(r):     # rows -> (B, C, H, W) (window_reverse FV:90-93); the two are each other's adjoint on exact tilings
+        return r.view(B, nh, nw, ws, ws, C_).permute(0, 5, 1, 3, 2, 4).reshape(B, C_, H, W).contiguous()
+
+    def params(blk):
+        bias_t = _table_with_grad(blk.attn.pos_emb_funct, S)   # (heads, S, S), differentiable w.r.t. cpb_mlp
+        pe_t = _table_with_grad(blk.pos_embed)                 # (S, C)
+        a = dict(ln_w=blk.norm1.weight, ln_b=blk.norm1.bias, qkv_w=blk.attn.qkv.weight, qkv_b=blk.attn.qkv.bias, proj_w=blk.attn.proj.weight,
+                 proj_b=blk.attn.proj.bias, gamma=blk.gamma3 if isinstance(blk.gamma3, torch.Tensor) else None, bias=bias_t.detach())
+        m = dict(ln_w=blk.norm2.weight, ln_b=blk.norm2.bias, fc1_w=blk.mlp.fc1.weight, fc1_b=blk.mlp.fc1.bias, fc2_w=blk.mlp.fc2.weight, fc2_b=blk.mlp.fc2.bias,
+                 gamma=blk.gamma4 if isinstance(blk.gamma4, torch.Tensor) else None)
+        return a, m, bias_t, pe_t
+
+    # ---- forward: checkpoints of every block's input rows (position embedding already added) ----
+    rows = partition(x.float())
+    ins, ps = [], []
+    for blk in blocks:
+        a, m, bias_t, pe_t = params(blk)
+        xin = (rows.view(-1, S, C_) + pe_t.detach().to(rows.dtype)).reshape(-1, C_).contiguous()
+        ins.append(xin)
+        ps.append((a, m, bias_t, pe_t))
+        x1 = attn_block_forward(xin, a["ln_w"], a["ln_b"], a["qkv_w"], a["qkv_b"], a["proj_w"], a["proj_b"], a["gamma"], a["bias"], heads, S, 1e-5,
+                                blk.attn.scale if hasattr(blk.attn, "scale") else None, operand_dtype)
+        rows = mlp_block_forward(x1, m["ln_w"], m["ln_b"], m["fc1_w"], m["fc1_b"], m["fc2_w"], m["fc2_b"], m["gamma"], 1e-5, operand_dtype)
+    # ---- backward ----
+    d = partition(dy.float())
+    for blk, xin, (a, m, bias_t, pe_t) in zip(reversed(blocks), reversed(ins), reversed(ps)):
+        ag = AttnGrads.zeros(C_, heads, S, x.device, with_gamma=a["gamma"] is not None)
+        mg = MlpGrads.zeros(C_, m["fc1_w"].shape[0], x.device, with_gamma=m["gamma"] is not None)
+        d = local_block_backward(xin, d, a, m, heads, S, ag, mg, 1e-5, operand_dtype)
+        for prm, g in ((blk.norm1.weight, ag.ln_w), (blk.norm1.bias, ag.ln_b), (blk.attn.qkv.weight, ag.qkv_w), (blk.attn.qkv.bias, ag.qkv_b),
+                       (blk.attn.proj.weight, ag.proj_w), (blk.attn.proj.bias, ag.proj_b), (blk.gamma3, ag.gamma), (blk.norm2.weight, mg.ln_w),
+                       (blk.norm2.bias, mg.ln_b), (blk.mlp.fc1.weight, mg.fc1_w), (blk.mlp.fc1.bias, mg.fc1_b), (blk.mlp.fc2.weight, mg.fc2_w),
+                       (blk.mlp.fc2.bias, mg.fc2_b), (blk.gamma4, mg.gamma)):
+            if g is not None:
+                _acc_grad(prm, g)
+        # the folded tables are functions of small MLPs: their gradients continue on the host through the modules' own table() code
+        torch.autograd.backward([bias_t, pe_t], [ag.bias.to(bias_t.dtype), d.view(-1, S, C_).sum(0).to(pe_t.dtype)])
+    return reverse(d)

@@ -202,3 +202,45 @@ def test_hier_hat_block_backward_vs_autograd(sr, dt, tol):
     for name, a, b in pairs:
         err, scale = (a - b).abs().max().item(), b.abs().max().item()
         assert torch.isfinite(a).all() and err < tol * scale, f"{name}: max-abs err {err:.3e} vs scale {scale:.3e}"
+
+
+def test_stage3_backward_of_the_model_vs_oracle_autograd():
+    """fastervit_amd.hat_backward.local_stage_backward on the REAL stage 3 of faster_vit_0_224 (five HAT blocks without carrier tokens, synthetic 'init'
+    weights): dx and the .grad of every parameter of layer.blocks -- including the cpb_mlp of the relative-position bias and of the 1-D position embedding,
+    reached through the folded tables -- against torch.autograd through the CPU oracle's hat_stage (oracle/hat_reference.py) on the same weights."""
+    import fastervit_amd
+    from oracle import hat_reference as hr
+    from tests.synth import synth_state_dict
+    torch.manual_seed(0)
+    model = fastervit_amd.create_model("faster_vit_0_224").eval()
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234, family="init"))
+    layer = model.levels[3]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B = 6
+    x = torch.randn(B, 512, 7, 7, generator=g)
+    dy = torch.randn(B, 512, 7, 7, generator=g)
+    # ---- reference: autograd through the oracle on CPU, fp32 ----
+    sd = {k: v.detach().clone().float().requires_grad_(v.dtype.is_floating_point) for k, v in layer.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    blk0 = layer.blocks[0]
+    out = hr.hat_stage(xr, sd, "", depth=len(layer.blocks), heads=blk0.attn.num_heads, ws=layer.window_size, cw=blk0.cr_window, input_resolution=[7, 7],
+                       only_local=True, do_propagation=False, any_res=layer.any_res)
+    out.backward(dy)
+    ref = {k: v.grad for k, v in sd.items() if k.startswith("blocks.") and v.requires_grad and v.grad is not None}
+    # ---- product ----
+    layer = layer.cuda()
+    for p in layer.parameters():
+        p.grad = None
+    dx = hat_backward.local_stage_backward(layer, x.cuda(), dy.cuda())
+    torch.cuda.synchronize()
+    err, scale = (dx.cpu() - xr.grad).abs().max().item(), xr.grad.abs().max().item()
+    assert err < 1e-2 * scale, f"dx: {err:.3e} vs {scale:.3e}"
+    got = {k: p.grad for k, p in layer.named_parameters() if k.startswith("blocks.")}
+    checked = 0
+    for k, r in ref.items():
+        assert k in got and got[k] is not None, f"no gradient for {k}"
+        a = got[k].float().cpu()
+        e, sc = (a - r).abs().max().item(), r.abs().max().item()
+        assert torch.isfinite(a).all() and e < 1.5e-2 * sc + 1e-7, f"{k}: max-abs err {e:.3e} vs scale {sc:.3e}"
+        checked += 1
+    assert checked >= 5 * 14   # 14 weight / bias / gamma tensors per block at least, plus the two cpb MLPs
