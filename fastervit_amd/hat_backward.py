@@ -456,3 +456,115 @@ def local_stage_backward(layer, x: torch.Tensor, dy: torch.Tensor, operand_dtype
         # the folded tables are functions of small MLPs: their gradients continue on the host through the modules' own table() code
         torch.autograd.backward([bias_t, pe_t], [ag.bias.to(bias_t.dtype), d.view(-1, S, C_).sum(0).to(pe_t.dtype)])
     return reverse(d)
+
+
+def hier_block_forward(x: torch.Tensor, ct: torch.Tensor, hat_attn: dict, hat_mlp: dict, attn: dict, mlp: dict, heads: int, ws: int, cw: int, sr,
+                       pe_x: Optional[torch.Tensor], pe_ct: Optional[torch.Tensor], eps: float = 1e-5, operand_dtype=torch.float16):
+    """Forward of one HAT block with carrier tokens through the unit kernels (the recompute ``hier_block_backward`` starts from): returns (x_out, ct_out)
+    in the reference's layouts, x (B nW, ws^2, C), ct (B, G, C).  No last-block propagation."""
+    Bw, nloc, C_ = x.shape
+    B, G, _ = ct.shape
+    sr0, sr1 = int(sr[0]), int(sr[1])
+    ncw = cw * cw
+    S = ncw + nloc
+    dew, win = _carrier_permutations(sr0, sr1, cw, x.device)
+    od = operand_dtype
+    x0 = (x + pe_x.to(x.device)) if pe_x is not None else x
+    ct0 = ct[:, dew]
+    if pe_ct is not None:
+        ct0 = ct0 + pe_ct.to(x.device)
+    ct0 = ct0.reshape(B * G, C_).contiguous()
+    ha, hm = hat_attn, hat_mlp
+    ct1 = attn_block_forward(ct0, ha["ln_w"], ha["ln_b"], ha["qkv_w"], ha.get("qkv_b"), ha["proj_w"], ha["proj_b"], ha.get("gamma"), ha.get("bias"), heads, G, eps,
+                             None, od)
+    ct2 = mlp_block_forward(ct1, hm["ln_w"], hm["ln_b"], hm["fc1_w"], hm["fc1_b"], hm["fc2_w"], hm["fc2_b"], hm.get("gamma"), eps, od)
+    ctw = ct2.view(B, G, C_)[:, win].reshape(Bw, ncw, C_)
+    xin = torch.cat((ctw, x0), dim=1).reshape(Bw * S, C_).contiguous()
+    y1 = attn_block_forward(xin, attn["ln_w"], attn["ln_b"], attn["qkv_w"], attn.get("qkv_b"), attn["proj_w"], attn["proj_b"], attn.get("gamma"), attn.get("bias"),
+                            heads, S, eps, None, od)
+    y2 = mlp_block_forward(y1, mlp["ln_w"], mlp["ln_b"], mlp["fc1_w"], mlp["fc1_b"], mlp["fc2_w"], mlp["fc2_b"], mlp.get("gamma"), eps, od).view(Bw, S, C_)
+    return y2[:, ncw:].contiguous(), y2[:, :ncw].reshape(B, G, C_).contiguous()
+
+
+def hier_stage_backward(layer, x: torch.Tensor, dy: torch.Tensor, operand_dtype=torch.float16) -> torch.Tensor:
+    """Backward of the transformer branch of a FasterViTLayer WITH carrier tokens (FasterViTLayer.forward FV:832-841: TokenInitializer, window_partition,
+    depth x hierarchical HAT block, window_reverse; stage 2 of FasterViT-0 / 1 / 2: ``do_propagation`` off, map an exact multiple of the window):
+    returns dx (B, C, H, W) and ADDS the gradient of every parameter of ``layer.blocks`` and ``layer.global_tokenizer`` into ``.grad``.
+    The HAT blocks run on the kernels (``hier_block_forward`` checkpoints per block, ``hier_block_backward``); the TokenInitializer (one depthwise conv +
+    average pool, FV:704-738) and the four folded tables per block are small torch modules differentiated by autograd on the host side."""
+    if not x.is_cuda:
+        raise RuntimeError("hier_stage_backward runs only on a HIP device (libfvit_hip.so kernels); there is no CPU fallback")
+    B, C_, H, W = x.shape
+    blocks = list(layer.blocks)
+    if not blocks or not all(b.do_sr_hat for b in blocks) or any(b.do_propagation for b in blocks):
+        raise RuntimeError("hier_stage_backward: the stage must consist of carrier-token HAT blocks without last-block propagation")
+    b0 = blocks[0]
+    ws, cw, sr = b0.window_size, b0.cr_window, tuple(b0.sr_ratio)
+    if H % ws or W % ws or (H // ws, W // ws) != sr:
+        raise RuntimeError(f"hier_stage_backward: map {H}x{W} does not tile into the stage's {sr[0]}x{sr[1]} windows of {ws}")
+    heads, nloc, ncw = b0.attn.num_heads, ws * ws, cw * cw
+    nh, nw = sr
+    G, S = ncw * nh * nw, ncw + nloc
+
+    def partition(t):
+        return t.view(B, C_, nh, ws, nw, ws).permute(0, 2, 4, 3, 5, 1).reshape(B * nh * nw, nloc, C_).contiguous()
+
+    def reverse(r):
+        return r.view(B, nh, nw, ws, ws, C_).permute(0, 5, 1, 3, 2, 4).reshape(B, C_, H, W).contiguous()
+
+    def gm(v):
+        return v if isinstance(v, torch.Tensor) else None
+
+    def params(blk):
+        t = dict(bias=_table_with_grad(blk.attn.pos_emb_funct, S), hat_bias=_table_with_grad(blk.hat_attn.pos_emb_funct, G), pe_x=_table_with_grad(blk.pos_embed),
+                 pe_ct=_table_with_grad(blk.hat_pos_embed) if hasattr(blk, "hat_pos_embed") and blk.square else None)
+        mk_a = lambda n, at, g, bias: dict(ln_w=n.weight, ln_b=n.bias, qkv_w=at.qkv.weight, qkv_b=at.qkv.bias, proj_w=at.proj.weight, proj_b=at.proj.bias,   # noqa: E731
+                                           gamma=gm(g), bias=bias.detach())
+        mk_m = lambda n, ml, g: dict(ln_w=n.weight, ln_b=n.bias, fc1_w=ml.fc1.weight, fc1_b=ml.fc1.bias, fc2_w=ml.fc2.weight, fc2_b=ml.fc2.bias, gamma=gm(g))   # noqa: E731
+        return dict(hat_attn=mk_a(blk.hat_norm1, blk.hat_attn, blk.gamma1, t["hat_bias"]), hat_mlp=mk_m(blk.hat_norm2, blk.hat_mlp, blk.gamma2),
+                    attn=mk_a(blk.norm1, blk.attn, blk.gamma3, t["bias"]), mlp=mk_m(blk.norm2, blk.mlp, blk.gamma4)), t
+
+    # ---- forward: carrier tokens from the tokenizer (torch, with autograd), then the blocks with a checkpoint per block ----
+    x_leaf = x.detach().float().requires_grad_(True)
+    with torch.enable_grad():
+        ct_init = layer.global_tokenizer(x_leaf)
+    rows, ct = partition(x.float()), ct_init.detach().float().contiguous()
+    ckpt, ps = [], []
+    for blk in blocks:
+        P, t = params(blk)
+        ckpt.append((rows, ct))
+        ps.append((P, t))
+        rows, ct = hier_block_forward(rows, ct, P["hat_attn"], P["hat_mlp"], P["attn"], P["mlp"], heads, ws, cw, sr, t["pe_x"].detach(),
+                                      None if t["pe_ct"] is None else t["pe_ct"].detach(), 1e-5, operand_dtype)
+    # ---- backward ----
+    d, dct = partition(dy.float()), torch.zeros(B, G, C_, dtype=torch.float32, device=x.device)   # the stage's final carrier tokens are dropped (FV:841)
+    dew, _ = _carrier_permutations(sr[0], sr[1], cw, x.device)
+    for blk, (xb, ctb), (P, t) in zip(reversed(blocks), reversed(ckpt), reversed(ps)):
+        hid = P["mlp"]["fc1_w"].shape[0]
+        grads = dict(hat_attn=AttnGrads.zeros(C_, heads, G, x.device, with_gamma=P["hat_attn"]["gamma"] is not None),
+                     hat_mlp=MlpGrads.zeros(C_, hid, x.device, with_gamma=P["hat_mlp"]["gamma"] is not None),
+                     attn=AttnGrads.zeros(C_, heads, S, x.device, with_gamma=P["attn"]["gamma"] is not None),
+                     mlp=MlpGrads.zeros(C_, hid, x.device, with_gamma=P["mlp"]["gamma"] is not None))
+        d, dct = hier_block_backward(xb, ctb, d, dct, P["hat_attn"], P["hat_mlp"], P["attn"], P["mlp"], heads, ws, cw, sr, t["pe_x"].detach(),
+                                     None if t["pe_ct"] is None else t["pe_ct"].detach(), grads, 1e-5, operand_dtype)
+        for key, norm, at in (("hat_attn", blk.hat_norm1, blk.hat_attn), ("attn", blk.norm1, blk.attn)):
+            gr = grads[key]
+            for prm, g in ((norm.weight, gr.ln_w), (norm.bias, gr.ln_b), (at.qkv.weight, gr.qkv_w), (at.qkv.bias, gr.qkv_b), (at.proj.weight, gr.proj_w),
+                           (at.proj.bias, gr.proj_b), (blk.gamma1 if key == "hat_attn" else blk.gamma3, gr.gamma)):
+                if g is not None:
+                    _acc_grad(prm, g)
+        for key, norm, ml in (("hat_mlp", blk.hat_norm2, blk.hat_mlp), ("mlp", blk.norm2, blk.mlp)):
+            gr = grads[key]
+            for prm, g in ((norm.weight, gr.ln_w), (norm.bias, gr.ln_b), (ml.fc1.weight, gr.fc1_w), (ml.fc1.bias, gr.fc1_b), (ml.fc2.weight, gr.fc2_w),
+                           (ml.fc2.bias, gr.fc2_b), (blk.gamma2 if key == "hat_mlp" else blk.gamma4, gr.gamma)):
+                if g is not None:
+                    _acc_grad(prm, g)
+        # folded tables -> their small MLPs (host autograd): d pe_x = sum over windows of dx, d pe_ct = sum over images of the dewindowed carrier gradient
+        outs, gouts = [t["bias"], t["hat_bias"], t["pe_x"]], [grads["attn"].bias, grads["hat_attn"].bias, d.sum(0)]
+        if t["pe_ct"] is not None:
+            outs.append(t["pe_ct"])
+            gouts.append(dct[:, dew].sum(0))
+        torch.autograd.backward(outs, [g_.to(o.dtype) for o, g_ in zip(outs, gouts)])
+    # ---- the carrier tokens came from the tokenizer: its conv parameters and its share of dx ----
+    torch.autograd.backward([ct_init], [dct.to(ct_init.dtype)])
+    return reverse(d) + x_leaf.grad

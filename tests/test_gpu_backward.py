@@ -244,3 +244,45 @@ def test_stage3_backward_of_the_model_vs_oracle_autograd():
         assert torch.isfinite(a).all() and e < 1.5e-2 * sc + 1e-7, f"{k}: max-abs err {e:.3e} vs scale {sc:.3e}"
         checked += 1
     assert checked >= 5 * 14   # 14 weight / bias / gamma tensors per block at least, plus the two cpb MLPs
+
+
+def test_stage2_backward_of_the_model_vs_oracle_autograd():
+    """hat_backward.hier_stage_backward on the REAL stage 2 of faster_vit_0_224 (TokenInitializer + six HAT blocks with carrier tokens, 14 x 14 map, 2 x 2
+    windows of 7 x 7 with 2 x 2 carrier tokens each): dx and the .grad of every parameter of layer.blocks and layer.global_tokenizer against torch.autograd
+    through the CPU oracle's hat_stage on the same synthetic 'init' weights."""
+    import fastervit_amd
+    from oracle import hat_reference as hr
+    from tests.synth import synth_state_dict
+    torch.manual_seed(0)
+    model = fastervit_amd.create_model("faster_vit_0_224").eval()
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234, family="init"))
+    layer = model.levels[2]
+    g = torch.Generator(device="cpu").manual_seed(4)
+    B = 4
+    x = torch.randn(B, 256, 14, 14, generator=g)
+    dy = torch.randn(B, 256, 14, 14, generator=g)
+    sd = {k: v.detach().clone().float().requires_grad_(v.dtype.is_floating_point) for k, v in layer.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    blk0 = layer.blocks[0]
+    out = hr.hat_stage(xr, sd, "", depth=len(layer.blocks), heads=blk0.attn.num_heads, ws=layer.window_size, cw=blk0.cr_window, input_resolution=[14, 14],
+                       only_local=False, do_propagation=False, any_res=layer.any_res)
+    out.backward(dy)
+    ref = {k: v.grad for k, v in sd.items() if (k.startswith("blocks.") or k.startswith("global_tokenizer.")) and v.requires_grad and v.grad is not None}
+    layer = layer.cuda()
+    for p in layer.parameters():
+        p.grad = None
+    dx = hat_backward.hier_stage_backward(layer, x.cuda(), dy.cuda())
+    torch.cuda.synchronize()
+    err, scale = (dx.cpu() - xr.grad).abs().max().item(), xr.grad.abs().max().item()
+    assert err < 1.5e-2 * scale, f"dx: {err:.3e} vs {scale:.3e}"
+    got = dict(layer.named_parameters())
+    checked = 0
+    for k, r in ref.items():
+        if k not in got:      # the tokenizer's conv is registered under two names (to_global_feature.pos == pos_embed): named_parameters lists it once
+            continue
+        assert got[k].grad is not None, f"no gradient for {k}"
+        a = got[k].grad.float().cpu()
+        e, sc = (a - r).abs().max().item(), r.abs().max().item()
+        assert torch.isfinite(a).all() and e < 2e-2 * sc + 1e-7, f"{k}: max-abs err {e:.3e} vs scale {sc:.3e}"
+        checked += 1
+    assert checked >= 6 * 28
