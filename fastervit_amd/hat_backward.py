@@ -568,3 +568,56 @@ def hier_stage_backward(layer, x: torch.Tensor, dy: torch.Tensor, operand_dtype=
     # ---- the carrier tokens came from the tokenizer: its conv parameters and its share of dx ----
     torch.autograd.backward([ct_init], [dct.to(ct_init.dtype)])
     return reverse(d) + x_leaf.grad
+
+
+# --------------------------------------------------------------------------------------------------------------------------------------
+# autograd bridge: the transformer branch of a FasterViTLayer as ONE autograd node (forward: fvit_hat_stage_forward, backward: the functions above)
+# --------------------------------------------------------------------------------------------------------------------------------------
+def _stage_params(layer):
+    seen, out = set(), []
+    mods = [layer.blocks] + ([layer.global_tokenizer] if getattr(layer, "do_gt", False) and hasattr(layer, "global_tokenizer") else [])
+    for m in mods:
+        for prm in m.parameters():
+            if id(prm) not in seen:
+                seen.add(id(prm))
+                out.append(prm)
+    return out
+
+
+class HatStageFunction(torch.autograd.Function):
+    """y = FasterViTLayer transformer branch (x) with the module's parameters as differentiable inputs.  Forward = the HIP inference path (eval semantics:
+    DropPath / Dropout are identities -- train with drop_path = 0 or accept that); backward = local_stage_backward / hier_stage_backward, whose parameter
+    gradients are handed back to autograd (so hooks such as DistributedDataParallel's fire) instead of being written into .grad."""
+
+    @staticmethod
+    def forward(ctx, x, layer, operand_dtype, *params):
+        from . import hat_runtime
+        ctx.layer, ctx.operand_dtype, ctx.params = layer, operand_dtype, params
+        ctx.save_for_backward(x)
+        return hat_runtime.stage_forward(layer, x.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        layer, params = ctx.layer, ctx.params
+        saved = [prm.grad for prm in params]
+        for prm in params:
+            prm.grad = None
+        try:
+            fn = hier_stage_backward if layer.blocks[0].do_sr_hat else local_stage_backward
+            dx = fn(layer, x.float().contiguous(), dy.float().contiguous(), ctx.operand_dtype)
+            grads = [prm.grad for prm in params]
+        finally:
+            for prm, g0 in zip(params, saved):
+                prm.grad = g0
+        return (dx.to(x.dtype), None, None, *grads)
+
+
+def stage_forward_with_grad(layer, x: torch.Tensor, operand_dtype=torch.float16) -> torch.Tensor:
+    """``hat_runtime.stage_forward`` as a differentiable op (see HatStageFunction).  The layer must be in eval mode (the HIP path has eval semantics)."""
+    if layer.training:
+        raise RuntimeError("stage_forward_with_grad: keep the HAT stages in eval mode (forward kernels have eval semantics: no DropPath / Dropout); "
+                           "BatchNorm lives on the conv side and is not affected")
+    if len(layer.blocks) == 0:
+        return x
+    return HatStageFunction.apply(x, layer, operand_dtype, *_stage_params(layer))

@@ -369,7 +369,11 @@ class FasterViTLayer(nn.Module):
     def forward(self, x):
         if self.transformer_block:
             from .. import hat_runtime
-            x = hat_runtime.stage_forward(self, x)
+            if self.__dict__.get("hat_backward", False) and torch.is_grad_enabled() and x.is_cuda:
+                from .. import hat_backward   # the stage as one autograd node: HIP forward, kernel-sequence backward (FasterViT.enable_hat_backward)
+                x = hat_backward.stage_forward_with_grad(self, x)
+            else:
+                x = hat_runtime.stage_forward(self, x)
         else:
             for blk in self.blocks:
                 x, _ = blk(x, None)
@@ -496,8 +500,19 @@ class FasterViT(nn.Module):
         from ..inference import CompiledInference
         return CompiledInference(self, example, dtype=dtype, streams=streams, graph=graph)
 
+    def enable_hat_backward(self, on: bool = True):
+        """Make the transformer stages differentiable: with the model in eval mode (HAT stages have eval semantics; BatchNorm uses its running statistics)
+        and grad enabled, every HAT stage becomes ONE autograd node whose forward is the HIP inference path and whose backward is the kernel sequence of
+        ``fastervit_amd.hat_backward`` (stages without last-block propagation whose maps tile exactly into windows: FasterViT-0 / 1 / 2 at their native
+        resolution).  The conv stages, norms and head are ordinary PyTorch modules and differentiate as usual.  Off by default: inference-only."""
+        self.__dict__["hat_backward"] = bool(on)
+        for lvl in self.levels:
+            if lvl.transformer_block:
+                lvl.__dict__["hat_backward"] = bool(on)
+        return self
+
     def forward(self, x):
-        if x.is_cuda and not self.training:
+        if x.is_cuda and not self.training and not (self.__dict__.get("hat_backward", False) and torch.is_grad_enabled()):
             from ..hat_runtime import check_user_input
             check_user_input(x)   # eval on the GPU = forward-only HIP stages: a caller asking for d/dx gets an error, not zeros
         plan = self.__dict__.get("_deploy_plan")
