@@ -178,3 +178,18 @@ def test_hat_backward_has_no_cpu_path():
         hat_backward.mlp_block_backward(x, x, x[0], x[0], torch.zeros(1024, 256), torch.zeros(1024), torch.zeros(256, 1024), torch.zeros(256), None, None)
     with pytest.raises(RuntimeError, match="HIP device"):
         hat_backward.attn_block_backward(x, x, x[0], x[0], torch.zeros(768, 256), None, torch.zeros(256, 256), torch.zeros(256), None, None, 8, 4, None)
+
+
+def test_enable_hat_backward_flags_and_cpu_behaviour():
+    """model.enable_hat_backward() marks the transformer levels only; on CPU tensors the stages still raise (no CPU path), and switching it off restores
+    the forward-only contract."""
+    import fastervit_amd
+    model = fastervit_amd.create_model("faster_vit_0_224").eval()
+    assert not any(lvl.__dict__.get("hat_backward", False) for lvl in model.levels)
+    assert model.enable_hat_backward(True) is model
+    assert [bool(lvl.__dict__.get("hat_backward", False)) for lvl in model.levels] == [False, False, True, True]
+    x = torch.randn(1, 3, 224, 224, requires_grad=True)
+    with pytest.raises(RuntimeError):
+        model(x)                       # HAT stages need the HIP device
+    model.enable_hat_backward(False)
+    assert not any(lvl.__dict__.get("hat_backward", False) for lvl in model.levels)
