@@ -59,3 +59,25 @@ def test_roofline_selection_is_dominant_kernel_by_time():
     assert dom["kernel"] == "conv3x3_kernel<2,2,4>"
     e = bench.roofline_entry(dom, "f16", 0.9)
     assert e["cu_share"] == 1.0 and "dominant kernel by time" in e["selection"]
+
+
+def test_printed_line_is_compact_and_carries_the_contract():
+    """The driver parses the LAST stdout line of bench.py; r03's 26 KB line was truncated by its stdout tail (BENCH_r03 parsed = null).
+    The full r03 record goes through the compaction the live run uses: < 8 KB, valid JSON, contract keys + roofline + cpu_baseline."""
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_final.json")).read().strip().splitlines()[-1])
+    line = bench.compact_line(full, "profiles/bench_last.json")
+    assert len(line) < bench.LINE_BUDGET <= 8000 and "\n" not in line
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in c, k
+    assert c["value"] == full["value"] and "workload" in c["config"] and "model" not in c["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in c["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c["cpu_baseline"], k
+    assert len(c["secondary"]) == 2 and all("value" in s and "parity" in s for s in c["secondary"])
+    # a record bloated with prose still fits: optional blocks are dropped before the contract keys
+    full["secondary"] = full["secondary"] * 20
+    assert len(bench.compact_line(full)) < bench.LINE_BUDGET
