@@ -300,41 +300,56 @@ class DeployPlan:
         # The per-geometry index tables (an H2D copy) and workspaces are created lazily by the first stage call too: the forked form
         # is allowed only for a (device, shard sizes, image size, operand mode) that has completed one serial pass.
         ops = tuple(getattr(lvl, "hat_operand_dtype", "f16") for lvl in self.model.levels if lvl.transformer_block)
-        wkey = (str(x.device), tuple(p.shape[0] for p in parts), tuple(x.shape[1:]), ops)
+        wkey = (str(x.device), tuple(p.shape[0] for p in parts), tuple(x.shape[1:]), ops, getattr(self, "join_from", None))
         warm = self.__dict__.setdefault("_warm_geometries", set())
         serial = getattr(self, "serialize_shards", False) or not self._hat_prepared(x.device) or wkey not in warm
+        # join_from = L (r04, ``plan.join_from``; None = off): the shards run levels [0, L) on their own streams, JOIN, and levels
+        # [L, end) + head run once on the whole batch on the caller's stream.  The last stage of FasterViT-0 (one 49-token window per
+        # image, 512 channels) is 86-workgroup launches per shard that cannot fill the chip; joined it is 196 / 256 workgroups.
+        jf = getattr(self, "join_from", None)
+        nlev = len(self.model.levels)
+        jf = jf if (jf is not None and 0 < jf < nlev) else None
+        front = (lambda xi: self._forward_one(xi, 0, jf)) if jf is not None else self._forward_one
+        back = (lambda xs: self._forward_one(torch.cat(xs, dim=0), jf, None)) if jf is not None else (lambda xs: torch.cat(xs, dim=0))
         if serial:
             # also the measurement aid of bench.py's HIP-event pass: the same shard-sized launches, one after the other on the
             # caller's stream, so that a kernel's event-pair duration is its own and not shared with the other shards' kernels
             for i in range(n):
                 with hat_runtime.workspace_slot(i):
-                    outs[i] = self._forward_one(parts[i])
+                    outs[i] = front(parts[i])
+            with hat_runtime.workspace_slot(0):
+                y = back(outs)
             if not torch.cuda.is_current_stream_capturing():
                 warm.add(wkey)
-            return torch.cat(outs, dim=0)
+            return y
         if self.side is None or len(self.side) != n - 1 or self.side[0].device != x.device:
             self.side = [torch.cuda.Stream(device=x.device) for _ in range(n - 1)]
         main = torch.cuda.current_stream(x.device)
         for i, s in enumerate(self.side):
             s.wait_stream(main)
             with torch.cuda.stream(s), hat_runtime.workspace_slot(i + 1):
-                outs[i + 1] = self._forward_one(parts[i + 1])
+                outs[i + 1] = front(parts[i + 1])
         with hat_runtime.workspace_slot(0):
-            outs[0] = self._forward_one(parts[0])
+            outs[0] = front(parts[0])
         for s in self.side:
             main.wait_stream(s)   # join: everything the caller enqueues next (the cat below, its own later work) is ordered after the shards
-        return torch.cat(outs, dim=0)
+        with hat_runtime.workspace_slot(0):
+            return back(outs)
 
     def shard_runner(self, x, n=None):
         """Free-running stream shards for throughput serving: see ``ShardRunner``."""
         return ShardRunner(self, x, n or max(self.streams, 1))
 
-    def _forward_one(self, x):
+    def _forward_one(self, x, lv_from=0, lv_to=None):
+        """Levels [lv_from, lv_to) of the plan; the stem runs in front of level 0, final norm + pool + head after the last level
+        (lv_to = None).  A partial call returns the (channels_last, 16-bit) map that the next level takes."""
         t = self.t
         with torch.autocast(device_type="cuda", enabled=False):
             w0, b0, w1, b1 = t["stem"]
             wk1 = w1[1]
-            if (self.fused_stem and t["stem_k"] is not None and x.shape[1] == 3 and x.dtype in hat_runtime._DT and wk1 is not None
+            if lv_from > 0:
+                pass
+            elif (self.fused_stem and t["stem_k"] is not None and x.shape[1] == 3 and x.dtype in hat_runtime._DT and wk1 is not None
                     and tuple(wk1.shape) == (64, 3, 3, 64)):
                 B, _, Hi, Wi = x.shape
                 H1, W1 = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
@@ -355,7 +370,9 @@ class DeployPlan:
             else:
                 x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
                 x = self._conv(self._conv(x, w0, b0, 2, 1), w1, b1, 2, 1)
-            for lvl, e in zip(self.model.levels, t["levels"]):
+            for li, (lvl, e) in enumerate(zip(self.model.levels, t["levels"])):
+                if li < lv_from or (lv_to is not None and li >= lv_to):
+                    continue
                 if "blocks" in e:
                     for wa, ba, wb, bb in e["blocks"]:
                         y = self._conv(x, wa, ba, 1, 2)
@@ -377,6 +394,8 @@ class DeployPlan:
                 if "down" in e:
                     lw, lb, eps, wd, cin = e["down"]
                     x = self._conv(self._ln2d(x, lw, lb, eps, cin), wd, None, 2, 0)
+            if lv_to is not None:
+                return x
             hw, hb, ln = t["head"]
             if ln is not None:
                 x = self._ln2d(x, *ln)

@@ -125,7 +125,7 @@ struct StageLayout {
 static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
     if (d.batch <= 0 || d.C <= 0 || d.heads <= 0 || d.C % d.heads || d.ws <= 0 || d.Hp % d.ws || d.Wp % d.ws ||
         (d.dpad != 32 && d.dpad != 64 && d.dpad != 96) || d.dpad < d.C / d.heads || d.hidden <= 0 || (d.C % 16) || (d.hidden % 16) ||
-        (d.operand_dtype != FVIT_F16 && d.operand_dtype != FVIT_BF16) || (d.hier && d.cw <= 0) || (d.weight_terms != 1 && d.weight_terms != 2)) {
+        (d.operand_dtype != FVIT_F16 && d.operand_dtype != FVIT_BF16) || (d.hier && d.cw <= 0) || d.weight_terms < 1 || d.weight_terms > 3) {
         set_error("stage descriptor rejected: batch=%d C=%d heads=%d dpad=%d ws=%d Hp=%d Wp=%d hidden=%d hier=%d cw=%d dtype=%d weight_terms=%d",
                   d.batch, d.C, d.heads, d.dpad, d.ws, d.Hp, d.Wp, d.hidden, d.hier, d.cw, d.operand_dtype, d.weight_terms);
         return false;
@@ -145,16 +145,18 @@ static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     L.off_X = take((size_t)L.Mx * d.C * 4);
-    L.off_Xn = take((size_t)Mxp * L.ldn * 2);
-    L.off_QKV = take((size_t)Mxp * L.ldqkv * 2);
-    L.off_AO = take((size_t)Mxp * L.ldao * 2);
-    L.off_H = take((size_t)Mxp * L.ldh * 2);
+    // weight_terms 3 ("x3"): every 16-bit activation row holds TWO terms [hi | lo] (row stride 2 x ld*, lo image at column ld*)
+    const size_t at = d.weight_terms == 3 ? 2 : 1;
+    L.off_Xn = take((size_t)Mxp * L.ldn * 2 * at);
+    L.off_QKV = take((size_t)Mxp * L.ldqkv * 2 * at);
+    L.off_AO = take((size_t)Mxp * L.ldao * 2 * at);
+    L.off_H = take((size_t)Mxp * L.ldh * 2 * at);
     if (d.hier) {
         L.off_R = take((size_t)L.Mc * d.C * 4);
-        L.off_Rn = take((size_t)Mcp * L.ldn * 2);
-        L.off_RQKV = take((size_t)Mcp * L.ldqkv * 2);
-        L.off_RAO = take((size_t)Mcp * L.ldao * 2);
-        L.off_RH = take((size_t)Mcp * L.ldh * 2);
+        L.off_Rn = take((size_t)Mcp * L.ldn * 2 * at);
+        L.off_RQKV = take((size_t)Mcp * L.ldqkv * 2 * at);
+        L.off_RAO = take((size_t)Mcp * L.ldao * 2 * at);
+        L.off_RH = take((size_t)Mcp * L.ldh * 2 * at);
     } else {
         L.off_R = L.off_Rn = L.off_RQKV = L.off_RAO = L.off_RH = 0;
     }
@@ -193,23 +195,27 @@ static bool use_ln_gemm(const FvitStageDesc& d, int N, int ldw, int ldo, int64_t
 static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttnWeights& w, float* x, int64_t rows, void* xn,
                     void* qkv, void* ao, int nwin, int S, bool ln_done, hipStream_t st, bool qkv_done = false) {
     const int dt = d.operand_dtype;
-    const int T = d.weight_terms;   // K-concatenated weight terms: the GEMMs run K = T x ld against the same activation columns
+    const int T = d.weight_terms;   // K-concatenated weight terms: the GEMMs run K = T x ld against the activation columns (GemmCall.ka)
+    const int AT = T == 3 ? 2 : 1;  // activation terms: rows of xn / qkv / ao hold [hi | lo] images (stride AT x ld, lo at column ld)
     if (!ln_done && !qkv_done) {
-        LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
+        LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, AT * L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
+        if (AT == 2) ln.lo_off = L.ldn;
         FVIT_TRY(launch_gather_layernorm(ln, st));
     }
-    dbg_rowhash("attn.xn", xn, rows, L.ldn * 2, st);
+    dbg_rowhash("attn.xn", xn, rows, AT * L.ldn * 2, st);
     if (!qkv_done) {
-        GemmCall g1 = {dt, xn, L.ldn, w.w_qkv, T * L.ldn, w.b_qkv, nullptr, qkv, L.ldqkv, (int)rows, L.ldqkv, T * L.ldn, 0};
+        GemmCall g1 = {dt, xn, AT * L.ldn, w.w_qkv, T * L.ldn, w.b_qkv, nullptr, qkv, AT * L.ldqkv, (int)rows, L.ldqkv, T * L.ldn, 0};
         g1.ka = L.ldn;
+        if (AT == 2) g1.out_lo_off = L.ldqkv;
         FVIT_TRY(launch_gemm(g1, st));
     }
-    dbg_rowhash("attn.qkv", qkv, rows, L.ldqkv * 2, st);
+    dbg_rowhash("attn.qkv", qkv, rows, AT * L.ldqkv * 2, st);
     const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
-    AttnCall at = {dt, qkv, L.ldqkv, ao, L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale, w.rel_table, w.rel_w, w.rel_ng, d.C / d.heads};
+    AttnCall at = {dt, qkv, AT * L.ldqkv, ao, AT * L.ldao, w.bias, nwin, S, d.heads, d.dpad, scale, w.rel_table, w.rel_w, w.rel_ng, d.C / d.heads};
+    if (AT == 2) { at.q_lo_off = L.ldqkv; at.o_lo_off = L.ldao; }
     FVIT_TRY(launch_attention(at, st));
-    dbg_rowhash("attn.ao", ao, rows, L.ldao * 2, st);
-    GemmCall g2 = {dt, ao, L.ldao, w.w_proj, T * L.ldao, w.b_proj, w.gamma, x, d.C, (int)rows, d.C, T * L.ldao, 2};
+    dbg_rowhash("attn.ao", ao, rows, AT * L.ldao * 2, st);
+    GemmCall g2 = {dt, ao, AT * L.ldao, w.w_proj, T * L.ldao, w.b_proj, w.gamma, x, d.C, (int)rows, d.C, T * L.ldao, 2};
     g2.ka = L.ldao;
     FVIT_TRY(launch_gemm(g2, st));
     dbg_rowhash("attn.out", x, rows, d.C * 4, st);
@@ -233,7 +239,7 @@ struct NextPe {   // position-embedding rows of the NEXT block, applied in this 
 };
 
 static bool win_mlp_ok(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t rows) {
-    if (!winmlp_supported(d.C, d.hidden) || !w.w_fc1_frag || !w.w_fc2_frag) return false;
+    if (d.weight_terms > 2 || !winmlp_supported(d.C, d.hidden) || !w.w_fc1_frag || !w.w_fc2_frag) return false;
     if (d.C == 512) return tune_get("win_mlp", 1) != 0;
     return rows >= tune_get("mlp_fused_min_rows", 16384) && tune_get("win_mlp256", 2) != 0;   // C = 256: 2 = 4-wave 64-row workgroups, two per CU (default); 1 = 8-wave 128-row
 }
@@ -273,19 +279,22 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
         dbg_rowhash("mlpf.out", x, rows, d.C * 4, st);
         return FVIT_OK;
     }
-    LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
+    const int AT = T == 3 ? 2 : 1;   // activation terms (see run_attn)
+    LnCall ln = {dt, x, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, xn, AT * L.ldn, w.ln_w, w.ln_b, 1e-5f, (int)rows, 1, d.C};
+    if (AT == 2) ln.lo_off = L.ldn;
     if (use_ln_gemm(d, d.hidden, L.ldn, L.ldh, rows)) {
         // norm2 -> fc1 -> GELU in one kernel (AR:697 with AR:401-403): the normalised rows never reach HBM
         LnGemmCall lg = {ln, w.w_fc1, L.ldn, w.b_fc1, h, L.ldh, d.hidden, 1};
         FVIT_TRY(launch_ln_gemm(lg, st));
     } else {
         FVIT_TRY(launch_gather_layernorm(ln, st));
-        GemmCall g1 = {dt, xn, L.ldn, w.w_fc1, T * L.ldn, w.b_fc1, nullptr, h, L.ldh, (int)rows, d.hidden, T * L.ldn, 1};
+        GemmCall g1 = {dt, xn, AT * L.ldn, w.w_fc1, T * L.ldn, w.b_fc1, nullptr, h, AT * L.ldh, (int)rows, d.hidden, T * L.ldn, 1};
         g1.ka = L.ldn;
+        if (AT == 2) g1.out_lo_off = L.ldh;
         FVIT_TRY(launch_gemm(g1, st));
     }
-    dbg_rowhash("mlp.h", h, rows, L.ldh * 2, st);
-    GemmCall g2 = {dt, h, L.ldh, w.w_fc2, T * L.ldh, w.b_fc2, w.gamma, x, d.C, (int)rows, d.C, T * L.ldh, 2};
+    dbg_rowhash("mlp.h", h, rows, AT * L.ldh * 2, st);
+    GemmCall g2 = {dt, h, AT * L.ldh, w.w_fc2, T * L.ldh, w.b_fc2, w.gamma, x, d.C, (int)rows, d.C, T * L.ldh, 2};
     g2.ka = L.ldh;
     if (next_pe && next_pe->add) { g2.add = next_pe->add; g2.add_idx = next_pe->add_idx; g2.rows_per_image = next_pe->rows_per_image; }
     FVIT_TRY(launch_gemm(g2, st));
@@ -298,7 +307,7 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
 // qkv GEMM.  Same two fp32 additions in the same order as the separate kernel (bitwise the same residual stream).
 // C = 512 (stage 3 of FasterViT-0): the attention sub-block with the waves of a window splitting heads / output channels (fvit_winblk.hip)
 static bool win_fused_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S) {
-    if ((d.weight_terms != 1 && d.C != 512) || !winblk_supported(d.C, d.heads, S) || d.dpad != 32 || !w.w_qkv_frag || !w.b_qkv_heads || !w.w_proj_frag || !w.bias) return false;
+    if (d.weight_terms > 2 || (d.weight_terms != 1 && d.C != 512) || !winblk_supported(d.C, d.heads, S) || d.dpad != 32 || !w.w_qkv_frag || !w.b_qkv_heads || !w.w_proj_frag || !w.bias) return false;
     return d.C == 512 ? tune_get("win_fused", 1) != 0 : tune_get("win_fused256", 0) != 0;   // C = 256: the 4-wave form, two workgroups per CU
 }
 
@@ -324,7 +333,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         void* RH = ws + L.off_RH;
         const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
         bool ct_done = false;
-        if (ctblk_supported(d.C, d.heads, L.G, d.hidden) && d.dpad == 32 && w.hat_attn.w_qkv_frag && w.hat_attn.b_qkv_heads && w.hat_attn.w_proj_frag &&
+        if (d.weight_terms <= 2 && ctblk_supported(d.C, d.heads, L.G, d.hidden) && d.dpad == 32 && w.hat_attn.w_qkv_frag && w.hat_attn.b_qkv_heads && w.hat_attn.w_proj_frag &&
             w.hat_attn.bias && w.hat_mlp.w_fc1_frag && w.hat_mlp.w_fc2_frag && tune_get("ct_fused", 1)) {
             // the whole carrier-token branch (AR:679-686) in one kernel, one workgroup per image
             CtBlkCall cb = {dt, X, rpi, t.ct_src, (d.square ? w.pe_ct : nullptr), R, d.batch, L.G, d.heads, d.C, d.hidden,
@@ -343,8 +352,10 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
             dbg_rowhash("ct.attnblk", R, L.Mc, d.C * 4, st);
         } else {
             // ct_dewindow gather (+ hat_pos_embed) -> R, LN(hat_norm1) -> Rn
-            LnCall ln = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), R, Rn, L.ldn,
+            const int AT = d.weight_terms == 3 ? 2 : 1;
+            LnCall ln = {dt, X, rpi, nullptr, 0, t.ct_src, nullptr, (d.square ? w.pe_ct : nullptr), R, Rn, AT * L.ldn,
                          w.hat_attn.ln_w, w.hat_attn.ln_b, 1e-5f, (int)L.Mc, L.G, d.C};
+            if (AT == 2) ln.lo_off = L.ldn;
             if (use_ln_gemm(d, L.ldqkv, L.ldn, L.ldqkv, L.Mc)) {
                 // ct_dewindow gather + hat_pos_embed + hat_norm1 + hat_attn.qkv in one kernel (AR:679-686); R (the fp32 carrier stream)
                 // is written by the kernel's first column group
@@ -389,8 +400,10 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st, true));
     } else {
         // cat(ct_window(ct), x + pos_embed) gather -> X, LN(norm1) -> Xn
-        LnCall ln1 = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, X, Xn, L.ldn,
+        const int AT = d.weight_terms == 3 ? 2 : 1;
+        LnCall ln1 = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, X, Xn, AT * L.ldn,
                       w.attn.ln_w, w.attn.ln_b, 1e-5f, (int)L.Mx, rpi, d.C};
+        if (AT == 2) ln1.lo_off = L.ldn;
         FVIT_TRY(launch_gather_layernorm(ln1, st));
         dbg_rowhash("win.gather", X, L.Mx, d.C * 4, st);
         FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st));
@@ -570,6 +583,36 @@ int fvit_gemm_terms(int32_t operand_dtype, const void* A, int32_t lda, const voi
     GemmCall g = {operand_dtype, A, lda, Wt, ldw, bias, epilogue == 2 ? gamma : nullptr, out, ldo, M, N, K, epilogue};
     g.ka = ka;
     return launch_gemm(g, (hipStream_t)stream);
+}
+
+int fvit_gemm_terms_lo(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias, const float* gamma,
+                       void* out, int32_t ldo, int32_t out_lo_off, int32_t M, int32_t N, int32_t K, int32_t ka, int32_t epilogue,
+                       fvit_stream_t stream) {
+    if (epilogue < 0 || epilogue > 2) { set_error("gemm_terms_lo: epilogue %d", epilogue); return FVIT_EINVAL; }
+    GemmCall g = {operand_dtype, A, lda, Wt, ldw, bias, epilogue == 2 ? gamma : nullptr, out, ldo, M, N, K, epilogue};
+    g.ka = ka;
+    g.out_lo_off = out_lo_off;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+int fvit_window_attention_terms(int32_t operand_dtype, const void* qkv, int32_t ldq, int32_t q_lo_off, void* out, int32_t ldo,
+                                int32_t o_lo_off, const float* bias, int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale,
+                                fvit_stream_t stream) {
+    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, bias, nwin, S, heads, dpad, scale, nullptr, 0, 0, 0};
+    a.q_lo_off = q_lo_off;
+    a.o_lo_off = o_lo_off;
+    if (q_lo_off <= 0 || o_lo_off <= 0) { set_error("window_attention_terms: q_lo_off / o_lo_off must be > 0"); return FVIT_EINVAL; }
+    return launch_attention(a, (hipStream_t)stream);
+}
+
+int fvit_gather_layernorm_terms(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB,
+                                const int32_t* src_idx, const int32_t* add_idx, const float* add, float* x_out, void* n_out, int32_t ldn,
+                                int32_t lo_off, const float* ln_w, const float* ln_b, float eps, int32_t rows, int32_t rows_per_image,
+                                int32_t C, fvit_stream_t stream) {
+    LnCall c = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, x_out, n_out, ldn, ln_w, ln_b, eps, rows,
+                rows_per_image, C};
+    c.lo_off = lo_off;
+    return launch_gather_layernorm(c, (hipStream_t)stream);
 }
 
 int fvit_window_attention(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, const float* bias,

@@ -34,22 +34,27 @@ struct AttnParams {
     int ldq, ldo;
     int nwin, S, heads;
     float scale;
+    int q_lo_off, o_lo_off;   // TT instances: column offset (elements) of the lo image inside a qkv row / an output row
 };
 
-// SB: number of 16-token blocks (Spad / 16); DP: padded head dim (32 or 64)
-template <typename T, int SB, int DP>
-__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+// SB: number of 16-token blocks (Spad / 16); DP: padded head dim (32, 64 or 96)
+// TT (r04, weight_terms 3): every activation as TWO 16-bit terms -- q, k, v read as hi + lo images of the qkv rows, scores =
+// qh.kh + qh.kl + ql.kh, the probabilities split in registers (ph + pl), O = ph.vh + ph.vl + pl.vh, the output stored as hi + lo.
+// Two waves per workgroup (the V^T image is held twice); the K lo fragments are re-read per query block instead of living in registers.
+template <typename T, int SB, int DP, bool TT = false>
+__global__ __launch_bounds__(TT ? 128 : 256) void attn_kernel(AttnParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int SP = SB * 16;
     constexpr int KD = DP / 32;            // k-steps over head_dim for the score MFMA
     constexpr int DB = DP / 16;            // output-channel blocks
     constexpr int KB = (SB + 1) / 2;       // 32-key blocks for the PV MFMA
     constexpr int VROW = KB * 32 + 8;      // V^T row length in elements (+8: keeps rows 16-B aligned, breaks bank stride)
-    __shared__ __attribute__((aligned(16))) T vt_all[4][DP * VROW];
+    constexpr int NWV = TT ? 2 : 4, NT = TT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) T vt_all[NWV][NT * DP * VROW];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * 4 + wave;  // (window, head)
+    const int item = blockIdx.x * NWV + wave;  // (window, head)
     if (item >= p.nwin * p.heads) return;    // no block-wide barriers below
     const int win = item / p.heads, head = item - win * p.heads;
     const int HD = p.heads * DP;             // columns per q/k/v section
@@ -73,6 +78,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             const int pos = (jb >> 1) * 32 + gg * 8 + (jb & 1) * 4 + r;
 #pragma unroll
             for (int j = 0; j < 8; ++j) vt[(ch * 8 + j) * VROW + pos] = val[j];
+            if constexpr (TT) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
+                if (key < S) val = *(const v8*)(qkv + p.q_lo_off + (size_t)key * p.ldq + 2 * HD + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vt[DP * VROW + (ch * 8 + j) * VROW + pos] = val[j];
+            }
         }
     }
 
@@ -115,6 +127,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             if (qi < S) val = *(const v8*)(qkv + (size_t)qi * p.ldq + kd * 32 + g * 8);
             qf[kd] = val;
         }
+        v8 ql[TT ? KD : 1];
+        if constexpr (TT) {
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) {
+                v8 val;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
+                if (qi < S) val = *(const v8*)(qkv + p.q_lo_off + (size_t)qi * p.ldq + kd * 32 + g * 8);
+                ql[kd] = val;
+            }
+        }
         // scores^T: lane holds keys jb*16 + g*4 + r (r = 0..3) of query qi
         f4 sc[SB];
         float mx = -3.0e38f;
@@ -122,7 +145,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         for (int jb = 0; jb < SB; ++jb) {
             f4 a = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kd = 0; kd < KD; ++kd) a = Op16<T>::mfma(kf[jb][kd], qf[kd], a);
+            for (int kd = 0; kd < KD; ++kd) {
+                if constexpr (TT) {   // the small products first: qh.kl + ql.kh, then qh.kh
+                    const int key = jb * 16 + s;
+                    v8 kl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) kl[j] = (T)0.f;
+                    if (key < S) kl = *(const v8*)(qkv + p.q_lo_off + (size_t)key * p.ldq + HD + kd * 32 + g * 8);
+                    a = Op16<T>::mfma(kl, qf[kd], a);
+                    a = Op16<T>::mfma(kf[jb][kd], ql[kd], a);
+                }
+                a = Op16<T>::mfma(kf[jb][kd], qf[kd], a);
+            }
             const f4 bz = *(const f4*)(bias + (size_t)qi * SP + jb * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -151,15 +185,25 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         for (int db = 0; db < DB; ++db) o[db] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-            v8 pf;
+            v8 pf, pl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pf[r] = (T)sc[2 * kb][r];
-                pf[4 + r] = (2 * kb + 1 < SB) ? (T)sc[(2 * kb + 1 < SB) ? 2 * kb + 1 : 0][r] : (T)0.f;
+                const float e0 = sc[2 * kb][r], e1 = (2 * kb + 1 < SB) ? sc[(2 * kb + 1 < SB) ? 2 * kb + 1 : 0][r] : 0.f;
+                pf[r] = (T)e0;
+                pf[4 + r] = (T)e1;
+                if constexpr (TT) {
+                    pl[r] = (T)(e0 - (float)pf[r]);
+                    pl[4 + r] = (T)(e1 - (float)pf[4 + r]);
+                }
             }
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const v8 vf = *(const v8*)(vrow[db] + kb * 32);
+                if constexpr (TT) {
+                    const v8 vl = *(const v8*)(vrow[db] + DP * VROW + kb * 32);
+                    o[db] = Op16<T>::mfma(vl, pf, o[db]);
+                    o[db] = Op16<T>::mfma(vf, pl, o[db]);
+                }
                 o[db] = Op16<T>::mfma(vf, pf, o[db]);
             }
         }
@@ -167,21 +211,29 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         if (qi < S) {
             T* po = out + (size_t)qi * p.ldo + g * (DP / 4);
             if (DP == 32) {
-                v8 ov;
+                v8 ov, ol;
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[db * 4 + r] = sat16<T>(o[db][r] * inv);
+                    for (int r = 0; r < 4; ++r) {
+                        ov[db * 4 + r] = sat16<T>(o[db][r] * inv);
+                        ol[db * 4 + r] = sat16<T>(o[db][r] * inv - (float)ov[db * 4 + r]);
+                    }
                 *(v8*)po = ov;
+                if constexpr (TT) *(v8*)(po + p.o_lo_off) = ol;
             } else {
 #pragma unroll
                 for (int hseg = 0; hseg < DB / 2; ++hseg) {
-                    v8 ov;
+                    v8 ov, ol;
 #pragma unroll
                     for (int d2 = 0; d2 < 2; ++d2)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ov[d2 * 4 + r] = sat16<T>(o[hseg * 2 + d2][r] * inv);
+                        for (int r = 0; r < 4; ++r) {
+                            ov[d2 * 4 + r] = sat16<T>(o[hseg * 2 + d2][r] * inv);
+                            ol[d2 * 4 + r] = sat16<T>(o[hseg * 2 + d2][r] * inv - (float)ov[d2 * 4 + r]);
+                        }
                     *(v8*)(po + hseg * 8) = ov;
+                    if constexpr (TT) *(v8*)(po + p.o_lo_off + hseg * 8) = ol;
                 }
             }
         }
@@ -191,7 +243,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 template <typename T, int SB, int DP>
 void launch_inst(const AttnParams& p, hipStream_t stream) {
     const int items = p.nwin * p.heads;
-    hipLaunchKernelGGL((attn_kernel<T, SB, DP>), dim3((items + 3) / 4), dim3(256), 0, stream, p);
+    if (p.q_lo_off > 0) hipLaunchKernelGGL((attn_kernel<T, SB, DP, true>), dim3((items + 1) / 2), dim3(128), 0, stream, p);
+    else hipLaunchKernelGGL((attn_kernel<T, SB, DP>), dim3((items + 3) / 4), dim3(256), 0, stream, p);
 }
 
 template <typename T, int DP>
@@ -224,6 +277,13 @@ bool attention_dense(int S, int dpad) {
 }
 
 int launch_attention(const AttnCall& c, hipStream_t stream) {
+    const bool tt = c.q_lo_off > 0 || c.o_lo_off > 0;
+    if (tt && (!attention_dense(c.S, c.dpad) || c.q_lo_off < 3 * c.heads * c.dpad || c.ldq < c.q_lo_off + 3 * c.heads * c.dpad || (c.q_lo_off % 8) ||
+               c.o_lo_off < c.heads * c.dpad || c.ldo < c.o_lo_off + c.heads * c.dpad || (c.o_lo_off % 8))) {
+        set_error("attention: two-term activations need a dense window (S=%d <= %d tokens) and rows holding [hi | lo] images (ldq=%d q_lo_off=%d ldo=%d o_lo_off=%d)",
+                  c.S, FVIT_MAX_DENSE_SEQ, c.ldq, c.q_lo_off, c.ldo, c.o_lo_off);
+        return FVIT_EINVAL;
+    }
     if (!attention_dense(c.S, c.dpad)) return launch_attention_long(c, stream);
     if (c.S <= 0 || c.nwin <= 0 || (c.dpad != 32 && c.dpad != 64 && c.dpad != 96) || (c.ldq % 8) || (c.ldo % 8) || !c.bias) {
         set_error("attention: unsupported geometry S=%d nwin=%d dpad=%d ldq=%d ldo=%d bias=%p", c.S, c.nwin, c.dpad, c.ldq, c.ldo, (const void*)c.bias);
@@ -235,11 +295,12 @@ int launch_attention(const AttnCall& c, hipStream_t stream) {
     AttnParams p;
     p.qkv = c.qkv; p.out = c.out; p.bias = c.bias; p.ldq = c.ldq; p.ldo = c.ldo;
     p.nwin = c.nwin; p.S = c.S; p.heads = c.heads; p.scale = c.scale;
+    p.q_lo_off = c.q_lo_off; p.o_lo_off = c.o_lo_off;
     // algorithmic FLOPs count the real head_dim (49 of FasterViT-4 runs on dpad = 64; padding work is not credited)
     const double flops = 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * (c.d > 0 && c.d <= c.dpad ? c.d : c.dpad);
     const double bytes = 2.0 * c.nwin * (double)c.S * c.heads * c.dpad * 4.0;  // q,k,v read + o write (16-bit)
     ProfScope prof(FVIT_K_ATTENTION, flops, bytes, stream);
-    prof_note("attn_kernel", (c.nwin * c.heads + 3) / 4);
+    prof_note(tt ? "attn_kernel<two-term>" : "attn_kernel", tt ? (c.nwin * c.heads + 1) / 2 : (c.nwin * c.heads + 3) / 4);
 #define FVIT_ATTN_DP(T) (c.dpad == 32 ? launch_sb<T, 32>(p, sb, stream) : c.dpad == 64 ? launch_sb<T, 64>(p, sb, stream) : launch_sb<T, 96>(p, sb, stream))
     if (c.dtype == FVIT_F16) return FVIT_ATTN_DP(_Float16);
     if (c.dtype == FVIT_BF16) return FVIT_ATTN_DP(__bf16);

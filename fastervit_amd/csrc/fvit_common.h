@@ -131,6 +131,10 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return hx * (z * q) + hx;
 }
 
+// the same function through fast_erf (|erf error| <= 1.5e-7): the two-term-activation mode (weight_terms 3) carries ~22 significant
+// bits through every Linear layer, the polynomial above would be its error floor
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+
 __host__ __device__ constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -195,8 +199,12 @@ struct GemmCall {
     const int32_t* add_idx = nullptr;
     int rows_per_image = 1;
     // K-concatenated weight terms (FvitStageDesc.weight_terms): the weight rows hold K columns = terms x ka, the activation rows ka
-    // columns that are re-used for every term (column k of the contraction reads A column k mod ka).  0 = K.
+    // columns that are re-used for every term (column k of the contraction reads A column k >= ka ? k - ka : k).  0 = K.
+    // K = 3 ka (weight_terms 3, "x3"): weights [hi | lo | hi], activation rows hold TWO terms [hi | lo] (2 ka columns): the three
+    // segments are hi.hi + hi_a.lo_w + lo_a.hi_w, i.e. both operands carried as two 16-bit terms, the lo.lo product dropped.
     int ka = 0;
+    // epilogues 0 / 1: > 0 = the output is stored as two terms, hi at column n and lo = round(y - hi) at column out_lo_off + n
+    int out_lo_off = 0;
 };
 int launch_gemm(const GemmCall& c, hipStream_t stream);
 
@@ -280,6 +288,9 @@ struct AttnCall {
     const float* rel_table;
     int rel_w, rel_ng;
     int d;  // real head_dim (<= dpad) for the FLOP count of the kernel timer; 0 = unknown (dpad is used)
+    // two-term activations (weight_terms 3): qkv rows hold [q|k|v] hi at column 0 and lo at column q_lo_off; scores = qh.kh + qh.kl + ql.kh,
+    // P and V as two terms too (P in registers), the output written as hi at column 0 and lo at column o_lo_off.  0 = single terms.
+    int q_lo_off = 0, o_lo_off = 0;
 };
 bool attention_dense(int S, int dpad);                               // in-register kernel + dense bias table, else the long kernel
 int launch_attention(const AttnCall& c, hipStream_t stream);        // dispatches on attention_dense(S, dpad)
@@ -301,6 +312,7 @@ struct LnCall {
     const float* ln_b;
     float eps;
     int rows, rows_per_image, C;
+    int lo_off = 0;   // > 0: n_out holds two terms per row, hi at column c and lo = round(y - hi) at column lo_off + c (ldn >= lo_off + pad64(C))
 };
 int launch_gather_layernorm(const LnCall& c, hipStream_t stream);
 

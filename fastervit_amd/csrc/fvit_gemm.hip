@@ -38,7 +38,8 @@ struct GemmParams {
     int lda, ldw, ldo;
     int M, N, K;
     int arow_max, wrow_max;   // last valid row of the 128-row padded operands
-    int ka;       // activation columns; the contraction index k reads A column k mod ka (K = terms x ka, see GemmCall)
+    int ka;       // activation columns of one term; contraction index k reads A column (k >= ka ? k - ka : k) (K = 1, 2 or 3 x ka, see GemmCall)
+    int lo_off;   // epilogues 0 / 1: > 0 = also store the second term lo = round(y - hi) at column offset lo_off (elements) of the same row
     int tiles_m, tiles_n;
     int stagger;  // 1: workgroup (tm, tn) walks the K tiles starting at a tile-dependent offset (see gemm_kernel)
     const float* add;        // residual epilogue: optional row table added after the update (see GemmCall)
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
         rot = (tn * per + tm) % nk;
     }
     auto ktile = [&](int kt) { const int k = kt + rot; return k >= nk ? k - nk : k; };
-    auto acol = [&](int kt) { const int k = ktile(kt) * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1 or 2 x ka
+    auto acol = [&](int kt) { const int k = ktile(kt) * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1, 2 or 3 x ka: terms [hi w | lo w | hi w] meet A columns [hi | hi | lo]
     char* const xring = smem;
     char* const wring = smem + NSTAGE * XT_BYTES;
 #pragma unroll
@@ -303,13 +304,29 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float y = a[r] + bias[ni * 4 + r];
-                        if (EPI == 1) y = gelu_fast(y);
+                        if (EPI == 1) y = p.lo_off > 0 ? gelu_erf(y) : gelu_fast(y);
                         if (ni < 2) o0[ni * 4 + r] = sat16<T>(y); else o1[(ni - 2) * 4 + r] = sat16<T>(y);
                     }
                 }
                 T* po = O + (size_t)m * p.ldo + nb;
                 *(v8*)po = o0;
                 *(v8*)(po + 8) = o1;
+                if (p.lo_off > 0) {   // two-term activations (weight_terms 3): the rounding remainder as a second 16-bit term
+                    v8 l0, l1;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        f4 a = acc[cg * 4 + ni][mi];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float y = a[r] + bias[ni * 4 + r];
+                            if (EPI == 1) y = p.lo_off > 0 ? gelu_erf(y) : gelu_fast(y);
+                            const float hi = (float)(ni < 2 ? o0[ni * 4 + r] : o1[(ni - 2) * 4 + r]);
+                            if (ni < 2) l0[ni * 4 + r] = sat16<T>(y - hi); else l1[(ni - 2) * 4 + r] = sat16<T>(y - hi);
+                        }
+                    }
+                    *(v8*)(po + p.lo_off) = l0;
+                    *(v8*)(po + p.lo_off + 8) = l1;
+                }
             }
         }
     }
@@ -358,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ W = (const T*)p.W;
     const int nk = p.K / BK;
-    auto acol = [&](int kt) { const int k = kt * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1 or 2 x ka
+    auto acol = [&](int kt) { const int k = kt * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1, 2 or 3 x ka (see gemm_kernel)
     auto req_x = [&](int h, int kt, char* buf) { stage_tile<T, false, 128, 8>(A, p.lda, m0 + 128 * h, acol(kt), buf + h * HT, wave, lane, p.arow_max); };
     auto req_w = [&](int h, int kt, char* buf) { stage_tile<T, true, 128, 8>(W, p.ldw, n0 + 128 * h, kt * BK, buf + (2 + h) * HT, wave, lane, p.wrow_max); };
 
@@ -509,13 +526,29 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float y = a[r] + bias[ni * 4 + r];
-                            if (EPI == 1) y = gelu_fast(y);
+                            if (EPI == 1) y = p.lo_off > 0 ? gelu_erf(y) : gelu_fast(y);
                             if (ni < 2) o0[ni * 4 + r] = sat16<T>(y); else o1[(ni - 2) * 4 + r] = sat16<T>(y);
                         }
                     }
                     T* po = O + (size_t)m * p.ldo + nb;
                     *(v8*)po = o0;
                     *(v8*)(po + 8) = o1;
+                    if (p.lo_off > 0) {   // two-term activations: see gemm_kernel
+                        v8 l0, l1;
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const f4 a = acc[ni][mi];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float y = a[r] + bias[ni * 4 + r];
+                                if (EPI == 1) y = p.lo_off > 0 ? gelu_erf(y) : gelu_fast(y);
+                                const float hi = (float)(ni < 2 ? o0[ni * 4 + r] : o1[(ni - 2) * 4 + r]);
+                                if (ni < 2) l0[ni * 4 + r] = sat16<T>(y - hi); else l1[(ni - 2) * 4 + r] = sat16<T>(y - hi);
+                            }
+                        }
+                        *(v8*)(po + p.lo_off) = l0;
+                        *(v8*)(po + p.lo_off + 8) = l1;
+                    }
                 }
             }
         }
@@ -533,6 +566,7 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.lda = c.lda; p.ldw = c.ldw; p.ldo = c.ldo;
     p.M = c.M; p.N = c.N; p.K = c.K;
     p.ka = c.ka > 0 ? c.ka : c.K;
+    p.lo_off = c.epilogue == 2 ? 0 : c.out_lo_off;
     p.arow_max = (c.M + 127) / 128 * 128 - 1;
     p.wrow_max = (c.N + 127) / 128 * 128 - 1;
     // 256 x 256 tiles once they fill the chip (fvit_tune "gemm256_min_tiles"; 0 = never): the large Linear layers of FasterViT-4
@@ -606,7 +640,8 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
 int launch_gemm(const GemmCall& c, hipStream_t stream) {
     if (c.M <= 0 || c.N <= 0 || c.K <= 0 || (c.K % BK) != 0 || (c.N % 16) != 0 || (c.lda % 8) != 0 ||
         (c.ldw % 8) != 0 || (c.ldo % (c.epilogue == 2 ? 4 : 8)) != 0 || c.ldw < c.K ||
-        (c.ka > 0 ? (c.ka % BK != 0 || (c.K != c.ka && c.K != 2 * c.ka) || c.lda < c.ka) : c.lda < c.K)) {
+        (c.ka > 0 ? (c.ka % BK != 0 || (c.K != c.ka && c.K != 2 * c.ka && c.K != 3 * c.ka) || c.lda < (c.K == 3 * c.ka ? 2 * c.ka : c.ka)) : c.lda < c.K) ||
+        c.out_lo_off < 0 || (c.out_lo_off % 8) != 0 || (c.out_lo_off > 0 && (c.epilogue == 2 || c.out_lo_off < c.N || c.ldo < c.out_lo_off + c.N))) {
         set_error("gemm: unsupported shape M=%d N=%d K=%d lda=%d ldw=%d ldo=%d (need K%%64==0, N%%16==0)", c.M, c.N,
                   c.K, c.lda, c.ldw, c.ldo);
         return FVIT_EINVAL;

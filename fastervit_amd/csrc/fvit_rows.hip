@@ -28,6 +28,8 @@ struct LnParams {
     float eps;
     int rowsA, rowsB, ldn;
     int rows, rows_per_image, C;
+    int lw;       // columns of one term in an n_out row (pad columns C .. lw - 1 are zero-filled); = ldn unless lo_off > 0
+    int lo_off;   // > 0: second term lo = round(y - hi) at column lo_off + c (two-term activations, weight_terms 3)
 };
 
 template <typename T, int MAXV>
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnParams p) {
     const float rstd = rsqrtf(sq / (float)p.C + p.eps);
     float* xo = p.x_out ? p.x_out + (size_t)row * p.C : nullptr;
     T* no = (T*)p.n_out + (size_t)row * p.ldn;
-    const int L4 = p.ldn >> 2;
+    const int L4 = p.lw >> 2;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c4 = lane + i * 64;
@@ -90,15 +92,21 @@ __global__ __launch_bounds__(256) void ln_kernel(LnParams p) {
             if (xo) *(f4*)(xo + c4 * 4) = v[i];
             const f4 w = *(const f4*)(p.ln_w + c4 * 4);
             const f4 bb = *(const f4*)(p.ln_b + c4 * 4);
-            v4 o;
+            v4 o, l;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = sat16<T>((v[i][r] - mean) * rstd * w[r] + bb[r]);
+            for (int r = 0; r < 4; ++r) {
+                const float y = (v[i][r] - mean) * rstd * w[r] + bb[r];
+                o[r] = sat16<T>(y);
+                l[r] = sat16<T>(y - (float)o[r]);
+            }
             *(v4*)(no + c4 * 4) = o;
+            if (p.lo_off > 0) *(v4*)(no + p.lo_off + c4 * 4) = l;
         } else if (c4 < L4) {
             v4 z;
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = (T)0.f;
             *(v4*)(no + c4 * 4) = z;
+            if (p.lo_off > 0) *(v4*)(no + p.lo_off + c4 * 4) = z;
         }
     }
 }
@@ -107,10 +115,10 @@ template <typename T>
 int launch_ln_t(const LnParams& p, hipStream_t stream) {
     const int grid = (p.rows + 3) / 4;
     const int c4 = p.C / 4;
-    if (c4 <= 64 * 2 && p.ldn / 4 <= 64 * 2) hipLaunchKernelGGL((ln_kernel<T, 2>), dim3(grid), dim3(256), 0, stream, p);
-    else if (c4 <= 64 * 4 && p.ldn / 4 <= 64 * 4) hipLaunchKernelGGL((ln_kernel<T, 4>), dim3(grid), dim3(256), 0, stream, p);
-    else if (c4 <= 64 * 8 && p.ldn / 4 <= 64 * 8) hipLaunchKernelGGL((ln_kernel<T, 8>), dim3(grid), dim3(256), 0, stream, p);
-    else if (c4 <= 64 * 12 && p.ldn / 4 <= 64 * 12) hipLaunchKernelGGL((ln_kernel<T, 12>), dim3(grid), dim3(256), 0, stream, p);
+    if (c4 <= 64 * 2 && p.lw / 4 <= 64 * 2) hipLaunchKernelGGL((ln_kernel<T, 2>), dim3(grid), dim3(256), 0, stream, p);
+    else if (c4 <= 64 * 4 && p.lw / 4 <= 64 * 4) hipLaunchKernelGGL((ln_kernel<T, 4>), dim3(grid), dim3(256), 0, stream, p);
+    else if (c4 <= 64 * 8 && p.lw / 4 <= 64 * 8) hipLaunchKernelGGL((ln_kernel<T, 8>), dim3(grid), dim3(256), 0, stream, p);
+    else if (c4 <= 64 * 12 && p.lw / 4 <= 64 * 12) hipLaunchKernelGGL((ln_kernel<T, 12>), dim3(grid), dim3(256), 0, stream, p);
     else {
         set_error("layernorm: C=%d too wide (max 3072)", p.C);
         return FVIT_EINVAL;
@@ -427,7 +435,7 @@ int elem_size(int dtype) { return dtype == FVIT_F32 ? 4 : 2; }
 }  // namespace
 
 int launch_gather_layernorm(const LnCall& c, hipStream_t stream) {
-    if (c.rows <= 0 || (c.C % 4) || (c.ldn % 4) || c.ldn < c.C) {
+    if (c.rows <= 0 || (c.C % 4) || (c.ldn % 4) || c.ldn < c.C || c.lo_off < 0 || (c.lo_off % 4) || (c.lo_off > 0 && (c.lo_off < c.C || c.ldn < 2 * c.lo_off))) {
         set_error("layernorm: unsupported shape rows=%d C=%d ldn=%d", c.rows, c.C, c.ldn);
         return FVIT_EINVAL;
     }
@@ -436,6 +444,7 @@ int launch_gather_layernorm(const LnCall& c, hipStream_t stream) {
     p.x_out = c.x_out; p.n_out = c.n_out; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.eps = c.eps;
     p.rowsA = c.rowsA; p.rowsB = c.rowsB; p.ldn = c.ldn; p.rows = c.rows;
     p.rows_per_image = c.rows_per_image > 0 ? c.rows_per_image : 1; p.C = c.C;
+    p.lo_off = c.lo_off; p.lw = c.lo_off > 0 ? c.lo_off : c.ldn;
     const double bytes = (double)c.rows * c.C * (4.0 + (c.x_out ? 4.0 : 0.0) + 2.0);
     ProfScope prof(FVIT_K_LAYERNORM, 8.0 * c.rows * (double)c.C, bytes, stream);
     prof_note("ln_kernel", (c.rows + 3) / 4);

@@ -33,8 +33,13 @@ from ._lib import (FVIT_BF16, FVIT_F16, FVIT_F32, FVIT_MASK_BIAS, FVIT_TILE_K, F
 _DT = {torch.float32: FVIT_F32, torch.float16: FVIT_F16, torch.bfloat16: FVIT_BF16}
 # operand modes: (MFMA operand code, torch dtype, weight terms).  "x2" = every Linear weight packed as TWO 16-bit terms
 # (hi = round(w), lo = round(w - hi); FvitStageDesc.weight_terms): the route to logits max-abs < 1e-3 with bf16 operands.
+# "x3" (r04) = two-term weights AND two-term activations (every Linear layer hi.hi + hi.lo + lo.hi, the attention core on two-term
+# q / k / v / P, exact-erf GELU): ~22 significant bits through the HAT stages -- the route to logits max-abs < 1e-3 ABSOLUTE on
+# FasterViT-4 / any-res, whose logits reach |7| (the single rounding of the fp16 activations alone is ~1e-3 there).  Runs the
+# unfused kernel chain (LayerNorm, GEMM, attention) with three times the MFMA work.
 _OP = {"f16": (FVIT_F16, torch.float16, 1), "bf16": (FVIT_BF16, torch.bfloat16, 1),
-       "f16x2": (FVIT_F16, torch.float16, 2), "bf16x2": (FVIT_BF16, torch.bfloat16, 2)}
+       "f16x2": (FVIT_F16, torch.float16, 2), "bf16x2": (FVIT_BF16, torch.bfloat16, 2),
+       "f16x3": (FVIT_F16, torch.float16, 3), "bf16x3": (FVIT_BF16, torch.bfloat16, 3)}
 OPERAND_MODES = tuple(_OP)
 
 
@@ -129,10 +134,15 @@ class _Keep:
         if self.terms == 1:
             return hi.contiguous()
         lo = (w - hi.float()).to(self.op_dtype)
+        if self.terms == 3:   # [hi | lo | hi]: met by activation columns [hi | hi | lo] (GemmCall.ka, csrc/fvit_gemm.hip)
+            return torch.cat([hi, lo, hi], dim=dim).contiguous()
         return torch.cat([hi, lo], dim=dim).contiguous()
 
-    def frag16(self, w: torch.Tensor) -> torch.Tensor:
-        """fragment-order image(s): [hi image | lo image] back to back."""
+    def frag16(self, w: torch.Tensor) -> Optional[torch.Tensor]:
+        """fragment-order image(s): [hi image | lo image] back to back.  None with 3 terms: the fused kernels that stream
+        fragment-order weights take one- and two-term weights only (the x3 modes run the LayerNorm / GEMM / attention chain)."""
+        if self.terms == 3:
+            return None
         return self.op16(w.reshape(1, -1), dim=0).reshape(-1)
 
     def ptr(self, t: Optional[torch.Tensor], op16: bool = False) -> Optional[int]:
@@ -403,11 +413,12 @@ def workspace_slot(slot: int):
 
 
 def _workspace(st: StageState, desc_common: dict, B: int, H: int, W: int, device) -> _Workspace:
-    # (the workspace LAYOUT does not depend on the weight terms -- activations are single-rounded in every mode -- but the
-    # descriptor carries them: one scratch buffer per key, one descriptor per weight-term count)
-    key = (B, desc_common["Hp"], desc_common["Wp"], H, W, desc_common["operand_dtype"], _slot())
-    hit = st.workspaces.get(key)
+    # (the workspace LAYOUT is the same for one- and two-term weights -- activations are single-rounded there -- but the descriptor
+    # carries the terms: one scratch buffer per key, one descriptor per weight-term count; the x3 modes hold two-term activation
+    # rows and get their own buffer)
     terms = desc_common["weight_terms"]
+    key = (B, desc_common["Hp"], desc_common["Wp"], H, W, desc_common["operand_dtype"], _slot()) + (("x3",) if terms == 3 else ())
+    hit = st.workspaces.get(key)
     if hit is not None:
         d = hit.descs.get(terms)
         if d is None:
@@ -534,8 +545,8 @@ def is_prepared(layer, device, batch: Optional[int] = None, hw=None, slots=(0,))
     Hp, Wp = H + (ws - H % ws) % ws, W + (ws - W % ws) % ws
     if (Hp, Wp) not in st.tables:
         return False
-    op_code = _OP[op_name][0]
-    return all((batch, Hp, Wp, H, W, op_code, s) in st.workspaces for s in slots)
+    op_code, _, terms = _OP[op_name]
+    return all(((batch, Hp, Wp, H, W, op_code, s) + (("x3",) if terms == 3 else ())) in st.workspaces for s in slots)
 
 
 def stage_forward(layer, x: torch.Tensor, tokenizer=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

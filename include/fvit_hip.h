@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FVIT_ABI_VERSION 5
+#define FVIT_ABI_VERSION 6
 
 /* error codes */
 #define FVIT_OK 0
@@ -80,7 +80,11 @@ typedef struct FvitStageDesc {
                                (K-concatenated; the kernels wrap the activation column at ldk), fragment-order arrays as two images back
                                to back [hi image | lo image].  Activations stay single-rounded: the logits error of this path is dominated
                                by the SYSTEMATIC weight rounding (identical for every token, it survives the average pool), not by the
-                               per-token activation rounding. */
+                               per-token activation rounding.
+                               3 ("f16x3" / "bf16x3", r04): weights as [hi | lo | hi] (K-concatenated) AND every 16-bit activation
+                               (LayerNorm output, q / k / v, attention output, GELU(fc1)) as two terms [hi | lo] in its workspace row:
+                               each Linear layer is hi.hi + hi.lo + lo.hi, the attention core runs on two-term q, k, v, P.  Only the
+                               unfused kernel chain (LayerNorm, GEMM, attention) takes this mode; three times the MFMA work. */
 } FvitStageDesc;
 
 /* One attention sub-block: LayerNorm -> qkv -> softmax(q k^T * scale + bias) v -> proj -> gamma-residual.
@@ -227,6 +231,27 @@ int fvit_gemm_residual(int32_t operand_dtype, const void* A, int32_t lda, const 
  * 2 gamma-residual into f32 out (gamma may be NULL = 1).  With K == ka this is fvit_gemm_bias_act / fvit_gemm_residual. */
 int fvit_gemm_terms(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias, const float* gamma,
                     void* out, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t ka, int32_t epilogue, fvit_stream_t stream);
+/* Two-term ACTIVATIONS (FvitStageDesc.weight_terms = 3, the "x3" operand modes; r04).  A 16-bit activation row holds two images
+ * [hi | lo], lo = round(y - hi) at column offset *_lo_off of the same row, so that hi + lo carries ~22 significant bits:
+ *   fvit_gather_layernorm_terms   fvit_gather_layernorm whose n_out rows are [hi | lo] (ldn >= 2 * lo_off, lo_off >= pad(C));
+ *   fvit_gemm_terms_lo            fvit_gemm_terms with K = 3 * ka allowed: weights [hi | lo | hi] against activation columns
+ *                                 [hi | hi | lo] (A is [..][lda >= 2 * ka]) = hi.hi + hi_a.lo_w + lo_a.hi_w, the lo.lo product dropped;
+ *                                 out_lo_off > 0 (epilogues 0 / 1): the output is stored as two terms too; GELU then uses the
+ *                                 1.5e-7-accurate erf instead of the 5e-5 polynomial;
+ *   fvit_window_attention_terms   fvit_window_attention on two-term q / k / v (scores qh.kh + qh.kl + ql.kh; P and V as two terms in
+ *                                 registers / LDS), output rows [hi | lo].  Dense windows only (fvit_attention_dense).
+ * The reference computes these in fp32 (FV:557-568, 398-407); this is the route to logits max-abs < 1e-3 ABSOLUTE on the deep /
+ * wide variants whose logits reach |7|. */
+int fvit_gemm_terms_lo(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias, const float* gamma,
+                       void* out, int32_t ldo, int32_t out_lo_off, int32_t M, int32_t N, int32_t K, int32_t ka, int32_t epilogue,
+                       fvit_stream_t stream);
+int fvit_window_attention_terms(int32_t operand_dtype, const void* qkv, int32_t ldq, int32_t q_lo_off, void* out, int32_t ldo,
+                                int32_t o_lo_off, const float* bias, int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale,
+                                fvit_stream_t stream);
+int fvit_gather_layernorm_terms(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB,
+                                const int32_t* src_idx, const int32_t* add_idx, const float* add, float* x_out, void* n_out, int32_t ldn,
+                                int32_t lo_off, const float* ln_w, const float* ln_b, float eps, int32_t rows, int32_t rows_per_image,
+                                int32_t C, fvit_stream_t stream);
 /* Windowed multi-head attention core on packed qkv (op16 [rows][ldq], columns [q|k|v][head][dpad]):
  * out (op16 [rows][ldo], columns [head][dpad]) = softmax(q k^T * scale + bias) v per (window, head).
  * S tokens per window (rows w*S .. w*S+S-1), bias f32 [heads][Spad][Spad] as in FvitAttnWeights. */

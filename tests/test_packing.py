@@ -74,7 +74,8 @@ def test_two_term_weight_packing_reconstructs_the_weights():
 
 def test_operand_modes_table():
     from fastervit_amd import hat_runtime, _lib
-    assert set(hat_runtime.OPERAND_MODES) == {"f16", "bf16", "f16x2", "bf16x2"}
+    assert set(hat_runtime.OPERAND_MODES) == {"f16", "bf16", "f16x2", "bf16x2", "f16x3", "bf16x3"}
+    assert hat_runtime._OP["f16x3"][2] == 3
     assert hat_runtime._OP["bf16x2"][0] == _lib.FVIT_BF16 and hat_runtime._OP["bf16x2"][2] == 2
     assert hat_runtime._OP["f16"][2] == 1
 
@@ -92,3 +93,28 @@ def test_conv128_fragment_stream_follows_its_documented_element_mapping():
         g, s = lane >> 4, lane & 15
         assert f[wave, step, ni, lane, e].item() == w[32 * wave + (s >> 2) * 8 + ni * 4 + (s & 3), step * 32 + 8 * g + e].item()
     assert torch.equal(torch.sort(f.reshape(-1)).values, w.reshape(-1))
+
+
+def test_three_term_packing_and_the_gemm_column_map():
+    """x3 modes (FvitStageDesc.weight_terms = 3): weight rows are packed [hi | lo | hi]; the GEMM reads activation column
+    (k >= ka ? k - ka : k) of a [hi | lo] row, i.e. segments [hi | hi | lo] -- together hi.hi + a_hi.w_lo + a_lo.w_hi.  Fragment-order
+    images (fused kernels) are not produced in this mode."""
+    from fastervit_amd import hat_runtime
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(7, 64, generator=g) * 0.05
+    a = torch.randn(3, 64, generator=g)
+    keep = hat_runtime._Keep(torch.float16, 3)
+    wp = keep.op16(w)
+    assert tuple(wp.shape) == (7, 192) and keep.frag16(w) is None
+    hi = w.half()
+    lo = (w - hi.float()).half()
+    assert torch.equal(wp[:, :64], hi) and torch.equal(wp[:, 64:128], lo) and torch.equal(wp[:, 128:], hi)
+    ah = a.half()
+    al = (a - ah.float()).half()
+    arow = torch.cat([ah, al], dim=1).float()                      # the [hi | lo] activation row
+    k = torch.arange(192)
+    acol = torch.where(k >= 64, k - 64, k)                          # csrc/fvit_gemm.hip: acol
+    y = arow[:, acol] @ wp.float().t()
+    exact = a.double() @ w.double().t()
+    single = ah.float() @ hi.float().t()
+    assert (y.double() - exact).abs().max() < 2e-6 < (single.double() - exact).abs().max()
