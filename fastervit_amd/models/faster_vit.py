@@ -431,13 +431,18 @@ class FasterViT(nn.Module):
     def set_hat_operand_dtype(self, name: str):
         """Choose the operand mode of the HAT kernels (fp32 accumulate): 'f16' (default) or 'bf16' -- 16-bit operands rounded once --
         or 'f16x2' / 'bf16x2' -- every Linear weight as two 16-bit terms hi + lo (twice the MFMA work on the weights' side; the
-        route to logits max-abs < 1e-3 with bf16 operands)."""
+        route to logits max-abs < 1e-3 with bf16 operands) -- or 'f16x3' / 'bf16x3' -- weights AND activations
+        as two terms (three times the MFMA work, unfused kernel chain): ~22 significant bits through the HAT stages, the route to
+        logits max-abs < 1e-3 ABSOLUTE on FasterViT-4 / any-res (measured 2.6e-5 on |7.1| with the fp32 conv side)."""
         from ..hat_runtime import OPERAND_MODES
         if name not in OPERAND_MODES:
             raise ValueError(f"operand mode must be one of {OPERAND_MODES}")
         self.hat_operand_dtype = name
         for lvl in self.levels:
             lvl.hat_operand_dtype = name
+            if lvl.transformer_block:
+                for blk in lvl.blocks:   # the block-level API (HAT.forward -> hat_runtime.block_forward) reads the mode from the block
+                    blk.hat_operand_dtype = name
         return self
 
     def switch_to_deploy(self, dtype=torch.float16, streams=1):

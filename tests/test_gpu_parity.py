@@ -157,7 +157,14 @@ def test_fvit4_224_logits_vs_reference():
         logits = model(case_input("fvit4_224").cuda()).float().cpu()
     err = max_abs(logits, g["logits"])
     print(f"faster_vit_4_224 logits max-abs err {err:.3e} (|logits| max {np.abs(g['logits']).max():.3f})")
+    # the FAST mode (16-bit operands rounded once) is claimed RELATIVE on this model (|logits| 7): ~5e-3 absolute, above north_star's absolute 1e-3 --
+    # which the x3 modes meet with margin (asserted absolute in the second half of this test and in tests/test_gpu_x3.py)
     assert err < 1e-3 * max(np.abs(g["logits"]).max(), 1.0)
+    model.set_hat_operand_dtype("f16x3")
+    with torch.no_grad():
+        err3 = max_abs(model(case_input("fvit4_224").cuda()).float().cpu(), g["logits"])
+    print(f"faster_vit_4_224 f16x3 logits max-abs err {err3:.3e} ABSOLUTE")
+    assert err3 < 2e-4   # north_star: < 1e-3; measured 2.6e-5
 
 
 @pytest.mark.parametrize("name", ["fvit4_21k_384", "fvit4_21k_768"])
@@ -217,7 +224,12 @@ def test_fvit4_anyres_576x960_logits_vs_reference():
         logits = model(case_input("fvit4_anyres_576x960").cuda()).float().cpu()
     err = max_abs(logits, g["logits"])
     print(f"faster_vit_4_any_res 576x960 logits max-abs err {err:.3e} (|logits| max {np.abs(g['logits']).max():.3f})")
-    assert err < 1e-3 * max(np.abs(g["logits"]).max(), 1.0)
+    assert err < 1e-3 * max(np.abs(g["logits"]).max(), 1.0)   # fast mode: relative claim (see test_fvit4_224_logits_vs_reference)
+    model.set_hat_operand_dtype("f16x3")
+    with torch.no_grad():
+        err3 = max_abs(model(case_input("fvit4_anyres_576x960").cuda()).float().cpu(), g["logits"])
+    print(f"faster_vit_4_any_res 576x960 f16x3 logits max-abs err {err3:.3e} ABSOLUTE")
+    assert err3 < 2e-4   # north_star: < 1e-3; measured 2.4e-5
 
 
 def test_batch_256_properties():

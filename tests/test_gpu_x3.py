@@ -204,13 +204,12 @@ def test_long_windows_reject_x3_loudly():
         model(case_input("tiny_21k_384").cuda())
 
 
-@pytest.mark.parametrize("case,mode,tol", [("fvit0_224", "f16x3", 1e-4), ("fvit0_224", "bf16x3", 4e-4), ("fvit4_224", "f16x3", 4e-4),
-                                           ("fvit4_anyres_576x960", "f16x3", 4e-4)])
+@pytest.mark.parametrize("case,mode,tol", [("fvit0_224", "f16x3", 1e-4), ("fvit0_224", "bf16x3", 4e-4), ("fvit4_224", "f16x3", 2e-4),
+                                           ("fvit4_anyres_576x960", "f16x3", 2e-4)])
 def test_x3_module_mode_logits_absolute(case, mode, tol):
     """north_star tolerance, ABSOLUTE (logits max-abs < 1e-3) on all three single-GPU BASELINE configurations, with margin: module mode
     (fp32 conv side) + x3 HAT stages.  faster_vit_4_224 / any-res reach |logits| 7 with the gamma ~ U(0.5, 1.5) test weights; simulated
-    2.2e-5 for the HAT roundings alone (precision_sim), the rest is the fp32 summation order of the conv side and the erf / exp
-    approximations."""
+    2.2e-5 for the HAT roundings alone (precision_sim); measured 2.6e-5 / 2.4e-5 on the 8 bench images of faster_vit_4_224 / any-res."""
     g = load_golden(case)
     model, _ = build_product_model(case, "cuda")
     x = case_input(case).cuda()
