@@ -393,11 +393,51 @@ def _acc_grad(param, g: torch.Tensor) -> None:
         param.grad = g.clone() if param.grad is None else param.grad + g
 
 
-def local_stage_backward(layer, x: torch.Tensor, dy: torch.Tensor, operand_dtype=torch.float16) -> torch.Tensor:
+def _emit(sink: Optional[dict], param, g: torch.Tensor) -> None:
+    """Hand one parameter gradient over: into ``sink`` (param -> fp32 gradient; the autograd bridge returns these to the engine, so that
+    DistributedDataParallel's reducer and post-accumulate hooks fire exactly once, from the OUTER backward) or, for the direct callers of the
+    ``*_stage_backward`` functions (sink None), accumulated into ``.grad``."""
+    if not (isinstance(param, torch.nn.Parameter) and param.requires_grad):
+        return
+    if sink is None:
+        _acc_grad(param, g)
+        return
+    g = g.detach().float().reshape(param.shape)
+    sink[param] = g.clone() if param not in sink else sink[param] + g
+
+
+def _module_params(mods):
+    seen, out = set(), []
+    for m in mods:
+        if m is None:
+            continue
+        for prm in m.parameters():
+            if prm.requires_grad and id(prm) not in seen:
+                seen.add(id(prm))
+                out.append(prm)
+    return out
+
+
+def _table_grads(sink: Optional[dict], outs, gouts, mods) -> None:
+    """Gradients of the folded tables continue into the small MLPs behind them (PosEmbMLPSwinv1D / PosEmbMLPSwinv2D, FV:213-367) with
+    ``torch.autograd.grad`` -- NOT ``torch.autograd.backward``: a nested backward would run the parameters' AccumulateGrad nodes (and with them
+    DDP's reducer hooks) from inside the outer backward, once on a partial gradient and again from the outer pass."""
+    live = [(o, g) for o, g in zip(outs, gouts) if o is not None and g is not None and o.requires_grad]
+    params = _module_params(mods)
+    if not live or not params:
+        return
+    gs = torch.autograd.grad([o for o, _ in live], params, [g.to(o.dtype) for o, g in live], allow_unused=True)
+    for prm, g in zip(params, gs):
+        if g is not None:
+            _emit(sink, prm, g)
+
+
+def local_stage_backward(layer, x: torch.Tensor, dy: torch.Tensor, operand_dtype=torch.float16, sink: Optional[dict] = None) -> torch.Tensor:
     """Backward of the transformer branch of a FasterViTLayer WITHOUT carrier tokens (FasterViTLayer.forward FV:832-841 with only-local HAT blocks: stage 3
     of FasterViT-0) -- window_partition, depth x HAT block, window_reverse -- for the module's own parameters:
 
       x, dy: (B, C, H, W) fp32 maps (H, W multiples of the window size);  returns dx and ADDS every parameter gradient of ``layer.blocks`` into ``.grad``
+      (``sink`` None) or into the dict ``sink`` (param -> gradient; nothing is written to ``.grad`` then: the autograd bridge below)
       (norm1 / norm2, attn.qkv / attn.proj, mlp.fc1 / fc2, gamma3 / gamma4 when they are parameters, and -- through the modules' differentiable ``table()``
       functions on the host -- the cpb_mlp of the relative-position bias and of the 1-D position embedding, from the table gradients the kernels return).
 
@@ -452,9 +492,9 @@ def local_stage_backward(layer, x: torch.Tensor, dy: torch.Tensor, operand_dtype
                        (blk.norm2.bias, mg.ln_b), (blk.mlp.fc1.weight, mg.fc1_w), (blk.mlp.fc1.bias, mg.fc1_b), (blk.mlp.fc2.weight, mg.fc2_w),
                        (blk.mlp.fc2.bias, mg.fc2_b), (blk.gamma4, mg.gamma)):
             if g is not None:
-                _acc_grad(prm, g)
+                _emit(sink, prm, g)
         # the folded tables are functions of small MLPs: their gradients continue on the host through the modules' own table() code
-        torch.autograd.backward([bias_t, pe_t], [ag.bias.to(bias_t.dtype), d.view(-1, S, C_).sum(0).to(pe_t.dtype)])
+        _table_grads(sink, [bias_t, pe_t], [ag.bias, d.view(-1, S, C_).sum(0)], [blk.attn.pos_emb_funct, blk.pos_embed])
     return reverse(d)
 
 
@@ -486,7 +526,7 @@ def hier_block_forward(x: torch.Tensor, ct: torch.Tensor, hat_attn: dict, hat_ml
     return y2[:, ncw:].contiguous(), y2[:, :ncw].reshape(B, G, C_).contiguous()
 
 
-def hier_stage_backward(layer, x: torch.Tensor, dy: torch.Tensor, operand_dtype=torch.float16) -> torch.Tensor:
+def hier_stage_backward(layer, x: torch.Tensor, dy: torch.Tensor, operand_dtype=torch.float16, sink: Optional[dict] = None) -> torch.Tensor:
     """Backward of the transformer branch of a FasterViTLayer WITH carrier tokens (FasterViTLayer.forward FV:832-841: TokenInitializer, window_partition,
     depth x hierarchical HAT block, window_reverse; stage 2 of FasterViT-0 / 1 / 2: ``do_propagation`` off, map an exact multiple of the window):
     returns dx (B, C, H, W) and ADDS the gradient of every parameter of ``layer.blocks`` and ``layer.global_tokenizer`` into ``.grad``.
@@ -552,22 +592,27 @@ def hier_stage_backward(layer, x: torch.Tensor, dy: torch.Tensor, operand_dtype=
             for prm, g in ((norm.weight, gr.ln_w), (norm.bias, gr.ln_b), (at.qkv.weight, gr.qkv_w), (at.qkv.bias, gr.qkv_b), (at.proj.weight, gr.proj_w),
                            (at.proj.bias, gr.proj_b), (blk.gamma1 if key == "hat_attn" else blk.gamma3, gr.gamma)):
                 if g is not None:
-                    _acc_grad(prm, g)
+                    _emit(sink, prm, g)
         for key, norm, ml in (("hat_mlp", blk.hat_norm2, blk.hat_mlp), ("mlp", blk.norm2, blk.mlp)):
             gr = grads[key]
             for prm, g in ((norm.weight, gr.ln_w), (norm.bias, gr.ln_b), (ml.fc1.weight, gr.fc1_w), (ml.fc1.bias, gr.fc1_b), (ml.fc2.weight, gr.fc2_w),
                            (ml.fc2.bias, gr.fc2_b), (blk.gamma2 if key == "hat_mlp" else blk.gamma4, gr.gamma)):
                 if g is not None:
-                    _acc_grad(prm, g)
+                    _emit(sink, prm, g)
         # folded tables -> their small MLPs (host autograd): d pe_x = sum over windows of dx, d pe_ct = sum over images of the dewindowed carrier gradient
         outs, gouts = [t["bias"], t["hat_bias"], t["pe_x"]], [grads["attn"].bias, grads["hat_attn"].bias, d.sum(0)]
         if t["pe_ct"] is not None:
             outs.append(t["pe_ct"])
             gouts.append(dct[:, dew].sum(0))
-        torch.autograd.backward(outs, [g_.to(o.dtype) for o, g_ in zip(outs, gouts)])
-    # ---- the carrier tokens came from the tokenizer: its conv parameters and its share of dx ----
-    torch.autograd.backward([ct_init], [dct.to(ct_init.dtype)])
-    return reverse(d) + x_leaf.grad
+        _table_grads(sink, outs, gouts, [blk.attn.pos_emb_funct, blk.hat_attn.pos_emb_funct, blk.pos_embed, getattr(blk, "hat_pos_embed", None)])
+    # ---- the carrier tokens came from the tokenizer: its conv parameters and its share of dx (autograd.grad: no .grad is touched) ----
+    tok_params = _module_params([layer.global_tokenizer])
+    gs = torch.autograd.grad([ct_init], tok_params + [x_leaf], [dct.to(ct_init.dtype)], allow_unused=True)
+    for prm, g in zip(tok_params, gs[:-1]):
+        if g is not None:
+            _emit(sink, prm, g)
+    dx_tok = gs[-1]
+    return reverse(d) + (dx_tok if dx_tok is not None else 0)
 
 
 # --------------------------------------------------------------------------------------------------------------------------------------
@@ -584,10 +629,57 @@ def _stage_params(layer):
     return out
 
 
+def operand_torch_dtype(layer) -> torch.dtype:
+    """16-bit operand type of the backward kernels for this layer: the type of its forward operand mode (``hat_operand_dtype``; the two- and
+    three-term modes recompute and differentiate with single 16-bit terms of the same type)."""
+    return torch.bfloat16 if str(getattr(layer, "hat_operand_dtype", "f16")).startswith("bf16") else torch.float16
+
+
+def backward_unsupported_reason(layer, H: Optional[int] = None, W: Optional[int] = None) -> Optional[str]:
+    """None if the kernel-sequence backward covers this stage (and, when given, this map size); otherwise the reason, as text.  Checked at FORWARD
+    time (``stage_forward_with_grad``) and by ``FasterViT.enable_hat_backward``: a stage that cannot be differentiated must not fail from inside
+    ``loss.backward()`` on the autograd engine's thread after a forward that succeeded."""
+    blocks = list(layer.blocks)
+    if not blocks:
+        return None
+    b0 = blocks[0]
+    C_, heads = b0.attn.qkv.in_features, b0.attn.num_heads
+    hid = b0.mlp.fc1.out_features
+    ws = b0.window_size
+    hier = bool(b0.do_sr_hat)
+    if C_ % heads or C_ // heads != 32:
+        return f"head_dim {C_ // heads} (the attention-core backward kernel is built for head_dim 32: FasterViT-0's geometry)"
+    if C_ % 64 or hid % 64:
+        return f"C = {C_} / hidden = {hid} are not multiples of 64"
+    if any(bool(b.do_sr_hat) != hier for b in blocks):
+        return "mixed hierarchical / local blocks in one stage"
+    if hier and any(b.do_propagation for b in blocks):
+        return "last-block carrier-token propagation (FasterViT-3 ... 6) has no backward"
+    ncw = b0.cr_window ** 2 if hier else 0
+    if ws * ws + ncw > 64:
+        return f"windows of {ws * ws + ncw} tokens (the attention-core backward holds at most 64 in LDS)"
+    if hier:
+        sr = tuple(b0.sr_ratio)
+        if ncw * sr[0] * sr[1] > 64:
+            return f"{ncw * sr[0] * sr[1]} carrier tokens per image (at most 64)"
+        if H is not None and (H % ws or W % ws or (H // ws, W // ws) != sr):
+            return f"map {H}x{W} does not tile exactly into the stage's {sr[0]}x{sr[1]} windows of {ws} (padded stages have no backward)"
+    elif H is not None and (H % ws or W % ws):
+        return f"map {H}x{W} is not a multiple of the window size {ws} (padded stages have no backward)"
+    if any(getattr(m, "p", 0.0) > 0 for m in layer.blocks.modules() if isinstance(m, torch.nn.Dropout)):
+        return "Dropout with p > 0 inside the HAT blocks"
+    return None
+
+
 class HatStageFunction(torch.autograd.Function):
     """y = FasterViTLayer transformer branch (x) with the module's parameters as differentiable inputs.  Forward = the HIP inference path (eval semantics:
     DropPath / Dropout are identities -- train with drop_path = 0 or accept that); backward = local_stage_backward / hier_stage_backward, whose parameter
-    gradients are handed back to autograd (so hooks such as DistributedDataParallel's fire) instead of being written into .grad."""
+    gradients are collected in a dict and RETURNED to autograd (so hooks such as DistributedDataParallel's fire once, from the outer engine); neither
+    ``.grad`` nor any AccumulateGrad node is touched from inside this backward (tables and tokenizer: ``torch.autograd.grad``).
+
+    fp16 operands: every gradient inside the kernel sequence (dz, dO, dqkv, dh, da and their transposes) is narrowed to 16 bits.  The backward is linear
+    in dy, so dy is scaled by a power of two that brings its largest entry to ~2^10 and dx / the parameter gradients are scaled back in fp32: a mean-reduced
+    loss (dy ~ 1e-6) or a 1e-5 layer scale would otherwise sit in or below the fp16 subnormals (spacing 6e-8).  bf16 operands need no scaling."""
 
     @staticmethod
     def forward(ctx, x, layer, operand_dtype, *params):
@@ -600,24 +692,39 @@ class HatStageFunction(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         layer, params = ctx.layer, ctx.params
-        saved = [prm.grad for prm in params]
+        dy32 = dy.float().contiguous()
+        inv = None
+        if ctx.operand_dtype == torch.float16:
+            amax = dy32.abs().amax().clamp_min(1e-30)
+            scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax)))   # 0-dim tensor on the device: no host synchronisation
+            dy32 = dy32 * scale
+            inv = 1.0 / scale
+        sink: dict = {}
+        fn = hier_stage_backward if layer.blocks[0].do_sr_hat else local_stage_backward
+        dx = fn(layer, x.float().contiguous(), dy32, ctx.operand_dtype, sink=sink)
+        if inv is not None:
+            dx = dx * inv
+        grads = []
         for prm in params:
-            prm.grad = None
-        try:
-            fn = hier_stage_backward if layer.blocks[0].do_sr_hat else local_stage_backward
-            dx = fn(layer, x.float().contiguous(), dy.float().contiguous(), ctx.operand_dtype)
-            grads = [prm.grad for prm in params]
-        finally:
-            for prm, g0 in zip(params, saved):
-                prm.grad = g0
+            g = sink.get(prm)
+            if g is not None and inv is not None:
+                g = g * inv
+            grads.append(None if g is None else g.to(prm.dtype))
         return (dx.to(x.dtype), None, None, *grads)
 
 
-def stage_forward_with_grad(layer, x: torch.Tensor, operand_dtype=torch.float16) -> torch.Tensor:
-    """``hat_runtime.stage_forward`` as a differentiable op (see HatStageFunction).  The layer must be in eval mode (the HIP path has eval semantics)."""
+def stage_forward_with_grad(layer, x: torch.Tensor, operand_dtype=None) -> torch.Tensor:
+    """``hat_runtime.stage_forward`` as a differentiable op (see HatStageFunction).  The layer must be in eval mode (the HIP path has eval semantics).
+    ``operand_dtype`` None = the 16-bit type of the layer's forward operand mode.  Unsupported geometries raise HERE, at forward time."""
     if layer.training:
         raise RuntimeError("stage_forward_with_grad: keep the HAT stages in eval mode (forward kernels have eval semantics: no DropPath / Dropout); "
                            "BatchNorm lives on the conv side and is not affected")
     if len(layer.blocks) == 0:
         return x
+    why = backward_unsupported_reason(layer, x.shape[2], x.shape[3])
+    if why is not None:
+        raise RuntimeError(f"stage_forward_with_grad: this HAT stage has no kernel-sequence backward: {why}. Run it forward-only under torch.no_grad() "
+                           "(model.enable_hat_backward(False)).")
+    if operand_dtype is None:
+        operand_dtype = operand_torch_dtype(layer)
     return HatStageFunction.apply(x, layer, operand_dtype, *_stage_params(layer))

@@ -369,9 +369,18 @@ class FasterViTLayer(nn.Module):
     def forward(self, x):
         if self.transformer_block:
             from .. import hat_runtime
-            if self.__dict__.get("hat_backward", False) and torch.is_grad_enabled() and x.is_cuda:
+            want_grad = torch.is_grad_enabled() and x.is_cuda and not self.training
+            if want_grad and self.__dict__.get("hat_backward", False):
                 from .. import hat_backward   # the stage as one autograd node: HIP forward, kernel-sequence backward (FasterViT.enable_hat_backward)
-                x = hat_backward.stage_forward_with_grad(self, x)
+                x = hat_backward.stage_forward_with_grad(self, x)   # raises HERE (forward time) if the geometry has no backward
+            elif want_grad and x.requires_grad and not x.is_leaf and len(self.blocks):
+                # eval-mode forward without torch.no_grad(): the stage input carries a graph (the conv side's parameters require grad).  Where the
+                # kernel-sequence backward covers the stage the gradient flows (PyTorch's own behaviour); elsewhere hat_runtime warns and detaches.
+                from .. import hat_backward
+                if hat_backward.backward_unsupported_reason(self, x.shape[2], x.shape[3]) is None:
+                    x = hat_backward.stage_forward_with_grad(self, x)
+                else:
+                    x = hat_runtime.stage_forward(self, x)
             else:
                 x = hat_runtime.stage_forward(self, x)
         else:
@@ -458,7 +467,16 @@ class FasterViT(nn.Module):
         self.__dict__["_deploy_plan"] = plan
         return self
 
+    def _check_grad_request(self, x):
+        if x.is_cuda and not self.training and torch.is_grad_enabled() and x.requires_grad:
+            from .. import hat_backward
+            from ..hat_runtime import check_user_input
+            for lvl in self.levels:   # d/dx through every HAT stage, or an error -- never a silently cut gradient
+                if lvl.transformer_block and len(lvl.blocks) and hat_backward.backward_unsupported_reason(lvl) is not None:
+                    check_user_input(x)
+
     def forward_features(self, x):
+        self._check_grad_request(x)
         x = self.patch_embed(x)
         for level in self.levels:
             x = level(x)
@@ -508,8 +526,15 @@ class FasterViT(nn.Module):
     def enable_hat_backward(self, on: bool = True):
         """Make the transformer stages differentiable: with the model in eval mode (HAT stages have eval semantics; BatchNorm uses its running statistics)
         and grad enabled, every HAT stage becomes ONE autograd node whose forward is the HIP inference path and whose backward is the kernel sequence of
-        ``fastervit_amd.hat_backward`` (stages without last-block propagation whose maps tile exactly into windows: FasterViT-0 / 1 / 2 at their native
-        resolution).  The conv stages, norms and head are ordinary PyTorch modules and differentiate as usual.  Off by default: inference-only."""
+        ``fastervit_amd.hat_backward`` (head_dim 32, windows and carrier grids of at most 64 tokens, no last-block propagation, maps that tile exactly
+        into windows: FasterViT-0's geometry; other variants raise here, and a map size that does not tile raises at forward time).  The conv stages, norms and head are ordinary PyTorch modules and differentiate as usual.  Off by default: inference-only."""
+        if on:
+            from .. import hat_backward
+            for i, lvl in enumerate(self.levels):
+                if lvl.transformer_block and len(lvl.blocks):
+                    why = hat_backward.backward_unsupported_reason(lvl)
+                    if why is not None:
+                        raise RuntimeError(f"enable_hat_backward: level {i} of this model has no kernel-sequence backward: {why}")
         self.__dict__["hat_backward"] = bool(on)
         for lvl in self.levels:
             if lvl.transformer_block:
@@ -517,13 +542,14 @@ class FasterViT(nn.Module):
         return self
 
     def forward(self, x):
-        if x.is_cuda and not self.training and not (self.__dict__.get("hat_backward", False) and torch.is_grad_enabled()):
-            from ..hat_runtime import check_user_input
-            check_user_input(x)   # eval on the GPU = forward-only HIP stages: a caller asking for d/dx gets an error, not zeros
+        self._check_grad_request(x)   # eval on the GPU, forward-only HIP stages: a caller asking for d/dx gets the gradient or an error, not zeros
         plan = self.__dict__.get("_deploy_plan")
         # nn.DataParallel replicas share __dict__ with the original: the plan's folded weights live on the original's device, so
         # replicas run the module path (per-device HAT state in hat_runtime)
         if plan is not None and x.is_cuda and not self.training and not getattr(self, "_is_replica", False):
+            if torch.is_grad_enabled() and (self.__dict__.get("hat_backward", False) or x.requires_grad):
+                raise RuntimeError("FasterViT: the deploy plan (folded BatchNorm, 16-bit conv kernels) is inference-only and returns detached logits; "
+                                   "call it under torch.no_grad(), or switch_to_deploy(None) to differentiate through the module path")
             return plan.forward(x)
         auto = self._autocast_plan(x)
         if auto is not None:

@@ -11,6 +11,10 @@ from fastervit_amd import _lib, hat_backward
 
 pytestmark = pytest.mark.gpu
 
+# per-tensor bound of the whole-model gradient tests: max-abs error of a parameter gradient relative to that gradient's largest entry (fp16 operands,
+# eleven HAT blocks deep; with the power-of-two scaling of dy inside the autograd bridge no tensor sits in the fp16 subnormals any more)
+PER_TENSOR = 4e-2
+
 
 def _reference(x, dy, lnw, lnb, w1, b1, w2, b2, gamma):
     ps = [t.clone().requires_grad_(True) for t in (x, lnw, lnb, w1, b1, w2, b2)] + ([gamma.clone().requires_grad_(True)] if gamma is not None else [])
@@ -315,9 +319,8 @@ def test_whole_model_gradients_through_the_hip_hat_stages_vs_oracle_autograd():
     torch.cuda.synchronize()
     err, scale = (xg.grad.cpu() - xr.grad).abs().max().item(), xr.grad.abs().max().item()
     assert err < 3e-2 * scale, f"d/dx: {err:.3e} vs {scale:.3e}"
-    # per tensor: max-abs error within 8 % of the tensor's largest entry (fp16 operands through eleven blocks; the first run measured <= 3 % on 351 of
-    # 367 tensors and 4-6 % on 16 carrier-branch tensors whose gradients are ~1e-4); over ALL parameters together: relative L2 error below 2 %
-    bad, n, num, den = [], 0, 0.0, 0.0
+    # per tensor: max-abs error within PER_TENSOR of the tensor's largest entry; over ALL parameters together: relative L2 error below 1.5 %
+    bad, n, num, den, worst = [], 0, 0.0, 0.0, 0.0
     for k, p in model.named_parameters():
         ref = sd[k].grad if k in sd and isinstance(sd[k], torch.Tensor) and sd[k].requires_grad else None
         if ref is None:
@@ -328,7 +331,127 @@ def test_whole_model_gradients_through_the_hip_hat_stages_vs_oracle_autograd():
         num += diff.double().pow(2).sum().item()
         den += ref.double().pow(2).sum().item()
         n += 1
-        if not (e < 8e-2 * sc + 1e-6):
+        worst = max(worst, e / (sc + 1e-30))
+        if not (e < PER_TENSOR * sc + 1e-6):
             bad.append((k, e, sc))
+    print(f"whole-model gradients: {n} tensors, worst per-tensor max-abs / max {worst:.3e}, relative L2 over all {(num / den) ** 0.5:.3e}")
     assert n > 300 and not bad, f"{len(bad)} of {n} parameter gradients off: {bad[:5]}"
-    assert (num / den) ** 0.5 < 2e-2, f"relative L2 error of all parameter gradients {(num / den) ** 0.5:.3e}"
+    assert (num / den) ** 0.5 < 1.5e-2, f"relative L2 error of all parameter gradients {(num / den) ** 0.5:.3e}"
+
+
+def _fvit0_with_reference_grads(r_scale=1.0, batch=2, seed=8):
+    """faster_vit_0_224 ('init' weights) + the gradient of every parameter of sum(logits * r) through the CPU oracle."""
+    import fastervit_amd
+    from oracle import model_reference as mr
+    from tests.cases import CASES
+    from tests.synth import synth_state_dict
+    torch.manual_seed(0)
+    model = fastervit_amd.create_model("faster_vit_0_224").eval()
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234, family="init"))
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(batch, 3, 224, 224, generator=g)
+    r = torch.randn(batch, 1000, generator=g) * r_scale
+    sd = {k: (v.detach().clone().float().requires_grad_(True) if v.dtype.is_floating_point and "running_" not in k and "num_batches" not in k
+              else v.detach().clone()) for k, v in model.state_dict().items()}
+    (mr.model_forward(sd, x, CASES["fvit0_224"]["arch"]) * r).sum().backward()
+    ref = {k: v.grad for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
+    return model, x, r, ref
+
+
+def _grad_errors(model, ref):
+    num = den = 0.0
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if k not in ref:
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        diff = p.grad.float().cpu() - ref[k]
+        worst = max(worst, diff.abs().max().item() / (ref[k].abs().max().item() + 1e-30))
+        num += diff.double().pow(2).sum().item()
+        den += ref[k].double().pow(2).sum().item()
+    return worst, (num / den) ** 0.5
+
+
+def test_tiny_upstream_gradients_survive_the_fp16_backward():
+    """with a mean-reduced loss the gradient entering a HAT stage is ~1e-6 .. 1e-7 -- inside the fp16 subnormals (spacing 6e-8).  The autograd
+    bridge scales dy by a power of two per stage call (the backward is linear in dy) and unscales in fp32: the gradients of sum(logits * r), r ~ 1e-6, must
+    be as accurate (relative to their own size) as those of r ~ 1."""
+    model, x, r, ref = _fvit0_with_reference_grads(r_scale=1e-6)
+    model = model.cuda().enable_hat_backward(True)
+    (model(x.cuda()) * r.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    worst, l2 = _grad_errors(model, ref)
+    print(f"upstream gradient 1e-6: worst per-tensor {worst:.3e}, relative L2 {l2:.3e}")
+    assert l2 < 1.5e-2 and worst < PER_TENSOR
+
+
+def test_bf16_operand_mode_differentiates_in_bf16():
+    """The backward's operand type follows the layer's forward operand mode (it used to be fp16 whatever the forward ran in)."""
+    model, x, r, ref = _fvit0_with_reference_grads()
+    model = model.cuda().set_hat_operand_dtype("bf16x2").enable_hat_backward(True)
+    assert hat_backward.operand_torch_dtype(model.levels[2]) == torch.bfloat16
+    (model(x.cuda()) * r.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    worst, l2 = _grad_errors(model, ref)
+    print(f"bf16 backward: worst per-tensor {worst:.3e}, relative L2 {l2:.3e}")
+    assert l2 < 6e-2   # 8-bit mantissas: ~8 x the fp16 figure
+
+
+def test_gradient_hooks_fire_once_and_ddp_step_runs():
+    """the stage backward used to call torch.autograd.backward re-entrantly on leaf parameters (cpb MLPs, tokenizer): their AccumulateGrad
+    nodes -- and with them DistributedDataParallel's reducer hooks -- ran from inside the outer backward and again from it.  Now every parameter gradient
+    is returned to the outer engine: each post-accumulate hook fires exactly once, and ONE DDP-wrapped step (RCCL backend, world size 1: the single-GPU
+    box) runs and yields the gradients of the unwrapped model."""
+    import os
+    import torch.distributed as dist
+    model, x, r, ref = _fvit0_with_reference_grads()
+    model = model.cuda().enable_hat_backward(True)
+    calls = {}
+    hooks = [p.register_post_accumulate_grad_hook(lambda p_, k=k: calls.__setitem__(k, calls.get(k, 0) + 1)) for k, p in model.named_parameters()]
+    (model(x.cuda()) * r.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    multi = {k: c for k, c in calls.items() if c != 1}
+    assert not multi, f"hooks fired more than once: {list(multi.items())[:5]}"
+    assert len(calls) > 300
+    plain = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    for p in model.parameters():
+        p.grad = None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+        (ddp(x.cuda()) * r.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        for k, p in model.named_parameters():
+            if k in plain:
+                assert p.grad is not None and torch.allclose(p.grad, plain[k], rtol=1e-4, atol=1e-7), k
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unsupported_geometries_fail_at_forward_time():
+    """head_dim 40 / 48 (FasterViT-1 / 2), propagation (FasterViT-3+) or a map that does not tile used to raise from inside loss.backward(),
+    on the autograd engine's thread, after a forward that succeeded."""
+    import fastervit_amd
+    m1 = fastervit_amd.create_model("faster_vit_1_224").eval().cuda()
+    with pytest.raises(RuntimeError, match="head_dim 40"):
+        m1.enable_hat_backward(True)
+    m4 = fastervit_amd.create_model("faster_vit_4_224", depths=[1, 1, 1, 1], num_heads=[1, 2, 4, 8], dim=32, in_dim=16).eval().cuda()   # head_dim 32 + propagation
+    with pytest.raises(RuntimeError, match="propagation"):
+        m4.enable_hat_backward(True)
+    m0 = fastervit_amd.create_model("faster_vit_0_224").eval().cuda().enable_hat_backward(True)
+    lvl = m0.levels[3]
+    with pytest.raises(RuntimeError, match="not a multiple of the window"):
+        lvl(torch.randn(1, 512, 9, 9, device="cuda", requires_grad=True))
+    # a supported model differentiates w.r.t. its input even without enable_hat_backward (the stage input carries a graph): no silent zero
+    m0.enable_hat_backward(False)
+    xg = torch.randn(1, 3, 224, 224, device="cuda", requires_grad=True)
+    m0(xg).sum().backward()
+    assert xg.grad is not None and xg.grad.abs().max().item() > 0
+    # the deploy plan is inference-only: asking it for a gradient raises instead of returning detached logits
+    m0.switch_to_deploy(torch.float16)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m0(xg)
