@@ -70,12 +70,14 @@ def parse():
                     help="deploy: BN folded into convs + fused HIP conv kernels (model.compile_inference); module: nn.Module forward under "
                          "autocast; auto: model(x) under autocast (automatic deploy plan)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--streams", type=int, default=3, help="deploy mode: stream shards of the batch (fork / join inside the hipGraph)")
+    ap.add_argument("--streams", type=int, default=2, help="deploy mode: stream shards of the batch (fork / join inside the hipGraph)")
     ap.add_argument("--shard-sizes", type=str, default="", help="comma list of images per stream shard (default: equal split)")
     ap.add_argument("--shard-launch", choices=["free", "forkjoin"], default="forkjoin",
                     help="'free' = one hipGraph per shard on its own stream, no join between steps (r01: slower); 'forkjoin' = one graph per step")
-    ap.add_argument("--join-from", type=int, default=-1,
-                    help="deploy mode: shards run levels [0, L) on their streams, join, levels [L, end) run once on the whole batch (-1: off)")
+    ap.add_argument("--join-from", type=int, default=3,
+                    help="deploy mode: shards run levels [0, L) on their streams, join, levels [L, end) run once on the whole batch (0: off). "
+                         "Default 3 + 2 shards (r04, A/B in one box x 3: 82.2-83.2k vs 80.2-81.8k images/s for 3 shards without the join: the last "
+                         "stage of FasterViT-0 is one 49-token window per image, 86-workgroup launches per shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline sample")
     ap.add_argument("--prof-steps", type=int, default=3, help="eager HIP-event passes for the roofline rows (0: skip)")
@@ -130,14 +132,12 @@ class Config:
         a = self.args
         if self.deploy:
             # the library-level runner: deploy plan + stream shards + ONE hipGraph with static buffers
-            self.runner = self.model.compile_inference(self.x, dtype=self.conv_dt, streams=self.streams, graph=not a.no_graph)
+            jf = a.join_from if (a.join_from > 0 and self.name == a.model and self.streams > 1) else None
+            self.runner = self.model.compile_inference(self.x, dtype=self.conv_dt, streams=self.streams, graph=not a.no_graph, join_from=jf)
             self.plan = self.runner.plan
             if a.shard_sizes:
                 self.plan.shard_sizes = [int(v) for v in a.shard_sizes.split(",")]
                 self.plan.streams = len(self.plan.shard_sizes)
-            if a.join_from > 0 and self.name == a.model:
-                self.plan.join_from = a.join_from
-            if a.shard_sizes or (a.join_from > 0 and self.name == a.model):
                 self.runner.recompile()
             if self.streams > 1 and not a.no_graph and a.shard_launch == "free":
                 self.free_runner = self.plan.shard_runner(self.x, self.streams)
@@ -183,7 +183,9 @@ class Config:
         if self.free_runner is not None:
             return f"{self.streams} free-running stream shards, one hipGraph replay per shard and step"
         g = "eager" if (self.args.no_graph or (self.runner is None and self.graph is None)) else "hipGraph replay"
-        return g + (f", {self.streams} stream shards (fork/join inside the graph; fastervit_amd.inference.CompiledInference)" if self.deploy and self.streams > 1 else "")
+        jf = getattr(self.plan, "join_from", None) if self.plan is not None else None
+        return g + (f", {self.streams} stream shards (fork/join inside the graph; fastervit_amd.inference.CompiledInference)" if self.deploy and self.streams > 1 else "") + \
+            (f", level {jf}+ joined on the whole batch" if jf and self.deploy and self.streams > 1 else "")
 
 
 def step_dispersion(cfg, n):
@@ -386,8 +388,8 @@ def run_secondary(args, dev):
     res = []
     # stream shards per configuration: 3 for batch 128; 2 for the 8-image any-res batch (3 / 3 / 2 images per shard lose to 4 / 4: 553 vs 573
     # images/s, profiles/r03_gemm_and_shard_launch_knob_sweeps.log)
-    specs = [("faster_vit_4_224", 128, None, {}, args.streams),
-             ("faster_vit_4_any_res", 8, (576, 960), dict(resolution=[576, 960], window_size=[7, 7, 12, 6], ct_size=2), min(args.streams, 2))]
+    specs = [("faster_vit_4_224", 128, None, {}, 3),
+             ("faster_vit_4_any_res", 8, (576, 960), dict(resolution=[576, 960], window_size=[7, 7, 12, 6], ct_size=2), 2)]
     for name, batch, hw, kw, nstreams in specs:
         t0 = time.perf_counter()
         try:

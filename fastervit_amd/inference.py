@@ -22,10 +22,11 @@ class CompiledInference:
     * ``example`` fixes the device, the maximum batch and the image size; shorter batches are zero-padded (images are independent in
       eval mode), other image sizes raise.
     * the returned logits are a view of the runner's static output buffer: they are overwritten by the next call (clone to keep).
+    * ``join_from`` (optional): the stream shards join in front of that level and the rest of the network runs on the whole batch.
     * a weight update after compilation is NOT picked up by the graph (its packed copies are baked in); call ``recompile()``.
     """
 
-    def __init__(self, model, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True):
+    def __init__(self, model, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True, join_from=None):
         if not example.is_cuda:
             raise RuntimeError("compile_inference: the example input must be on a HIP device (no CPU fallback)")
         if model.training:
@@ -35,6 +36,9 @@ class CompiledInference:
         self.device = example.device
         self.plan = DeployPlan(model, dtype)
         self.plan.streams = max(1, int(streams))
+        # join_from = L: the shards run levels [0, L) on their streams, join, and levels [L, end) + head run once on the whole batch
+        # (DeployPlan._forward_sharded).  FasterViT-0 at batch 256: streams = 2, join_from = 3 is the measured optimum (bench.py)
+        self.plan.join_from = join_from
         self.use_graph = bool(graph)
         self.static_x = example.detach().clone()
         self.graph = None
