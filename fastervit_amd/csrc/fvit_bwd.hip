@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const T* __restrict__ in,
 // Backward of the windowed attention core (WindowAttention.forward FV:557-568 between the qkv and proj Linears), one workgroup per (window, head):
 //   S = q k^T * scale + bias, P = softmax(S), O = P v;  given dO:
 //   dV = P^T dO;  dP = dO v^T;  dS = P * (dP - rowsum(dP * P));  dq = scale * dS k;  dk = scale * dS^T q;  dbias = dS
-// qkv / dqkv: op16 [rows][ld], columns [q|k|v][head][D]; dO: op16 [rows][ldo], columns [head][D]; bias f32 [heads][spad][spad];
+// qkv / dqkv: op16 [rows][ld], columns [q|k|v][head][D] (D = the PADDED head_dim 32 / 64 / 96: zero pad channels give zero gradients); dO: op16 [rows][ldo], columns [head][D]; bias f32 [heads][spad][spad];
 // dbias_part f32 [nwin][heads][S][S] (summed over windows afterwards, in window order).  fp32 arithmetic on values staged in LDS: this is the
 // training path's correctness reference, not a tuned kernel (2 MFLOP per workgroup).
 template <typename T, int D>
@@ -283,14 +283,18 @@ int fvit_bwd_colsum16(int32_t dtype, const void* in, int32_t ld, float* part, in
 
 int fvit_bwd_window_attention(int32_t dtype, const void* qkv, int32_t ld, const void* dO, int32_t ldo, const float* bias, int32_t spad, float scale,
                               void* dqkv, float* dbias_part, int32_t nwin, int32_t S, int32_t heads, int32_t D, fvit_stream_t stream) {
-    if (!qkv || !dO || !dqkv || nwin <= 0 || S < 1 || S > 64 || heads <= 0 || D != 32 || ld < 3 * heads * D || ldo < heads * D || (bias && spad < S)) {
-        set_error("bwd_window_attention: unsupported arguments nwin=%d S=%d heads=%d D=%d (need S <= 64, head_dim 32)", nwin, S, heads, D);
+    if (!qkv || !dO || !dqkv || nwin <= 0 || S < 1 || S > 64 || heads <= 0 || (D != 32 && D != 64 && D != 96) || ld < 3 * heads * D || ldo < heads * D || (bias && spad < S)) {
+        set_error("bwd_window_attention: unsupported arguments nwin=%d S=%d heads=%d D=%d (need S <= 64, padded head_dim 32 / 64 / 96)", nwin, S, heads, D);
         return FVIT_EINVAL;
     }
     const dim3 grid(nwin * heads);
-    if (dtype == FVIT_F16) hipLaunchKernelGGL((attn_bwd_kernel<_Float16, 32>), grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)qkv, ld, (const _Float16*)dO, ldo, bias, spad, scale, (_Float16*)dqkv, dbias_part, S, heads);
-    else if (dtype == FVIT_BF16) hipLaunchKernelGGL((attn_bwd_kernel<__bf16, 32>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv, ld, (const __bf16*)dO, ldo, bias, spad, scale, (__bf16*)dqkv, dbias_part, S, heads);
+#define FVIT_ATTN_BWD(T_, D_) hipLaunchKernelGGL((attn_bwd_kernel<T_, D_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)qkv, ld, (const T_*)dO, ldo, bias, spad, scale, (T_*)dqkv, dbias_part, S, heads)
+#define FVIT_ATTN_BWD_D(T_) do { if (D == 32) FVIT_ATTN_BWD(T_, 32); else if (D == 64) FVIT_ATTN_BWD(T_, 64); else FVIT_ATTN_BWD(T_, 96); } while (0)
+    if (dtype == FVIT_F16) FVIT_ATTN_BWD_D(_Float16);
+    else if (dtype == FVIT_BF16) FVIT_ATTN_BWD_D(__bf16);
     else { set_error("bwd_window_attention: dtype %d", dtype); return FVIT_EINVAL; }
+#undef FVIT_ATTN_BWD_D
+#undef FVIT_ATTN_BWD
     return check_launch("attn_bwd_kernel");
 }
 

@@ -496,33 +496,36 @@ _WARNED = set()
 
 
 def _check_mode(layer, x: torch.Tensor, what: str):
-    """The HIP path has forward kernels only and implements eval semantics (DropPath / Dropout identity, AR:636-637, 657-658).
-      * train mode                               -> RuntimeError (stochastic depth / dropout would silently be skipped);
+    """The fused inference kernels implement EVAL semantics (DropPath / Dropout identity, AR:636-637, 657-658) and have no backward of their own:
+      * train mode                               -> RuntimeError here.  ``FasterViTLayer.forward`` does not get here in train mode: it runs the stage
+        through ``fastervit_amd.hat_backward`` (unit-kernel chain with stochastic depth + kernel-sequence backward); this guards the low-level entry
+        points (``stage_forward`` / the block-level ``HAT.forward``) against silently skipping stochastic depth;
       * grad enabled + a LEAF input that requires grad (the caller differentiates w.r.t. this very tensor)
                                                   -> RuntimeError (outputs are detached, the gradient would silently be zero);
-      * grad enabled otherwise                   -> one warning; the stage runs and returns detached outputs.  This covers
-        ``model.eval()(x)`` without ``torch.no_grad()``: there the stage input is the output of the conv modules, which requires
-        grad only because their parameters do (a non-leaf) -- not an error of the caller.  ``FasterViT.forward`` applies the leaf
-        check to the user's own tensor."""
+      * grad enabled otherwise                   -> a RuntimeWarning; the stage runs and returns detached outputs.  ``FasterViTLayer.forward`` routes
+        eval-mode forwards that carry a graph through ``hat_backward`` wherever the geometry is covered (the gradient then flows, as in PyTorch); the
+        warning remains for geometries it does not cover (windows of more than 64 tokens) and for direct calls of this function."""
     if layer.training:
-        raise RuntimeError(f"{what}: the MI355X HAT path is inference-only (forward kernels, eval semantics); call model.eval(). "
-                           "Backward kernels for the HAT block are not built (DESIGN.md, SURVEY.md §8f-4); the head-only training "
-                           "step (fastervit_amd.head_train) keeps the backbone in eval mode.")
+        raise RuntimeError(f"{what}: the fused HIP stage kernels are inference-only (eval semantics: no stochastic depth); call model.eval(), or run the "
+                           "stage through the module (FasterViTLayer.forward in train mode uses fastervit_amd.hat_backward: unit-kernel forward with "
+                           "DropPath + kernel-sequence backward).")
     if torch.is_grad_enabled():
         if x.requires_grad and x.is_leaf:
-            raise RuntimeError(f"{what}: the input requires grad, but the HIP HAT stage has no backward: its output would be silently "
-                               "detached. Run under torch.no_grad() (or detach the input).")
+            raise RuntimeError(f"{what}: the input requires grad, but this entry point is forward-only: its output would be silently detached. Use "
+                               "model.enable_hat_backward() / FasterViTLayer.forward (differentiable where fastervit_amd.hat_backward covers the "
+                               "geometry), or run under torch.no_grad().")
         if what not in _WARNED:
             _WARNED.add(what)
-            warnings.warn(f"{what}: called with grad enabled; the HIP HAT path returns detached outputs (no backward kernels). "
-                          "Wrap inference in torch.no_grad().", stacklevel=3)
+            warnings.warn(f"{what}: called with grad enabled; this forward-only HIP entry point returns DETACHED outputs (gradients do not flow "
+                          "through it). Wrap inference in torch.no_grad(), or use model.enable_hat_backward().", RuntimeWarning, stacklevel=3)
 
 
 def check_user_input(x: torch.Tensor, what: str = "FasterViT") -> None:
     """Model-level form of the leaf check above: the caller's own tensor asks for a gradient through a forward-only path."""
     if torch.is_grad_enabled() and x.requires_grad:
-        raise RuntimeError(f"{what}: the input requires grad, but the transformer stages run forward-only HIP kernels: the gradient "
-                           "w.r.t. the input would silently be cut. Run under torch.no_grad() (or detach the input).")
+        raise RuntimeError(f"{what}: the input requires grad, but this model has a transformer stage whose geometry fastervit_amd.hat_backward does not "
+                           "cover (windows or carrier grids of more than 64 tokens): the gradient w.r.t. the input would silently be cut. Run under "
+                           "torch.no_grad() (or detach the input).")
 
 
 def is_prepared(layer, device, batch: Optional[int] = None, hw=None, slots=(0,)) -> bool:

@@ -95,6 +95,31 @@ class PatchEmbed(nn.Module):
         return self.conv_down(self.proj(x))
 
 
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm.layers.DropPath as the reference uses it, FV:21, 497, 630, 652): in train mode every sample of dim 0 is kept
+    with probability 1 - drop_prob and scaled by 1 / (1 - drop_prob); identity in eval mode.  No parameters, no buffers (the state_dict is unaffected).
+    Inside the HAT stages the HIP path does not call this module: it reads ``drop_prob`` and applies the same draw as a per-row factor of the
+    residual update (fastervit_amd.hat_backward.drop_path_masks)."""
+
+    def __init__(self, drop_prob: float = 0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob <= 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * (mask / keep)
+
+    def extra_repr(self):
+        return f"drop_prob={self.drop_prob:.3f}"
+
+
+def _drop_path(p):
+    return DropPath(p) if p and p > 0.0 else nn.Identity()   # FV:497, 630, 652
+
+
 class ConvBlock(nn.Module):
     """FV:472-512: conv-BN-GELU-conv-BN with an (optionally gamma-scaled) residual."""
 
@@ -108,13 +133,13 @@ class ConvBlock(nn.Module):
         self.layer_scale = layer_scale is not None and type(layer_scale) in (int, float)
         if self.layer_scale:
             self.gamma = nn.Parameter(layer_scale * torch.ones(dim))
-        self.drop_path = nn.Identity()  # stochastic depth is the identity in eval mode
+        self.drop_path = _drop_path(drop_path)
 
     def forward(self, x, global_feature=None):
         y = self.norm2(self.conv2(self.act1(self.norm1(self.conv1(x)))))
         if self.layer_scale:
             y = y * self.gamma.view(1, -1, 1, 1)
-        return x + y, global_feature
+        return x + self.drop_path(y), global_feature   # FV:505-512
 
 
 class TokenInitializer(nn.Module):
@@ -304,7 +329,7 @@ class HAT(nn.Module):
         self.norm1 = norm_layer(dim)
         self.attn = WindowAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
                                     proj_drop=drop, resolution=window_size, seq_length=window_size ** 2 + per_window)
-        self.drop_path = nn.Identity()
+        self.drop_path = _drop_path(drop_path)
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=hidden, act_layer=act_layer, drop=drop)
         self.gamma3 = nn.Parameter(layer_scale * torch.ones(dim)) if use_ls else 1
@@ -316,7 +341,7 @@ class HAT(nn.Module):
                                             attn_drop=attn_drop, proj_drop=drop, resolution=int(total ** 0.5),
                                             seq_length=total)
             self.hat_mlp = Mlp(in_features=dim, hidden_features=hidden, act_layer=act_layer, drop=drop)
-            self.hat_drop_path = nn.Identity()
+            self.hat_drop_path = _drop_path(drop_path)
             if self.square or not any_res:
                 self.hat_pos_embed = PosEmbMLPSwinv1D(dim, rank=2, seq_length=total)
             self.gamma1 = nn.Parameter(layer_scale * torch.ones(dim)) if use_ls else 1
@@ -370,7 +395,12 @@ class FasterViTLayer(nn.Module):
         if self.transformer_block:
             from .. import hat_runtime
             want_grad = torch.is_grad_enabled() and x.is_cuda and not self.training
-            if want_grad and self.__dict__.get("hat_backward", False):
+            if self.training and x.is_cuda and len(self.blocks):
+                # TRAIN mode: the unit-kernel chain with stochastic depth as one autograd node (the fused inference kernels have eval semantics);
+                # raises here if the geometry is not covered (hat_backward.backward_unsupported_reason)
+                from .. import hat_backward
+                x = hat_backward.stage_forward_with_grad(self, x)
+            elif want_grad and self.__dict__.get("hat_backward", False):
                 from .. import hat_backward   # the stage as one autograd node: HIP forward, kernel-sequence backward (FasterViT.enable_hat_backward)
                 x = hat_backward.stage_forward_with_grad(self, x)   # raises HERE (forward time) if the geometry has no backward
             elif want_grad and x.requires_grad and not x.is_leaf and len(self.blocks):
@@ -524,10 +554,11 @@ class FasterViT(nn.Module):
         return CompiledInference(self, example, dtype=dtype, streams=streams, graph=graph, join_from=join_from)
 
     def enable_hat_backward(self, on: bool = True):
-        """Make the transformer stages differentiable: with the model in eval mode (HAT stages have eval semantics; BatchNorm uses its running statistics)
-        and grad enabled, every HAT stage becomes ONE autograd node whose forward is the HIP inference path and whose backward is the kernel sequence of
-        ``fastervit_amd.hat_backward`` (head_dim 32, windows and carrier grids of at most 64 tokens, no last-block propagation, maps that tile exactly
-        into windows: FasterViT-0's geometry; other variants raise here, and a map size that does not tile raises at forward time).  The conv stages, norms and head are ordinary PyTorch modules and differentiate as usual.  Off by default: inference-only."""
+        """Make the transformer stages differentiable in EVAL mode: with grad enabled every HAT stage becomes ONE autograd node whose forward is the HIP
+        inference path and whose backward is the kernel sequence of ``fastervit_amd.hat_backward`` (head_dim <= 96, windows and carrier grids of at most
+        64 tokens: every entrypoint at 224 x 224; other geometries raise here or -- for a map size that does not fit -- at forward time).  In TRAIN mode
+        (``model.train()``) the stages always run as such a node, with stochastic depth (``drop_path_rate``).  The conv stages, norms and head are
+        ordinary PyTorch modules and differentiate as usual.  Off by default: eval mode is inference-only."""
         if on:
             from .. import hat_backward
             for i, lvl in enumerate(self.levels):

@@ -439,7 +439,8 @@ int fvit_bwd_layernorm(const float* x, const float* dxn, const float* dy, const 
 int fvit_bwd_colsum16(int32_t operand_dtype, const void* in, int32_t ld, float* part, int32_t M, int32_t N, fvit_stream_t stream);
 /* Backward of the windowed attention core (WindowAttention.forward FV:557-568 between the two Linears; fvit_window_attention's layouts): per
  * (window, head)  dv = P^T dO, dS = P * (dO v^T - rowsum(dO v^T * P)), dq = scale * dS k, dk = scale * dS^T q  -> dqkv (op16, qkv's layout);
- * dbias_part f32 [nwin][heads][S][S] = dS (sum over windows with fvit_bwd_colsum_finish) or NULL.  S <= 64, head_dim D == 32. */
+ * dbias_part f32 [nwin][heads][S][S] = dS (sum over windows with fvit_bwd_colsum_finish) or NULL.  S <= 64; D = the padded head_dim of the
+ * qkv layout, 32 / 64 / 96 (pad channels are zero and receive zero gradients). */
 int fvit_bwd_window_attention(int32_t operand_dtype, const void* qkv, int32_t ld, const void* dO, int32_t ldo, const float* bias, int32_t spad,
                               float scale, void* dqkv, float* dbias_part, int32_t nwin, int32_t S, int32_t heads, int32_t D, fvit_stream_t stream);
 /* out[i] (+)= sum over b < blocks of part[b * stride + i], i < n, in block order. */

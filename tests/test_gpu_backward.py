@@ -434,19 +434,22 @@ def test_gradient_hooks_fire_once_and_ddp_step_runs():
 
 
 def test_unsupported_geometries_fail_at_forward_time():
-    """head_dim 40 / 48 (FasterViT-1 / 2), propagation (FasterViT-3+) or a map that does not tile used to raise from inside loss.backward(),
-    on the autograd engine's thread, after a forward that succeeded."""
+    """a geometry the kernel-sequence backward does not cover used to raise from inside loss.backward(), on the autograd engine's thread, after a
+    forward that succeeded.  Now: enable_hat_backward() raises for a model with such a stage (windows of more than 64 tokens), a map that does not fit a
+    hierarchical stage's window grid raises at FORWARD time, and everything the backward covers -- head_dim 40 / 48 / 49 / 64 / 80, propagation, padded
+    maps -- is accepted."""
     import fastervit_amd
-    m1 = fastervit_amd.create_model("faster_vit_1_224").eval().cuda()
-    with pytest.raises(RuntimeError, match="head_dim 40"):
-        m1.enable_hat_backward(True)
-    m4 = fastervit_amd.create_model("faster_vit_4_224", depths=[1, 1, 1, 1], num_heads=[1, 2, 4, 8], dim=32, in_dim=16).eval().cuda()   # head_dim 32 + propagation
-    with pytest.raises(RuntimeError, match="propagation"):
-        m4.enable_hat_backward(True)
+    for name in ("faster_vit_1_224", "faster_vit_3_224", "faster_vit_5_224"):
+        m = fastervit_amd.create_model(name, depths=[1, 1, 1, 1]).eval()
+        assert m.enable_hat_backward(True) is m
+    big = fastervit_amd.create_model("faster_vit_4_21k_384", depths=[1, 1, 1, 1], num_heads=[1, 1, 2, 4], dim=16, in_dim=16).eval().cuda()   # 576-token windows
+    with pytest.raises(RuntimeError, match="no kernel-sequence backward"):
+        big.enable_hat_backward(True)
     m0 = fastervit_amd.create_model("faster_vit_0_224").eval().cuda().enable_hat_backward(True)
-    lvl = m0.levels[3]
-    with pytest.raises(RuntimeError, match="not a multiple of the window"):
-        lvl(torch.randn(1, 512, 9, 9, device="cuda", requires_grad=True))
+    with pytest.raises(RuntimeError, match="does not pad into"):
+        m0.levels[2](torch.randn(1, 256, 21, 21, device="cuda", requires_grad=True))     # 3 x 3 windows on a stage built for 2 x 2
+    y = m0.levels[3](torch.randn(1, 512, 9, 9, device="cuda", requires_grad=True))        # padded to 14 x 14 inside, cropped back
+    assert y.shape[-2:] == (9, 9) and y.grad_fn is not None
     # a supported model differentiates w.r.t. its input even without enable_hat_backward (the stage input carries a graph): no silent zero
     m0.enable_hat_backward(False)
     xg = torch.randn(1, 3, 224, 224, device="cuda", requires_grad=True)
@@ -456,3 +459,200 @@ def test_unsupported_geometries_fail_at_forward_time():
     m0.switch_to_deploy(torch.float16)
     with pytest.raises(RuntimeError, match="inference-only"):
         m0(xg)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+# r04: every head_dim / channel count of the reference entrypoints, the last block's carrier propagation, padded stages, stochastic depth
+# ------------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nwin,S,C,heads", [(5, 53, 320, 8), (3, 49, 784, 16), (4, 16, 160, 2), (6, 53, 96, 4)])
+def test_attn_block_backward_padded_head_dims(nwin, S, C, heads):
+    """head_dim 40 (FasterViT-1), 49 (FasterViT-4; C = 784 is not a multiple of 64 either), 80 (FasterViT-5, padded to 96) and 24: the kernels run on the
+    head_dim padded to 32 / 64 / 96 with zero channels; gradients come back in the module's own (3C, C) / (C, C) layouts."""
+    dt, tol = torch.float16, 6e-3
+    g = torch.Generator(device="cpu").manual_seed(nwin * 100 + S + C)
+    M = nwin * S
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.2).cuda()
+    dy = torch.randn(M, C, generator=g).cuda()
+    lnw, lnb = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    wq, bq = (torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda(), (torch.randn(3 * C, generator=g) * 0.3).cuda()
+    wp, bp = (torch.randn(C, C, generator=g) / C ** 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    bias = torch.randn(heads, S, S, generator=g).cuda()
+    ref, dgam, dbias = _attn_reference(x, dy, lnw, lnb, wq, bq, wp, bp, gamma, bias, heads, S)
+    grads = hat_backward.AttnGrads.zeros(C, heads, S, x.device)
+    dx = hat_backward.attn_block_backward(x, dy, lnw, lnb, wq, bq, wp, bp, gamma, bias, heads, S, grads, operand_dtype=dt)
+    torch.cuda.synchronize()
+    pairs = [("dx", dx, ref[0]), ("d ln_w", grads.ln_w, ref[1]), ("d ln_b", grads.ln_b, ref[2]), ("dWqkv", grads.qkv_w, ref[3]), ("dbqkv", grads.qkv_b, ref[4]),
+             ("dWproj", grads.proj_w, ref[5]), ("dbproj", grads.proj_b, ref[6]), ("dgamma", grads.gamma, dgam), ("dbias", grads.bias, dbias)]
+    for name, a, b in pairs:
+        assert torch.isfinite(a).all(), name
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert err < tol * scale, f"{name}: max-abs err {err:.3e} vs scale {scale:.3e}"
+
+
+def test_mlp_block_backward_channel_count_not_a_multiple_of_64():
+    """C = 784 (FasterViT-4 stage 2): as a GEMM K dimension the channel axis is zero-padded to 832; outputs and gradients keep C columns."""
+    M, C, hid = 300, 784, 3136
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.2).cuda()
+    dy = torch.randn(M, C, generator=g).cuda()
+    lnw, lnb = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    w1, b1 = (torch.randn(hid, C, generator=g) / C ** 0.5).cuda(), (torch.randn(hid, generator=g) * 0.3).cuda()
+    w2, b2 = (torch.randn(C, hid, generator=g) / hid ** 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    ref = _reference(x, dy, lnw, lnb, w1, b1, w2, b2, gamma)
+    grads = hat_backward.MlpGrads.zeros(C, hid, x.device)
+    dx = hat_backward.mlp_block_backward(x, dy, lnw, lnb, w1, b1, w2, b2, gamma, grads)
+    torch.cuda.synchronize()
+    got = [dx, grads.ln_w, grads.ln_b, grads.fc1_w, grads.fc1_b, grads.fc2_w, grads.fc2_b, grads.gamma]
+    for name, a, b in zip(["dx", "d ln_w", "d ln_b", "dW1", "db1", "dW2", "db2", "dgamma"], got, ref):
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert torch.isfinite(a).all() and err < 5e-3 * scale, f"{name}: max-abs err {err:.3e} vs scale {scale:.3e}"
+    y = hat_backward.mlp_block_forward(x, lnw, lnb, w1, b1, w2, b2, gamma)
+    yr = x + gamma * F.linear(F.gelu(F.linear(F.layer_norm(x, (C,), lnw, lnb, 1e-5), w1, b1)), w2, b2)
+    assert (y - yr).abs().max().item() < 5e-3 * yr.abs().max().item()
+
+
+def test_drop_path_row_scale_in_the_sub_block_backwards():
+    """Stochastic depth (FV:690-691): y = x + m[row group] * gamma * f(x) with m in {0, 1 / keep}: forward and every gradient against autograd on the
+    masked form (the sub-block sees dy * m, the skip connection sees dy; dropped groups contribute nothing to the parameter gradients)."""
+    nwin, S, C, hid = 9, 49, 256, 1024
+    heads, M = C // 32, nwin * S
+    g = torch.Generator(device="cpu").manual_seed(21)
+    rnd = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).cuda()   # noqa: E731
+    x, dy = rnd(M, C, k=1.3), rnd(M, C)
+    m = (torch.tensor([1, 0, 1, 1, 0, 1, 0, 1, 1], dtype=torch.float32) / 0.75).cuda()   # per window
+    rows = m.repeat_interleave(S)
+    lnw, lnb = (torch.rand(C, generator=g) + 0.5).cuda(), rnd(C, k=0.2)
+    w1, b1, w2, b2 = rnd(hid, C, k=C ** -0.5), rnd(hid, k=0.3), rnd(C, hid, k=hid ** -0.5), rnd(C, k=0.3)
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    leaves = [t.clone().requires_grad_(True) for t in (x, lnw, lnb, w1, b1, w2, b2, gamma)]
+    xr, lw, lb, W1, B1, W2, B2, G = leaves
+    yr = xr + rows[:, None] * (G * F.linear(F.gelu(F.linear(F.layer_norm(xr, (C,), lw, lb, 1e-5), W1, B1)), W2, B2))
+    yr.backward(dy)
+    y = hat_backward.mlp_block_forward(x, lnw, lnb, w1, b1, w2, b2, gamma, row_scale=rows)
+    assert (y - yr.detach()).abs().max().item() < 5e-3 * yr.abs().max().item()
+    assert torch.equal(y.view(nwin, S, C)[1], x.view(nwin, S, C)[1])   # a dropped window passes through untouched
+    grads = hat_backward.MlpGrads.zeros(C, hid, x.device)
+    dx = hat_backward.mlp_block_backward(x, dy, lnw, lnb, w1, b1, w2, b2, gamma, grads, row_scale=rows)
+    torch.cuda.synchronize()
+    got = [dx, grads.ln_w, grads.ln_b, grads.fc1_w, grads.fc1_b, grads.fc2_w, grads.fc2_b, grads.gamma]
+    for name, a, b in zip(["dx", "d ln_w", "d ln_b", "dW1", "db1", "dW2", "db2", "dgamma"], got, [t.grad for t in leaves]):
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert torch.isfinite(a).all() and err < 5e-3 * scale, f"mlp {name}: max-abs err {err:.3e} vs scale {scale:.3e}"
+    assert torch.equal(dx.view(nwin, S, C)[1], dy.view(nwin, S, C)[1])
+    # attention sub-block
+    wq, bq, wp, bp = rnd(3 * C, C, k=C ** -0.5), rnd(3 * C, k=0.3), rnd(C, C, k=C ** -0.5), rnd(C, k=0.3)
+    bias = rnd(heads, S, S)
+    L = [t.clone().requires_grad_(True) for t in (x, lnw, lnb, wq, bq, wp, bp, gamma, bias)]
+    xr, lw, lb, Wq, Bq, Wp, Bp, G, Bt = L
+    qkv = F.linear(F.layer_norm(xr, (C,), lw, lb, 1e-5), Wq, Bq).view(nwin, S, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    o = (((qkv[0] @ qkv[1].transpose(-1, -2)) * 32 ** -0.5 + Bt).softmax(-1) @ qkv[2]).transpose(1, 2).reshape(M, C)
+    ya = xr + rows[:, None] * (G * F.linear(o, Wp, Bp))
+    ya.backward(dy)
+    y = hat_backward.attn_block_forward(x, lnw, lnb, wq, bq, wp, bp, gamma, bias, heads, S, row_scale=rows)
+    assert (y - ya.detach()).abs().max().item() < 5e-3 * ya.abs().max().item()
+    ag = hat_backward.AttnGrads.zeros(C, heads, S, x.device)
+    dx = hat_backward.attn_block_backward(x, dy, lnw, lnb, wq, bq, wp, bp, gamma, bias, heads, S, ag, row_scale=rows)
+    torch.cuda.synchronize()
+    got = [dx, ag.ln_w, ag.ln_b, ag.qkv_w, ag.qkv_b, ag.proj_w, ag.proj_b, ag.gamma, ag.bias]
+    for name, a, b in zip(["dx", "d ln_w", "d ln_b", "dWqkv", "dbqkv", "dWproj", "dbproj", "dgamma", "dbias"], got, [t.grad for t in L]):
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert torch.isfinite(a).all() and err < 6e-3 * scale, f"attn {name}: max-abs err {err:.3e} vs scale {scale:.3e}"
+
+
+GENERAL = [  # (entry, kwargs, input size): reduced-depth builds of the reference entrypoints' geometries
+    ("faster_vit_1_224", dict(depths=[1, 1, 2, 2]), 224),                                        # head_dim 40
+    ("faster_vit_3_224", dict(depths=[1, 1, 2, 2], dim=64, in_dim=32, num_heads=[1, 2, 4, 8]), 224),   # head_dim 64, last-block propagation
+    ("faster_vit_4_224", dict(depths=[1, 1, 2, 1]), 224),                                        # head_dim 49, C = 784 / 1568, propagation
+    ("faster_vit_4_any_res", dict(depths=[1, 1, 2, 2], num_heads=[1, 1, 2, 4], dim=16, in_dim=16, resolution=[96, 160], window_size=[7, 7, 3, 3], ct_size=2), (96, 160)),
+]
+
+
+@pytest.mark.parametrize("entry,kwargs,hw", GENERAL)
+def test_stage_backward_of_every_geometry_vs_oracle_autograd(entry, kwargs, hw):
+    """hier_stage_backward / local_stage_backward on stages 2 and 3 of FasterViT-1 / -3 / -4 geometries and of a padded non-square any-res model (6 x 10 map
+    padded to 6 x 12, carrier grid 2 x 4 windows: the ct_window scramble): dx and the gradient of every parameter against torch.autograd through the CPU
+    oracle's hat_stage on the same synthetic 'stress' weights."""
+    import fastervit_amd
+    from oracle import hat_reference as hr
+    from tests.synth import synth_state_dict
+    torch.manual_seed(0)
+    model = fastervit_amd.create_model(entry, **kwargs).eval()
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=77, family="stress"))
+    H0, W0 = (hw, hw) if isinstance(hw, int) else hw
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for li in (2, 3):
+        layer = model.levels[li]
+        b0 = layer.blocks[0]
+        C = b0.attn.qkv.in_features
+        H, W = H0 // (4 * 2 ** li), W0 // (4 * 2 ** li)
+        x = torch.randn(2, C, H, W, generator=g)
+        dy = torch.randn(2, C, H, W, generator=g)
+        sd = {k: v.detach().clone().float().requires_grad_(v.dtype.is_floating_point) for k, v in layer.state_dict().items()}
+        xr = x.clone().requires_grad_(True)
+        out = hr.hat_stage(xr, sd, "", depth=len(layer.blocks), heads=b0.attn.num_heads, ws=layer.window_size, cw=b0.cr_window, input_resolution=[H, W],
+                           only_local=not b0.do_sr_hat, do_propagation=bool(b0.do_propagation), any_res=layer.any_res)
+        out.backward(dy)
+        ref = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None and (k.startswith("blocks.") or k.startswith("global_tokenizer."))}
+        layer = layer.cuda()
+        for p in layer.parameters():
+            p.grad = None
+        fn = hat_backward.hier_stage_backward if b0.do_sr_hat else hat_backward.local_stage_backward
+        dx = fn(layer, x.cuda(), dy.cuda())
+        torch.cuda.synchronize()
+        # the train-mode forward chain (drop probabilities 0) reproduces the oracle's forward
+        y = hat_backward.stage_forward_train(layer, x.cuda()).cpu()
+        assert (y - out.detach()).abs().max().item() < 1e-2 * out.abs().max().item(), f"{entry} level {li}: forward chain"
+        err, scale = (dx.cpu() - xr.grad).abs().max().item(), xr.grad.abs().max().item()
+        assert err < 2e-2 * scale, f"{entry} level {li} dx: {err:.3e} vs {scale:.3e}"
+        got = dict(layer.named_parameters())
+        checked, worst = 0, 0.0
+        for k, r in ref.items():
+            if k not in got:
+                continue
+            assert got[k].grad is not None, f"{entry} level {li}: no gradient for {k}"
+            a = got[k].grad.float().cpu()
+            e, sc = (a - r).abs().max().item(), r.abs().max().item()
+            worst = max(worst, e / (sc + 1e-30))
+            assert torch.isfinite(a).all() and e < 3e-2 * sc + 1e-7, f"{entry} level {li} {k}: max-abs err {e:.3e} vs scale {sc:.3e}"
+            checked += 1
+        print(f"{entry} level {li}: {checked} parameter gradients, worst {worst:.3e}; dx {err / scale:.3e}")
+        assert checked >= 14 * len(layer.blocks)
+        model.levels[li] = layer.cpu()
+
+
+def test_train_mode_runs_with_stochastic_depth_and_matches_eval_when_nothing_is_dropped():
+    """model.train(): conv side = PyTorch modules (BatchNorm in train mode, DropPath), HAT stages = the unit-kernel chain with per-window / per-image
+    DropPath draws as one autograd node each.  With every drop probability 0 the HAT stages reproduce their eval output; with drop_path_rate > 0 a step
+    runs, every parameter receives a finite gradient, and the draws differ between calls."""
+    import fastervit_amd
+    from fastervit_amd import hat_backward as hb
+    torch.manual_seed(0)
+    model = fastervit_amd.create_model("faster_vit_0_224", drop_path_rate=0.3).cuda()
+    probs = sorted({round(m.drop_prob, 4) for m in model.modules() if hasattr(m, "drop_prob")})
+    assert probs and max(probs) > 0.25 and len(probs) > 5      # the linear schedule of FV:918 reached the blocks
+    x = torch.randn(4, 3, 224, 224, device="cuda")
+    lvl = model.levels[2]
+    xs = torch.randn(4, 256, 14, 14, device="cuda")
+    model.train()
+    masks = hb.drop_path_masks(lvl, 4, 4, xs.device)
+    assert masks[-1]["attn"] is not None and tuple(masks[-1]["attn"].shape) == (16,) and tuple(masks[-1]["hat_attn"].shape) == (4,)
+    vals = torch.cat([m for d in masks for m in d.values() if m is not None]).unique()
+    assert (vals == 0).any() and all(v == 0 or v > 1 for v in vals.tolist())
+    y1 = lvl(xs)
+    y2 = lvl(xs)
+    assert y1.grad_fn is not None and not torch.equal(y1, y2)        # different draws
+    logits = model(x)
+    logits.square().mean().backward()
+    missing = [k for k, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing[:5]
+    # nothing dropped: the train-mode chain equals the eval path of the same stage (up to the 16-bit rounding of different kernels)
+    for m in model.modules():
+        if hasattr(m, "drop_prob"):
+            m.drop_prob = 0.0
+    with torch.no_grad():
+        yt = hb.stage_forward_with_grad(lvl, xs)
+        model.eval()
+        ye = hb.stage_forward_with_grad(lvl, xs)
+    assert (yt - ye).abs().max().item() < 1e-2 * ye.abs().max().item()
