@@ -50,8 +50,11 @@ OPERAND_MODES = ("f16", "bf16", "f16x2", "bf16x2")   # the modes the headline co
 ALL_OPERAND_MODES = OPERAND_MODES + ("f16x3", "bf16x3")   # fastervit_amd.hat_runtime.OPERAND_MODES
 WEIGHT_SEED = 1234          # tests/cases.py SEED: the weights of the committed golden fixtures
 # scripts/gpu_pmc_traffic.sh -> scripts/pmc_traffic_summary.py; the newest committed round wins
-PMC_FILE = next((f for f in (os.path.join("profiles", f"r0{r}_pmc_hbm_traffic_by_kernel.json") for r in (3, 2))
+PMC_FILE = next((f for f in (os.path.join("profiles", f"r0{r}_pmc_hbm_traffic_by_kernel.json") for r in (4, 3, 2))
                  if os.path.exists(os.path.join(ROOT, f))), os.path.join("profiles", "r02_pmc_hbm_traffic_by_kernel.json"))
+# rocprofv3 --kernel-trace --stats of this command, per (kernel, launch shape) (scripts/summarize_rocprof_db.py): the newest committed round
+ROCPROF_SHAPES = next((f for f in (os.path.join("profiles", f"r0{r}_bench_final_fvit_kernels_by_shape.csv") for r in (4, 3))
+                       if os.path.exists(os.path.join(ROOT, f))), None)
 
 
 def parse():
@@ -277,6 +280,26 @@ def pmc_row(kernel, workgroups, pmc_file=None):
     return best
 
 
+def rocprof_row(kernel, workgroups):
+    """Average duration of (kernel family, workgroups) in the committed rocprofv3 kernel trace of this command (None: no such row).  The live HIP-event
+    timer and the kernel trace differ by ~10 % on short kernels (the event pair sees launch gaps rocprofv3 does not, the trace runs a slightly slower
+    clock): both are reported."""
+    if not ROCPROF_SHAPES:
+        return None
+    import csv
+    fam = kernel.split("<")[0].split(" ")[0]
+    best = None
+    try:
+        with open(os.path.join(ROOT, ROCPROF_SHAPES)) as f:
+            for r in csv.DictReader(f):
+                if r["Name"].startswith(fam) and int(r["Workgroups"]) == int(workgroups):
+                    if best is None or float(r["TotalUs"]) > float(best["TotalUs"]):
+                        best = r
+    except (OSError, KeyError, ValueError):
+        return None
+    return None if best is None else {"avg_us": round(float(best["AverageUs"]), 2), "calls": int(best["Calls"]), "file": ROCPROF_SHAPES, "name": best["Name"]}
+
+
 def dominant_by_time(shapes):
     """The dominant kernel BY TIME: launches summed per kernel name -- the key of a rocprofv3 --kernel-trace --stats row; every kernel
     with algorithmic work counts, conv kernels included, no weighting -- and, inside that kernel, its heaviest launch shape."""
@@ -307,6 +330,15 @@ def roofline_entry(row, operand, family_ms=None, pmc_file=None):
          "selection": ("dominant kernel by time: launches of the timed configuration summed per kernel name (as a rocprofv3 --stats row), "
                        "conv kernels included, no weighting; reported through that kernel's heaviest launch shape.  cu_share = "
                        "min(workgroups, 256) / 256 and frac_of_occupied_cus = frac / cu_share are extra fields")}
+    e["workgroups"] = row["workgroups"]
+    e["timer"] = "live HIP-event pair per launch on the launch stream (fvit_prof_*)"
+    rp = rocprof_row(row["kernel"], row["workgroups"]) if pmc_file == PMC_FILE else None
+    if rp is not None:
+        e["avg_launch_us_rocprof"] = rp["avg_us"]
+        # MFLOP / us = TFLOP/s; MB / us * 1e3 = GB/s
+        rate = row["algorithmic_mflop_per_launch"] / rp["avg_us"] if row["bound"] == "mfma" else row["algorithmic_mbyte_per_launch"] / rp["avg_us"] * 1e3
+        e["frac_rocprof"] = round(rate / e["peak"], 4)
+        e["rocprof_source"] = f"{rp['file']}: {rp['name']} x {row['workgroups']} workgroups, {rp['calls']} calls"
     pm = pmc_row(row["kernel"], row["workgroups"], pmc_file)
     if pm is not None:
         e["traffic"] = int(pm["hbm_traffic_mb"] * 1e6)
@@ -447,7 +479,7 @@ def run_secondary(args, dev):
 LINE_BUDGET = 8000
 DETAIL_FILES = (os.path.join("gpurun_out", "bench_detail.json"), os.path.join("profiles", "bench_last.json"))
 _ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "avg_launch_us",
-              "avg_launch_us_rocprof", "launches_per_step", "ms_per_step", "workgroups", "cu_share", "algorithmic_mflop_per_launch",
+              "avg_launch_us_rocprof", "frac_rocprof", "launches_per_step", "ms_per_step", "workgroups", "cu_share", "algorithmic_mflop_per_launch",
               "algorithmic_mbyte_per_launch", "timer")
 _PAR_KEYS = ("logits_max_abs_err", "logits_abs_max", "relative", "images", "meets_1e-3", "images_per_s", "tolerance", "error")
 

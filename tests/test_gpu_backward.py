@@ -12,8 +12,9 @@ from fastervit_amd import _lib, hat_backward
 pytestmark = pytest.mark.gpu
 
 # per-tensor bound of the whole-model gradient tests: max-abs error of a parameter gradient relative to that gradient's largest entry (fp16 operands,
-# eleven HAT blocks deep; with the power-of-two scaling of dy inside the autograd bridge no tensor sits in the fp16 subnormals any more)
-PER_TENSOR = 4e-2
+# eleven HAT blocks deep).  Measured r04 (profiles/r04_backward_tests.log): worst tensor 3.0e-3, relative L2 over all 367 tensors 3.6e-4 -- before the
+# power-of-two scaling of dy inside the autograd bridge 16 carrier-branch tensors sat at 4-6e-2 (their gradients were fp16 subnormals)
+PER_TENSOR = 1e-2
 
 
 def _reference(x, dy, lnw, lnb, w1, b1, w2, b2, gamma):
@@ -318,7 +319,7 @@ def test_whole_model_gradients_through_the_hip_hat_stages_vs_oracle_autograd():
     (logits * r.cuda()).sum().backward()
     torch.cuda.synchronize()
     err, scale = (xg.grad.cpu() - xr.grad).abs().max().item(), xr.grad.abs().max().item()
-    assert err < 3e-2 * scale, f"d/dx: {err:.3e} vs {scale:.3e}"
+    assert err < 1e-2 * scale, f"d/dx: {err:.3e} vs {scale:.3e}"
     # per tensor: max-abs error within PER_TENSOR of the tensor's largest entry; over ALL parameters together: relative L2 error below 1.5 %
     bad, n, num, den, worst = [], 0, 0.0, 0.0, 0.0
     for k, p in model.named_parameters():
@@ -336,7 +337,7 @@ def test_whole_model_gradients_through_the_hip_hat_stages_vs_oracle_autograd():
             bad.append((k, e, sc))
     print(f"whole-model gradients: {n} tensors, worst per-tensor max-abs / max {worst:.3e}, relative L2 over all {(num / den) ** 0.5:.3e}")
     assert n > 300 and not bad, f"{len(bad)} of {n} parameter gradients off: {bad[:5]}"
-    assert (num / den) ** 0.5 < 1.5e-2, f"relative L2 error of all parameter gradients {(num / den) ** 0.5:.3e}"
+    assert (num / den) ** 0.5 < 2e-3, f"relative L2 error of all parameter gradients {(num / den) ** 0.5:.3e}"
 
 
 def _fvit0_with_reference_grads(r_scale=1.0, batch=2, seed=8):
@@ -382,7 +383,7 @@ def test_tiny_upstream_gradients_survive_the_fp16_backward():
     torch.cuda.synchronize()
     worst, l2 = _grad_errors(model, ref)
     print(f"upstream gradient 1e-6: worst per-tensor {worst:.3e}, relative L2 {l2:.3e}")
-    assert l2 < 1.5e-2 and worst < PER_TENSOR
+    assert l2 < 2e-3 and worst < PER_TENSOR
 
 
 def test_bf16_operand_mode_differentiates_in_bf16():
@@ -394,7 +395,7 @@ def test_bf16_operand_mode_differentiates_in_bf16():
     torch.cuda.synchronize()
     worst, l2 = _grad_errors(model, ref)
     print(f"bf16 backward: worst per-tensor {worst:.3e}, relative L2 {l2:.3e}")
-    assert l2 < 6e-2   # 8-bit mantissas: ~8 x the fp16 figure
+    assert l2 < 1e-2 and worst < 5e-2   # 8-bit mantissas: ~8 x the fp16 figure (measured 2.7e-3 / 1.5e-2)
 
 
 def test_gradient_hooks_fire_once_and_ddp_step_runs():

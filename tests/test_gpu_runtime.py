@@ -144,8 +144,8 @@ def test_device_and_mode_errors():
     with warnings.catch_warnings(record=True):
         warnings.simplefilter("always")
         yb = big(xb)
-    with torch.no_grad():
-        assert torch.equal(yb.detach(), big(xb))
+    with torch.no_grad():   # (module mode: MIOpen's fp32 convolutions are not bitwise repeatable call to call)
+        assert (yb.detach() - big(xb)).abs().max().item() < 1e-3 * yb.abs().max().item()
     with pytest.raises(RuntimeError, match="no kernel-sequence backward"):
         big.enable_hat_backward(True)
     # train mode: the low-level forward-only entry point refuses (it would skip stochastic depth) ...
