@@ -47,7 +47,7 @@ run_cfg() {   # name, bench args: kernel-trace stats only
   python $R/scripts/summarize_rocprof_db.py $DB $R/gpurun_out/${T}_${N}_rocprof >> $R/$S 2>&1
 }
 run_cfg faster_vit_4_224 --model faster_vit_4_224 --batch 128 --streams 3 --join-from 0
-run_cfg faster_vit_4_any_res --model faster_vit_4_any_res --batch 8 --input-size 576x960 --model-kwargs "dict(resolution=[576,960],window_size=[7,7,12,6],ct_size=2)" --streams 2 --join-from 0
+run_cfg faster_vit_4_any_res --model faster_vit_4_any_res --batch 8 --input-size 576x960 --model-kwargs "{'resolution':[576,960],'window_size':[7,7,12,6],'ct_size':2}" --streams 2 --join-from 0
 run_cfg faster_vit_4_224_precise_f16x3 --model faster_vit_4_224 --batch 128 --mode module --conv-dtype f32 --operand f16x3
 cd $R
 ls gpurun_out | grep ${T} >> $S
