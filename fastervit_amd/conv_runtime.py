@@ -88,6 +88,11 @@ class DeployPlan:
         # would otherwise fall back to MIOpen + glue passes; a 196-channel fp16 pixel is not even 16-byte aligned).  Pad channels
         # stay exactly zero through bias (0), ReLU / GELU (f(0) = 0), residual adds and LayerNorm2d (zero weight / bias there).
         self.pad_channels = True
+        # weight terms of the Downsample.reduction convs (FV:435): 2 = hi + lo (r04).  These three strided, bias-free convs feed their
+        # rounding straight into the next stage; the weight part of it is systematic (the same for every pixel of every image) and makes up
+        # 2.4e-4 / 1.7e-4 / 2.1e-4 of FasterViT-0's 4.2e-4 conv-side logits error (per-layer replay on the fp32 oracle); two-term weights cost
+        # twice the MFMA work of 3 of the 15 convs.  1 = single rounding (the r03 plan).
+        self.down_weight_terms = int(os.environ.get("FVIT_DOWN_WEIGHT_TERMS", "2"))
         self.fused_stem = os.environ.get("FVIT_NO_FUSED_STEM", "0") != "1"   # both PatchEmbed convs in one kernel when in_dim == dim == 64 (the 112x112x64 map never reaches HBM)
 
     # ---- folding -------------------------------------------------------------------------
@@ -112,8 +117,8 @@ class DeployPlan:
         out[:v.numel()] = v
         return out
 
-    def _cw(self, w):
-        """(MIOpen weight, HIP-kernel weight, band-kernel weight): the channels_last 16-bit tensor for F.conv2d, -- when the fused
+    def _cw(self, w, terms: int = 1):
+        """(MIOpen weight, HIP-kernel weight, band-kernel weight[, weight terms]): the channels_last 16-bit tensor for F.conv2d, -- when the fused
         implicit-GEMM kernel supports the shape (3x3, Cin and Cout multiples of 64) -- its [Cout][3][3][Cin] matrix view, and for
         128 -> 128 channels the fragment-order stream of the row-band kernel.
         Both channel counts are zero-padded to the map layout (``_cp``)."""
@@ -128,13 +133,17 @@ class DeployPlan:
         wk = wband = None
         if self.use_hip_conv and kh == 3 and kw == 3 and ci % 64 == 0 and co % 64 == 0:
             wk = wcl.permute(0, 2, 3, 1).contiguous()
+            if terms == 2:   # [Cout][hi (3,3,Cin) | lo (3,3,Cin)]: fvit_conv3x3_nhwc_terms
+                lo = (w - wcl.float()).to(self.dtype).permute(0, 2, 3, 1).contiguous()
+                wk = torch.cat([wk.reshape(co, -1), lo.reshape(co, -1)], dim=1).contiguous()
+                return wcl, wk, None, 2
             if (co, ci) == (128, 128):   # the fragment-order image fvit_conv3x3_c128_band streams (level 1 of FasterViT-0)
                 wband = frag_pack_conv128(wk.reshape(128, 1152))
-        return wcl, wk, wband
+        return wcl, wk, wband, 1
 
     def _conv(self, x, w, bias, stride, act, residual=None):
         """act(conv3x3(x, w) + bias) (+ residual): one fused HIP kernel when supported, else MIOpen conv + glue passes."""
-        wcl, wk, wband = w
+        wcl, wk, wband, wterms = w
         B, Ci, Hi, Wi = x.shape
         if wk is not None and x.is_contiguous(memory_format=torch.channels_last):
             Co = wk.shape[0]
@@ -149,10 +158,10 @@ class DeployPlan:
                                                        self.zeros.data_ptr(), _stream(self.dev))
                 _lib.check(rc, "fvit_conv3x3_c128_band")
                 return out
-            rc = _lib.lib().fvit_conv3x3_nhwc(self.code, x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                              residual.data_ptr() if residual is not None else None, out.data_ptr(), B, Hi, Wi,
-                                              Ci, Co, stride, act, self.zeros.data_ptr(), _stream(self.dev))
-            _lib.check(rc, "fvit_conv3x3_nhwc")
+            rc = _lib.lib().fvit_conv3x3_nhwc_terms(self.code, x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                    residual.data_ptr() if residual is not None else None, out.data_ptr(), B, Hi, Wi,
+                                                    Ci, Co, stride, act, wterms, self.zeros.data_ptr(), _stream(self.dev))
+            _lib.check(rc, "fvit_conv3x3_nhwc_terms")
             return out
         y = F.conv2d(x, wcl, None, stride, 1)
         if residual is not None:
@@ -193,7 +202,7 @@ class DeployPlan:
                 cin = ds.norm.weight.numel()
                 e["down"] = (self._padv(ds.norm.weight.float(), self._cp(cin)).contiguous(),
                              self._padv(ds.norm.bias.float(), self._cp(cin)).contiguous(), float(ds.norm.eps),
-                             self._cw(ds.reduction[0].weight.float()), cin)
+                             self._cw(ds.reduction[0].weight.float(), terms=2 if self.down_weight_terms == 2 else 1), cin)
             t["levels"].append(e)
         if isinstance(m.head, torch.nn.Linear):
             hw = m.head.weight.float()

@@ -35,6 +35,8 @@ struct ConvParams {
     int B, Hi, Wi, Cin, Cout, Ho, Wo, stride, act;
     int M, tiles_m, tiles_n;
     int ablate;   // experiment knob (wrong results when non-zero): 1 no X gather, 2 no W staging, 4 no MFMA, 8 no epilogue
+    int wterms;   // weight terms (conv3x3_kernel only): 2 = rows [hi | lo] of 2 x 9 x Cin columns, every K step of the lo image re-reads the
+                  // activation tile of the same (tap, channel) step -- the conv's weights to ~22 bits, its maps still rounded once
 };
 
 __device__ __forceinline__ int swz_x(int r) { return (r >> 1) & 7; }
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     const T* __restrict__ In = (const T*)p.in;
     const T* __restrict__ W = (const T*)p.w;
     const T* __restrict__ Z = (const T*)p.zeros;
-    const int ldw = 9 * p.Cin;
+    const int ldw = p.wterms * 9 * p.Cin;
 
     // ---- per-lane gather state for the rows this lane stages (fixed for the whole K loop) ----
     const T* rowbase[XP];   // &in[b][yo*s-1][xo*s-1][0] (may point outside the image; only used when the tap is valid)
@@ -117,8 +119,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     }
 
     const int cpt = p.Cin / BK;  // K steps per tap
+    const int nk1 = 9 * cpt;     // K steps of one weight term
     auto stage = [&](int kt, char* xbuf, char* wbuf) {
-        const int tap = kt / cpt, ci0 = (kt - tap * cpt) * BK;
+        const int kta = kt >= nk1 ? kt - nk1 : kt;   // the activation side wraps at the second weight term
+        const int tap = kta / cpt, ci0 = (kta - tap * cpt) * BK;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int toff = (ky * p.Wi + kx) * p.Cin + ci0;
         if (!(p.ablate & 1))
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = 9 * cpt;
+    const int nk = p.wterms * nk1;
     stage(0, smem, smem + 2 * X_BYTES);
 
     const int g = lane >> 4, s = lane & 15;
@@ -1054,14 +1058,14 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
 
 template <typename T>
 int launch_t(ConvParams& p, hipStream_t stream) {
-    if (p.Cin == 64 && p.Cout == 64 && p.stride == 1 && tune_get("conv_halo", 1)) {
+    if (p.Cin == 64 && p.Cout == 64 && p.stride == 1 && p.wterms == 1 && tune_get("conv_halo", 1)) {
         if (ablate_skip(64)) return FVIT_OK;
         return launch_halo_t<T>(p, stream);
     }
     if (ablate_skip(32)) return FVIT_OK;
     const double flops = 2.0 * p.M * (double)p.Cout * 9.0 * p.Cin;
-    const double bytes = 2.0 * ((double)p.B * p.Hi * p.Wi * p.Cin + (double)p.M * p.Cout * (p.res ? 2.0 : 1.0) + 9.0 * p.Cin * p.Cout);
-    ProfScope prof(FVIT_K_CONV, flops, bytes, stream);
+    const double bytes = 2.0 * ((double)p.B * p.Hi * p.Wi * p.Cin + (double)p.M * p.Cout * (p.res ? 2.0 : 1.0) + 9.0 * p.wterms * p.Cin * p.Cout);
+    ProfScope prof(FVIT_K_CONV, flops, bytes, stream);   // (the second weight term is a precision cost, not algorithmic FLOPs)
     const int variant = tune_get("conv64_variant", 0);
     // 128x128 tiles run two workgroups per CU (64 KiB LDS): 512 slots.  A grid just above a multiple of 512 pays a whole extra
     // round for a handful of tiles (527 tiles at 86 images of 28x28: 2 rounds, 42 us, of which one full round for 15 tiles).
@@ -1093,11 +1097,21 @@ int launch_t(ConvParams& p, hipStream_t stream) {
 
 using namespace fvit;
 
+extern "C" int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual, void* out,
+                                       int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride, int32_t act,
+                                       int32_t weight_terms, const void* zeros, fvit_stream_t stream);
+
 extern "C" int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual, void* out,
                                  int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride, int32_t act,
                                  const void* zeros, fvit_stream_t stream) {
+    return fvit_conv3x3_nhwc_terms(dtype, in, weight, bias, residual, out, B, Hi, Wi, Cin, Cout, stride, act, 1, zeros, stream);
+}
+
+extern "C" int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual, void* out,
+                                       int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride, int32_t act,
+                                       int32_t weight_terms, const void* zeros, fvit_stream_t stream) {
     if (!in || !weight || !out || !zeros || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 64) ||
-        (stride != 1 && stride != 2) || act < 0 || act > 2) {
+        (stride != 1 && stride != 2) || act < 0 || act > 2 || (weight_terms != 1 && weight_terms != 2)) {
         set_error("conv3x3: unsupported arguments Cin=%d Cout=%d stride=%d act=%d (need Cin %% 64 == 0, Cout %% 64 == 0, stride 1|2)",
                   Cin, Cout, stride, act);
         return FVIT_EINVAL;
@@ -1106,6 +1120,7 @@ extern "C" int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weig
     p.in = in; p.w = weight; p.bias = bias; p.res = residual; p.out = out; p.zeros = zeros;
     p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.act = act;
     p.ablate = tune_get("conv_ablate", 0);
+    p.wterms = weight_terms;
     p.Ho = (Hi + 2 - 3) / stride + 1;
     p.Wo = (Wi + 2 - 3) / stride + 1;
     const int64_t M = (int64_t)B * p.Ho * p.Wo;

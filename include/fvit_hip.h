@@ -394,6 +394,14 @@ int fvit_layernorm2d_cl(int32_t dtype, const void* in, void* out, const float* w
 int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual,
                       void* out, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride,
                       int32_t act, const void* zeros, fvit_stream_t stream);
+/* The same convolution with the weights as TWO 16-bit terms (weight_terms = 2): weight is [Cout][2 * 9 * Cin] = [hi | lo] per output channel
+ * (hi = round(w), lo = round(w - hi), each in [3][3][Cin] order); the lo image's K steps re-read the activation tile of the same
+ * (tap, channel) step.  The conv's weights then carry ~22 bits while its maps stay 16-bit.  Used by the deploy plan for the three
+ * Downsample.reduction convs (FV:435), whose weight rounding -- systematic, identical for every pixel of every image -- is 2.4e-4 / 1.7e-4 /
+ * 2.1e-4 of FasterViT-0's 4.2e-4 conv-side logits error.  weight_terms = 1: fvit_conv3x3_nhwc. */
+int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual,
+                            void* out, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride,
+                            int32_t act, int32_t weight_terms, const void* zeros, fvit_stream_t stream);
 
 /* The same convolution for Cin = Cout = 128, stride 1, maps up to 30 pixels wide (level 1 of FasterViT-0: 28 x 28), one ROW BAND of an
  * image per workgroup: the band's input rows + halo go to LDS once, the weights stream from L2 into registers in MFMA fragment order.

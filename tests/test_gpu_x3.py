@@ -239,3 +239,38 @@ def test_x3_stages_are_bitwise_repeatable(entry, batch):
         torch.cuda.synchronize()
         assert torch.isfinite(outs[0]).all()
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"{entry} level {li}: repeat call differs"
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("B,Ci,Co,H,W,stride", [(5, 64, 128, 56, 56, 2), (7, 128, 256, 28, 28, 2), (3, 256, 512, 14, 14, 2), (2, 64, 64, 9, 11, 1), (2, 256, 448, 15, 9, 2)])
+def test_conv3x3_two_weight_terms(opname, dt, code, B, Ci, Co, H, W, stride):
+    """fvit_conv3x3_nhwc_terms: the Downsample.reduction convs of the deploy plan with weights as hi + lo ([Cout][hi (3,3,Cin) | lo (3,3,Cin)]).  Against
+    the convolution of the SAME 16-bit map with the fp32 weights: the two-term result differs from it by the output rounding only, and is closer to
+    it than the single-term result (whose weight rounding is systematic); one term through the new entry point = fvit_conv3x3_nhwc bitwise."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5).cuda()            # fp32 weights
+    hi = w.to(dt)
+    lo = (w - hi.float()).to(dt)
+    k1 = hi.permute(0, 2, 3, 1).contiguous()
+    k2 = torch.cat([k1.reshape(Co, -1), lo.permute(0, 2, 3, 1).reshape(Co, -1)], dim=1).contiguous()
+    zeros = torch.zeros(256, dtype=dt, device="cuda")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    outs = []
+    for wk, terms in ((k2, 2), (k1, 1)):
+        out = torch.full((B, Co, Ho, Wo), float("nan"), dtype=dt, device="cuda").contiguous(memory_format=torch.channels_last)
+        _lib.check(lib.fvit_conv3x3_nhwc_terms(code, x.data_ptr(), wk.data_ptr(), None, None, out.data_ptr(), B, H, W, Ci, Co, stride, 0, terms,
+                                               zeros.data_ptr(), _stream()), "conv3x3_nhwc_terms")
+        outs.append(out)
+    ref1 = torch.full_like(outs[1], float("nan"))
+    _lib.check(lib.fvit_conv3x3_nhwc(code, x.data_ptr(), k1.data_ptr(), None, None, ref1.data_ptr(), B, H, W, Ci, Co, stride, 0, zeros.data_ptr(), _stream()), "conv3x3")
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], ref1)
+    exact = F.conv2d(x.double(), w.double(), None, stride, 1)
+    e2, e1 = (outs[0].double() - exact).abs(), (outs[1].double() - exact).abs()
+    scale = exact.abs().max().item()
+    eps1 = 2.0 ** -11 if dt == torch.float16 else 2.0 ** -8
+    assert torch.isfinite(outs[0].float()).all() and e2.max().item() < 1.2 * eps1 * scale          # output rounding (half an ulp of the largest value) + slack
+    print(f"conv two-term {opname} {Ci}->{Co} {H}x{W}: mean |err| two terms {e2.mean().item():.3e}, one term {e1.mean().item():.3e}")
+    assert e2.mean().item() < e1.mean().item()
