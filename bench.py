@@ -7,26 +7,28 @@
 
 A step is one forward pass of faster_vit_0_224 over one synthetic batch of 256 images per GPU (BASELINE configs[1]); inputs are
 resident in HBM before the timed region.  Inference is embarrassingly data parallel: every rank runs its own shard, there is no
-data-path collective (SURVEY.md §8e); the only collectives are the barrier and the MAX / SUM reductions that turn per-rank
-timings into one whole-job figure.  Rank 0 prints ONE JSON line:
+data-path collective (SURVEY.md section 8e); the only collectives are the barrier and the MAX / SUM reductions that turn per-rank
+timings into one whole-job figure.  Rank 0 prints ONE COMPACT JSON line (< 8 KB: the driver parses the last stdout line; r03's 26 KB
+line was cut by its stdout tail) and writes the full record to gpurun_out/bench_detail.json and profiles/bench_last.json:
 
-  value / ms_per_step     W untimed + exactly K timed hipGraph replays, barrier + synchronize on both sides, MAX over ranks
+  value / ms_per_step     W untimed + exactly K timed hipGraph replays, barrier + synchronize on both sides, MAX over ranks.  The graph
+                          holds the deploy plan as 2 stream shards through level 2, joined, level 3 + head on the whole batch (--streams,
+                          --join-from; fastervit_amd.inference.CompiledInference)
   step_ms                 min / median / max of individually event-timed steps (a separate pass; dispersion of the number above)
   roofline                the DOMINANT KERNEL BY TIME: launches of the timed configuration are summed per kernel name (the key of a
                           rocprofv3 --kernel-trace --stats row, conv kernels included, no weighting); the kernel with the largest
                           summed time per step is reported through its heaviest launch shape: live HIP-event duration per launch
-                          (library kernel timer, on the launch stream), algorithmic bytes / FLOPs of THAT shape, PMC traffic of THAT
-                          (kernel, grid) from the committed rocprofv3 passes (null when the committed file has no such row).
-                          cu_share / frac_of_occupied_cus are extra fields (a 66-workgroup launch holds a quarter of the chip)
-  roofline_shapes         every (kernel, launch shape) of the step with the same columns (what DESIGN.md §4 quotes)
+                          (library kernel timer, on the launch stream), algorithmic bytes / FLOPs of THAT shape; beside it the duration of
+                          the same (kernel, workgroups) in the committed rocprofv3 kernel trace (avg_launch_us_rocprof, frac_rocprof) and
+                          its PMC traffic from the committed FETCH_SIZE / WRITE_SIZE passes (null when the committed file has no such row)
   parity / parity_<op>    logits max-abs error vs the fp32 CPU oracle, 8 images from EACH stream shard, on synthetic weights of the
-                          'init' family of tests/synth.py (reference init + gamma ~ U(0.5, 1.5), BN statistics, biases: with the
-                          reference's plain init FasterViT-4's layer-scale gamma = 1e-5 would hide the HAT stages).  The timed
-                          operand type first; every other operand mode (bf16, and the two-term-weight modes f16x2 / bf16x2) is
-                          reported beside it with its own error AND its own images/s
-  secondary               BASELINE configs 3 and 5 (faster_vit_4_224 bs 128; faster_vit_4_any_res 576x960 bs 8): a few timed steps
-                          each + parity on 2 images, same synthetic weights (N = 1 only)
-  cpu_baseline            the CPU oracle (a port of the reference's fp32 PyTorch path) on the host cores, batch 8 and batch 64
+                          'init' family of tests/synth.py (reference init + gamma ~ U(0.5, 1.5), BN statistics, biases).  The timed
+                          operand type first; bf16, f16x2, bf16x2 beside it with their own error AND their own images/s
+  secondary               BASELINE configs 3 and 5 (faster_vit_4_224 bs 128; faster_vit_4_any_res 576x960 bs 8), each TIMED and CHECKED ON THE
+                          SAME 8 IMAGES in two configurations: fast (16-bit deploy plan: relative claim) and precise (module mode + f16x3:
+                          meets north_star's absolute logits max-abs < 1e-3 on models whose logits reach |7|)   (N = 1 only)
+  cpu_baseline            the CPU oracle (kind "port": a restatement of the reference's fp32 PyTorch path pinned by golden vectors generated
+                          from the real reference; /root/reference does not exist on the GPU box) on the host cores, batch 8 and batch 64
 """
 import argparse
 import ast
