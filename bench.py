@@ -505,7 +505,7 @@ def compact_line(out, detail_path=None):
     if cb and cb.get("batch_64"):
         c["cpu_baseline"]["batch_64_images_per_s"] = cb["batch_64"]["value"]
     c["parity"] = _pick(out.get("parity"), _PAR_KEYS)
-    for m in OPERAND_MODES:
+    for m in OPERAND_MODES + tuple(mm + "_down2" for mm in ALL_OPERAND_MODES):
         if "parity_" + m in out:
             c["parity_" + m] = _pick(out["parity_" + m], _PAR_KEYS)
     for k in ("hat_ms_per_step", "kernel_ms_per_step_serialized", "launches_per_step"):
@@ -682,6 +682,20 @@ def main():
             except Exception as e:
                 out["parity_" + other] = {"error": f"{type(e).__name__}: {e}"[:300]}
         cfg.model.set_hat_operand_dtype(args.operand)
+        if cfg.runner is not None and cfg.plan is not None and not args.no_modes:
+            # the accuracy option of the 16-bit plan: two-term weights in the three Downsample.reduction convs (same operand mode otherwise)
+            try:
+                cfg.plan.down_weight_terms, cfg.plan.sig = 2, None
+                cfg.runner.recompile()
+                el = dp.timed_steps(cfg.step, max(5, args.steps // 4), 2, torch.cuda.synchronize, None, dev)
+                y = cfg.logits()
+                err = (y[idx] - ref_all).abs().max().item()
+                out[f"parity_{args.operand}_down2"] = {"logits_max_abs_err": float(f"{err:.3e}"), "images": len(idx), "meets_1e-3": bool(err < 1e-3),
+                                                       "images_per_s": round(args.batch * max(5, args.steps // 4) / el, 1),
+                                                       "vs": "CPU oracle fp32, the images of 'parity'; Downsample.reduction convs with two-term weights"}
+            except Exception as e:
+                out[f"parity_{args.operand}_down2"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            cfg.plan.down_weight_terms, cfg.plan.sig = 1, None
         if cfg.runner is not None:
             cfg.runner.recompile()
         if not args.no_cpu_baseline:

@@ -88,11 +88,12 @@ class DeployPlan:
         # would otherwise fall back to MIOpen + glue passes; a 196-channel fp16 pixel is not even 16-byte aligned).  Pad channels
         # stay exactly zero through bias (0), ReLU / GELU (f(0) = 0), residual adds and LayerNorm2d (zero weight / bias there).
         self.pad_channels = True
-        # weight terms of the Downsample.reduction convs (FV:435): 2 = hi + lo (r04).  These three strided, bias-free convs feed their
+        # weight terms of the Downsample.reduction convs (FV:435): 2 = hi + lo (r04, opt-in).  These three strided, bias-free convs feed their
         # rounding straight into the next stage; the weight part of it is systematic (the same for every pixel of every image) and makes up
-        # 2.4e-4 / 1.7e-4 / 2.1e-4 of FasterViT-0's 4.2e-4 conv-side logits error (per-layer replay on the fp32 oracle); two-term weights cost
-        # twice the MFMA work of 3 of the 15 convs.  1 = single rounding (the r03 plan).
-        self.down_weight_terms = int(os.environ.get("FVIT_DOWN_WEIGHT_TERMS", "2"))
+        # 2.4e-4 / 1.7e-4 / 2.1e-4 of FasterViT-0's 4.2e-4 conv-side logits error (per-layer replay on the fp32 oracle).  Measured (A/B x 2 in
+        # one box, scripts/r04_calls/call5.sh): logits max-abs 7.5e-4 -> 4.7e-4 (f16), 5.0e-4 -> 3.0e-4 (f16x2), 7.9e-4 -> 6.9e-4 (bf16x2) for
+        # 81.0k -> 77.7k images/s (twice the K steps of 3 of the 15 convs).  Default 1 = single rounding: the plan that is timed.
+        self.down_weight_terms = int(os.environ.get("FVIT_DOWN_WEIGHT_TERMS", "1"))
         self.fused_stem = os.environ.get("FVIT_NO_FUSED_STEM", "0") != "1"   # both PatchEmbed convs in one kernel when in_dim == dim == 64 (the 112x112x64 map never reaches HBM)
 
     # ---- folding -------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -119,7 +120,7 @@ struct StageLayout {
     int nW, nloc, ncw, S, G;
     int64_t Mx, Mc;          // window-tensor rows, carrier rows
     int ldn, ldqkv, ldao, ldh;
-    size_t off_X, off_Xn, off_QKV, off_AO, off_H, off_R, off_Rn, off_RQKV, off_RAO, off_RH, off_SLAB, off_CNT, total;
+    size_t off_X, off_Xn, off_QKV, off_AO, off_H, off_R, off_Rn, off_RQKV, off_RAO, off_RH, off_SLAB, off_CNT, off_SPLITK, splitk_bytes, total;
 };
 
 static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
@@ -167,6 +168,20 @@ static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
         L.off_SLAB = take(winmlp_split_slab_bytes(L.Mx, d.C, 4));
         L.off_CNT = take((size_t)(L.Mx / 32 + 8) * 4);   // >= windows (winblk split) and >= 64-row groups (winmlp split)
     }
+    // deterministic split-K of the small-grid residual GEMMs (fvit_gemm.hip): fp32 partials [splits <= 8][rows][C] for the row counts whose 128 x 128
+    // tile grid is small (the carrier-token branch; a narrow window branch such as stage 3 of FasterViT-4 at batch 43)
+    L.off_SPLITK = 0;
+    L.splitk_bytes = 0;
+    {
+        auto need = [&](int64_t rows) -> size_t {
+            if (rows <= 0) return 0;
+            const int64_t tiles = ((rows + 127) / 128) * ((d.C + 127) / 128);
+            const int64_t sp = std::min<int64_t>(8, 460 / std::max<int64_t>(tiles, 1));
+            return sp >= 2 ? (size_t)sp * rows * d.C * 4 : 0;
+        };
+        const size_t nb = std::max(need(L.Mx), d.hier ? need(L.Mc) : (size_t)0);
+        if (nb > 0) { L.off_SPLITK = take(nb); L.splitk_bytes = nb; }
+    }
     L.total = off;
     const int want_s = fvit_attention_spad(L.S), want_g = d.hier ? fvit_attention_spad(L.G) : d.gpad;
     if (d.spad != want_s || d.gpad != want_g) {
@@ -193,7 +208,7 @@ static bool use_ln_gemm(const FvitStageDesc& d, int N, int ldw, int ldo, int64_t
 
 // LN -> qkv -> attention -> proj + gamma-residual, on `rows` rows of the f32 stream `x`
 static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttnWeights& w, float* x, int64_t rows, void* xn,
-                    void* qkv, void* ao, int nwin, int S, bool ln_done, hipStream_t st, bool qkv_done = false) {
+                    void* qkv, void* ao, int nwin, int S, bool ln_done, hipStream_t st, bool qkv_done = false, char* wsb = nullptr) {
     const int dt = d.operand_dtype;
     const int T = d.weight_terms;   // K-concatenated weight terms: the GEMMs run K = T x ld against the activation columns (GemmCall.ka)
     const int AT = T == 3 ? 2 : 1;  // activation terms: rows of xn / qkv / ao hold [hi | lo] images (stride AT x ld, lo at column ld)
@@ -217,6 +232,7 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
     dbg_rowhash("attn.ao", ao, rows, AT * L.ldao * 2, st);
     GemmCall g2 = {dt, ao, AT * L.ldao, w.w_proj, T * L.ldao, w.b_proj, w.gamma, x, d.C, (int)rows, d.C, T * L.ldao, 2};
     g2.ka = L.ldao;
+    if (wsb && L.splitk_bytes) { g2.splitk_slab = (float*)(wsb + L.off_SPLITK); g2.splitk_bytes = L.splitk_bytes; }
     FVIT_TRY(launch_gemm(g2, st));
     dbg_rowhash("attn.out", x, rows, d.C * 4, st);
     return FVIT_OK;
@@ -297,6 +313,7 @@ static int run_mlp(const FvitStageDesc& d, const StageLayout& L, const FvitMlpWe
     GemmCall g2 = {dt, h, AT * L.ldh, w.w_fc2, T * L.ldh, w.b_fc2, w.gamma, x, d.C, (int)rows, d.C, T * L.ldh, 2};
     g2.ka = L.ldh;
     if (next_pe && next_pe->add) { g2.add = next_pe->add; g2.add_idx = next_pe->add_idx; g2.rows_per_image = next_pe->rows_per_image; }
+    if (slab && L.splitk_bytes) { g2.splitk_slab = (float*)(slab + L.off_SPLITK); g2.splitk_bytes = L.splitk_bytes; }
     FVIT_TRY(launch_gemm(g2, st));
     dbg_rowhash("mlp.out", x, rows, d.C * 4, st);
     return FVIT_OK;
@@ -361,14 +378,14 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
                 // is written by the kernel's first column group
                 LnGemmCall lg = {ln, w.hat_attn.w_qkv, L.ldn, w.hat_attn.b_qkv, RQKV, L.ldqkv, L.ldqkv, 0};
                 FVIT_TRY(launch_ln_gemm(lg, st));
-                FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st, true));
+                FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st, true, ws));
             } else {
                 FVIT_TRY(launch_gather_layernorm(ln, st));
                 dbg_rowhash("ct.gather", R, L.Mc, d.C * 4, st);
-                FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st));
+                FVIT_TRY(run_attn(d, L, w.hat_attn, R, L.Mc, Rn, RQKV, RAO, d.batch, L.G, true, st, false, ws));
             }
         }
-        if (!ct_done) FVIT_TRY(run_mlp(d, L, w.hat_mlp, R, L.Mc, Rn, RH, st));
+        if (!ct_done) FVIT_TRY(run_mlp(d, L, w.hat_mlp, R, L.Mc, Rn, RH, st, nullptr, ws));
     }
     if (win_fused_ok(d, w.attn, L.S)) {
         // C = 512 (stage 3 of FasterViT-0): the same sub-block with the waves of a window splitting heads / output channels
@@ -397,7 +414,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         LnCall ln1 = {dt, X, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w.attn.ln_w, w.attn.ln_b, 1e-5f, (int)L.Mx, 1, d.C};
         LnGemmCall lg = {ln1, w.attn.w_qkv, L.ldn, w.attn.b_qkv, QKV, L.ldqkv, L.ldqkv, 0};
         FVIT_TRY(launch_ln_gemm(lg, st));
-        FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st, true));
+        FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st, true, ws));
     } else {
         // cat(ct_window(ct), x + pos_embed) gather -> X, LN(norm1) -> Xn
         const int AT = d.weight_terms == 3 ? 2 : 1;
@@ -406,7 +423,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         if (AT == 2) ln1.lo_off = L.ldn;
         FVIT_TRY(launch_gather_layernorm(ln1, st));
         dbg_rowhash("win.gather", X, L.Mx, d.C * 4, st);
-        FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st));
+        FVIT_TRY(run_attn(d, L, w.attn, X, L.Mx, Xn, QKV, AO, d.batch * L.nW, L.S, true, st, false, ws));
     }
     FVIT_TRY(run_mlp(d, L, w.mlp, X, L.Mx, Xn, Hb, st, next_pe, ws));
     return FVIT_OK;
@@ -574,6 +591,14 @@ int fvit_gemm_bias_act(int32_t operand_dtype, const void* A, int32_t lda, const 
 int fvit_gemm_residual(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias,
                        const float* gamma, float* x, int32_t ldx, int32_t M, int32_t N, int32_t K, fvit_stream_t stream) {
     GemmCall g = {operand_dtype, A, lda, Wt, ldw, bias, gamma, x, ldx, M, N, K, 2};
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+int fvit_gemm_residual_splitk(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias, const float* gamma,
+                              float* x, int32_t ldx, int32_t M, int32_t N, int32_t K, float* slab, size_t slab_bytes, fvit_stream_t stream) {
+    GemmCall g = {operand_dtype, A, lda, Wt, ldw, bias, gamma, x, ldx, M, N, K, 2};
+    g.splitk_slab = slab;
+    g.splitk_bytes = slab_bytes;
     return launch_gemm(g, (hipStream_t)stream);
 }
 

@@ -205,6 +205,9 @@ struct GemmCall {
     int ka = 0;
     // epilogues 0 / 1: > 0 = the output is stored as two terms, hi at column n and lo = round(y - hi) at column out_lo_off + n
     int out_lo_off = 0;
+    // residual epilogue: optional fp32 scratch for deterministic split-K (small grids with long K, see fvit_gemm.hip); nullptr = never split
+    float* splitk_slab = nullptr;
+    size_t splitk_bytes = 0;
 };
 int launch_gemm(const GemmCall& c, hipStream_t stream);
 

@@ -20,6 +20,8 @@
 //   * blockIdx -> tile mapping is XCD aware: each XCD (blockIdx % 8) owns a contiguous range of
 //     tiles ordered n-fastest, so the activation tile is fetched from HBM once per XCD L2 and the
 //     (small) weight matrix stays L2 resident.
+#include <algorithm>
+
 #include "fvit_common.h"
 
 namespace fvit {
@@ -40,6 +42,8 @@ struct GemmParams {
     int arow_max, wrow_max;   // last valid row of the 128-row padded operands
     int ka;       // activation columns of one term; contraction index k reads A column (k >= ka ? k - ka : k) (K = 1, 2 or 3 x ka, see GemmCall)
     int lo_off;   // epilogues 0 / 1: > 0 = also store the second term lo = round(y - hi) at column offset lo_off (elements) of the same row
+    int splits;   // > 1 (EPI 3): deterministic split-K -- the grid is splits x tiles, workgroup (sp, tile) accumulates K tiles [sp nk / splits, (sp + 1) nk / splits)
+    float* slab;  // EPI 3: f32 [splits][M][N] partial sums (no bias); splitk_reduce_kernel adds them in split order and applies the residual epilogue
     int tiles_m, tiles_n;
     int stagger;  // 1: workgroup (tm, tn) walks the K tiles starting at a tile-dependent offset (see gemm_kernel)
     const float* add;        // residual epilogue: optional row table added after the update (see GemmCall)
@@ -114,7 +118,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
     const int nblk = gridDim.x, b = blockIdx.x;
     const int q = nblk >> 3, rr = nblk & 7, xcd = b & 7, idx = b >> 3;
     const int v = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-    const int tm = v / p.tiles_n, tn = v - tm * p.tiles_n;
+    int sp = 0, vt = v;
+    if (EPI == 3) {   // split-K: consecutive ids = the tiles of one K range
+        const int tiles = p.tiles_m * p.tiles_n;
+        sp = v / tiles;
+        vt = v - sp * tiles;
+    }
+    const int tm = vt / p.tiles_n, tn = vt - tm * p.tiles_n;
     const int m0 = tm * BMT, n0 = tn * BNT;
 
     const T* __restrict__ A = (const T*)p.A;
@@ -126,7 +136,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk_all = p.K / BK;
+    const int k_lo = EPI == 3 ? sp * nk_all / p.splits : 0;
+    const int nk = EPI == 3 ? (sp + 1) * nk_all / p.splits - k_lo : nk_all;
     // K-order stagger: the workgroups of an XCD that share an activation panel (same tm) or a weight panel (same tn) start at
     // different K tiles, so a panel chunk is fetched from the memory side by ONE of them and found in L2 by the others when
     // they get there; in lockstep every sharer waits on the same outstanding miss (hit-under-miss = full memory latency for
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
         const int per = p.tiles_n < nk ? nk / p.tiles_n : 1;
         rot = (tn * per + tm) % nk;
     }
-    auto ktile = [&](int kt) { const int k = kt + rot; return k >= nk ? k - nk : k; };
+    auto ktile = [&](int kt) { const int k = kt + rot; return k_lo + (k >= nk ? k - nk : k); };
     auto acol = [&](int kt) { const int k = ktile(kt) * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1, 2 or 3 x ka: terms [hi w | lo w | hi w] meet A columns [hi | hi | lo]
     char* const xring = smem;
     char* const wring = smem + NSTAGE * XT_BYTES;
@@ -234,7 +246,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
         f4 t = p.bias ? *(const f4*)(p.bias + nb + j * 4) : (f4){0.f, 0.f, 0.f, 0.f};
         bias[j * 4 + 0] = t[0]; bias[j * 4 + 1] = t[1]; bias[j * 4 + 2] = t[2]; bias[j * 4 + 3] = t[3];
     }
-    if (EPI == 2) {
+    if (EPI == 3) {   // split-K partial: raw fp32 accumulators into this split's slab image
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * (16 * MI) + mi * 16 + s;
+            if (m < p.M) {
+                float* P = p.slab + ((size_t)sp * p.M + m) * p.N + nb;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) *(f4*)(P + ni * 4) = acc[cg * 4 + ni][mi];
+            }
+        }
+    } else if (EPI == 2) {
         float gam[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -559,6 +581,22 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     else finish(BoolTag<false>{}, BoolTag<false>{});
 }
 
+// split-K second pass: x[m][n] += gamma[n] * (sum_s slab[s][m][n] + bias[n]), partial sums added in split order (fixed: bitwise repeatable)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, float* __restrict__ X, int ldo,
+                                                             const float* __restrict__ bias, const float* __restrict__ gamma, int M, int N) {
+    const int n4 = N >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * n4) return;
+    const int m = (int)(idx / n4), c = (int)(idx - (int64_t)m * n4) * 4;
+    f4 sum = *(const f4*)(slab + (size_t)m * N + c);
+    for (int sp = 1; sp < splits; ++sp) sum += *(const f4*)(slab + ((size_t)sp * M + m) * N + c);
+    const f4 b = bias ? *(const f4*)(bias + c) : (f4){0.f, 0.f, 0.f, 0.f};
+    const f4 g = gamma ? *(const f4*)(gamma + c) : (f4){1.f, 1.f, 1.f, 1.f};
+    f4 x = *(const f4*)(X + (size_t)m * ldo + c);
+    x += g * (sum + b);
+    *(f4*)(X + (size_t)m * ldo + c) = x;
+}
+
 template <typename T>
 int launch_t(const GemmCall& c, hipStream_t stream) {
     GemmParams p;
@@ -567,6 +605,8 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.M = c.M; p.N = c.N; p.K = c.K;
     p.ka = c.ka > 0 ? c.ka : c.K;
     p.lo_off = c.epilogue == 2 ? 0 : c.out_lo_off;
+    p.splits = 1;
+    p.slab = nullptr;
     p.arow_max = (c.M + 127) / 128 * 128 - 1;
     p.wrow_max = (c.N + 127) / 128 * 128 - 1;
     // 256 x 256 tiles once they fill the chip (fvit_tune "gemm256_min_tiles"; 0 = never): the large Linear layers of FasterViT-4
@@ -588,7 +628,17 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     // (K = 2048 .. 6272, cold weights: every K step is a memory-side round trip) want more MFMA work per step: +2.6 % images/s
     const bool small = !big && grid128 <= bm64_max && c.K <= tune_get("gemm_bm64_max_k", 1024);   // 64-row tiles
     p.tiles_m = big ? (c.M + 255) / 256 : small ? (c.M + 63) / 64 : (c.M + 127) / 128;
-    const int grid = p.tiles_m * p.tiles_n;
+    int grid = p.tiles_m * p.tiles_n;
+    // deterministic split-K (r04) for the residual GEMMs of small grids with long K (the carrier-token branch of FasterViT-4: 42 / 14 workgroups x 49 K
+    // tiles = 48 us at 0.02-0.035 of the MFMA peak; stage 3: 221 workgroups x 98 K tiles): `splits` x the workgroups, each over 1 / splits of K, fp32
+    // partials into the caller's slab, then splitk_reduce_kernel adds them in split order and applies bias / gamma / residual.  No atomics.
+    int splits = 1;
+    if (c.epilogue == 2 && !c.add && c.splitk_slab && !big && tune_get("gemm_splitk", 1)) {
+        const int nkt = p.K / BK;
+        splits = std::min(std::min(8, tune_get("gemm_splitk_slots", 460) / std::max(grid, 1)), nkt / std::max(tune_get("gemm_splitk_min_ktiles", 4), 1));
+        if (splits < 2 || (size_t)splits * c.M * (size_t)c.N * 4 > c.splitk_bytes || p.stagger) splits = 1;
+    }
+    if (splits > 1) { p.splits = splits; p.slab = c.splitk_slab; grid *= splits; }
     const double flops = 2.0 * c.M * (double)c.N * p.ka;   // algorithmic: the extra weight terms are a precision cost, not work
     double bytes = 2.0 * c.M * (double)p.ka + 2.0 * c.N * (double)c.K;  // operands once
     int kind;
@@ -604,6 +654,7 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     prof_note(c.epilogue == 2 ? (pp ? "gemm_pp_kernel<2> 256x256" : big ? "gemm_kernel<2> 256x256" : small ? "gemm_kernel<2> 64-row" : "gemm_kernel<2> 128-row")
                               : c.epilogue == 1 ? (pp ? "gemm_pp_kernel<1> 256x256" : big ? "gemm_kernel<1> 256x256" : small ? "gemm_kernel<1> 64-row" : "gemm_kernel<1> 128-row")
                                                 : (pp ? "gemm_pp_kernel<0> 256x256" : big ? "gemm_kernel<0> 256x256" : small ? "gemm_kernel<0> 64-row" : "gemm_kernel<0> 128-row"), grid);
+    if (splits > 1) prof_note(small ? "gemm_kernel<2> 64-row split-K" : "gemm_kernel<2> 128-row split-K", grid);
     // measured r01: a 3-stage ring with counted vmcnt gave no gain over 2 stages at 64..392 workgroups => opt-in only
     const bool deep = !small && !nw8 && grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
     // ring depth of the 64-row tiles (small grids): 2 (48 KiB, three workgroups per CU), 3 (72 KiB, two) or 4 (96 KiB, one)
@@ -611,7 +662,8 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
 #define FVIT_GEMM(E, NS, MI_, NW_) hipLaunchKernelGGL((gemm_kernel<T, E, NS, MI_, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p)
 #define FVIT_GEMM256(E) hipLaunchKernelGGL((gemm_kernel<T, E, 2, 4, 8, 8>), dim3(grid), dim3(512), 0, stream, p)
 #define FVIT_GEMM_E(NS, MI_, NW_) \
-    switch (c.epilogue) { case 0: FVIT_GEMM(0, NS, MI_, NW_); break; case 1: FVIT_GEMM(1, NS, MI_, NW_); break; default: FVIT_GEMM(2, NS, MI_, NW_); break; }
+    switch (splits > 1 ? 3 : c.epilogue) { case 0: FVIT_GEMM(0, NS, MI_, NW_); break; case 1: FVIT_GEMM(1, NS, MI_, NW_); break; case 3: FVIT_GEMM(3, NS, MI_, NW_); break; \
+                                           default: FVIT_GEMM(2, NS, MI_, NW_); break; }
     // the ping-pong form of the 256 x 256 tile (default since r03: 8-25 % faster than the 2-stage form on every shape that selects the tile,
     // bitwise the same result; FasterViT-4 batch 128 + 0.7 %, any-res + 0.6 % end to end -- profiles/r03_gemm_ping_pong_256_tile.log)
     if (pp) {
@@ -632,6 +684,11 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
 #undef FVIT_GEMM_E
 #undef FVIT_GEMM256
 #undef FVIT_GEMM
+    if (splits > 1) {
+        const int64_t n = (int64_t)c.M * (c.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)c.splitk_slab, splits, (float*)c.out, c.ldo,
+                           c.bias, c.gamma, c.M, c.N);
+    }
     return check_launch("gemm_kernel");
 }
 

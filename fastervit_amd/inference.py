@@ -26,7 +26,8 @@ class CompiledInference:
     * a weight update after compilation is NOT picked up by the graph (its packed copies are baked in); call ``recompile()``.
     """
 
-    def __init__(self, model, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True, join_from=None):
+    def __init__(self, model, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True, join_from=None,
+                 conv_down_terms: Optional[int] = None):
         if not example.is_cuda:
             raise RuntimeError("compile_inference: the example input must be on a HIP device (no CPU fallback)")
         if model.training:
@@ -39,6 +40,8 @@ class CompiledInference:
         # join_from = L: the shards run levels [0, L) on their streams, join, and levels [L, end) + head run once on the whole batch
         # (DeployPlan._forward_sharded).  FasterViT-0 at batch 256: streams = 2, join_from = 3 is the measured optimum (bench.py)
         self.plan.join_from = join_from
+        if conv_down_terms is not None:   # 2 = two-term weights in the Downsample.reduction convs: the accuracy option of the 16-bit plan (DeployPlan)
+            self.plan.down_weight_terms = int(conv_down_terms)
         self.use_graph = bool(graph)
         self.static_x = example.detach().clone()
         self.graph = None

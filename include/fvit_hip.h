@@ -226,6 +226,14 @@ int fvit_gemm_residual(int32_t operand_dtype, const void* A, int32_t lda, const 
                        const float* bias, const float* gamma, float* x, int32_t ldx, int32_t M,
                        int32_t N, int32_t K, fvit_stream_t stream);
 
+/* fvit_gemm_residual with an fp32 scratch for deterministic split-K (r04): when the 128 x 128 tile grid is small (<= 230 workgroups) and K is long
+ * (>= 8 K tiles of 64), `splits` (2 .. 8) x the workgroups each accumulate 1 / splits of K into slab [splits][M][N], and a second launch adds the
+ * partials in split order and applies bias / gamma / the residual update: no atomics, bitwise repeatable; the result differs from the unsplit
+ * GEMM only by fp32 summation order.  slab_bytes >= splits * M * N * 4, else (or slab NULL) the call is fvit_gemm_residual.  The stage path gives
+ * the carrier-token branch's proj / fc2 GEMMs (FasterViT-4: 42 workgroups x 49 K tiles) this scratch from its workspace. */
+int fvit_gemm_residual_splitk(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias, const float* gamma,
+                              float* x, int32_t ldx, int32_t M, int32_t N, int32_t K, float* slab, size_t slab_bytes, fvit_stream_t stream);
+
 /* The same GEMM with K-concatenated weight terms (FvitStageDesc.weight_terms): Wt is [pad128(N)][ldw >= K], K = ka or 2 * ka, the
  * contraction index k reads activation column k mod ka (A is [pad128(M)][lda >= ka]).  epilogue: 0 bias, 1 bias + GELU (out op16),
  * 2 gamma-residual into f32 out (gamma may be NULL = 1).  With K == ka this is fvit_gemm_bias_act / fvit_gemm_residual. */

@@ -274,3 +274,41 @@ def test_conv3x3_two_weight_terms(opname, dt, code, B, Ci, Co, H, W, stride):
     assert torch.isfinite(outs[0].float()).all() and e2.max().item() < 1.2 * eps1 * scale          # output rounding (half an ulp of the largest value) + slack
     print(f"conv two-term {opname} {Ci}->{Co} {H}x{W}: mean |err| two terms {e2.mean().item():.3e}, one term {e1.mean().item():.3e}")
     assert e2.mean().item() < e1.mean().item()
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("M,N,K", [(688, 784, 3136), (240, 784, 1024), (2107, 1568, 6272), (2048, 256, 1024), (77, 512, 512), (5000, 784, 3136)])
+def test_gemm_residual_split_k(opname, dt, code, M, N, K):
+    """Deterministic split-K of the small-grid residual GEMMs (the carrier-token branch of FasterViT-4: 688 x 784 x 3136 = 42 workgroups x 49 K tiles):
+    against the fp32 product, against the unsplit kernel (same products, other fp32 summation order), bitwise repeatable; a grid that fills the chip
+    (the last shape) is not split and returns the unsplit kernel's bits."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dt).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda()
+    bias, gamma = torch.randn(N, generator=g).cuda(), (torch.rand(N, generator=g) + 0.5).cuda()
+    x0 = torch.randn(M, N, generator=g).cuda()
+    Ap = torch.zeros(_rup(M, 128), K, dtype=dt, device="cuda")
+    Ap[:M] = A
+    Wp = torch.zeros(_rup(N, 128), K, dtype=dt, device="cuda")
+    Wp[:N] = W
+    slab = torch.full((8 * M * N,), float("nan"), dtype=torch.float32, device="cuda")
+    outs = []
+    for _ in range(2):
+        out = x0.clone()
+        _lib.check(lib.fvit_gemm_residual_splitk(code, Ap.data_ptr(), K, Wp.data_ptr(), K, bias.data_ptr(), gamma.data_ptr(), out.data_ptr(), N, M, N, K,
+                                                 slab.data_ptr(), slab.numel() * 4, _stream()), "gemm_residual_splitk")
+        outs.append(out)
+    plain = x0.clone()
+    _lib.check(lib.fvit_gemm_residual(code, Ap.data_ptr(), K, Wp.data_ptr(), K, bias.data_ptr(), gamma.data_ptr(), plain.data_ptr(), N, M, N, K, _stream()), "gemm_residual")
+    torch.cuda.synchronize()
+    ref = x0.double() + gamma.double() * (A.double() @ W.double().t() + bias.double())
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    scale = ref.abs().max().item()
+    assert (outs[0].double() - ref).abs().max().item() < 2e-5 * scale
+    assert (outs[0] - plain).abs().max().item() < 2e-5 * scale
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles > 230:
+        assert torch.equal(outs[0], plain)
+    else:
+        assert torch.isfinite(slab[:2 * M * N]).all()   # the partials went through the scratch
