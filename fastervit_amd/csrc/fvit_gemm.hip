@@ -632,8 +632,12 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     // deterministic split-K (r04) for the residual GEMMs of small grids with long K (the carrier-token branch of FasterViT-4: 42 / 14 workgroups x 49 K
     // tiles = 48 us at 0.02-0.035 of the MFMA peak; stage 3: 221 workgroups x 98 K tiles): `splits` x the workgroups, each over 1 / splits of K, fp32
     // partials into the caller's slab, then splitk_reduce_kernel adds them in split order and applies bias / gamma / residual.  No atomics.
+    // OPT-IN (fvit_tune "gemm_splitk" = 1).  Measured r04 (scripts/r04_calls/call6.sh, A/B x 2 in one box): the launches get 3 x shorter (46 -> ~15 us)
+    // and the STEP gets slower -- FasterViT-4 batch 128: 6 371 / 6 390 -> 6 261 / 6 265 images/s; any-res 571 -> 576 (noise): with three stream shards
+    // a 42-workgroup launch holding a sixth of the chip for 46 us costs the other shards almost nothing, 336 workgroups for 15 us do.  The measure
+    // of a kernel inside the shard pipeline is CU x time, not latency (the r03 sibling-split result again, profiles/HISTORY.md).
     int splits = 1;
-    if (c.epilogue == 2 && !c.add && c.splitk_slab && !big && tune_get("gemm_splitk", 1)) {
+    if (c.epilogue == 2 && !c.add && c.splitk_slab && !big && tune_get("gemm_splitk", 0)) {
         const int nkt = p.K / BK;
         splits = std::min(std::min(8, tune_get("gemm_splitk_slots", 460) / std::max(grid, 1)), nkt / std::max(tune_get("gemm_splitk_min_ktiles", 4), 1));
         if (splits < 2 || (size_t)splits * c.M * (size_t)c.N * 4 > c.splitk_bytes || p.stagger) splits = 1;
