@@ -140,8 +140,13 @@ class Config:
             jf = a.join_from if (a.join_from > 0 and self.name == a.model and self.streams > 1) else None
             self.runner = self.model.compile_inference(self.x, dtype=self.conv_dt, streams=self.streams, graph=not a.no_graph, join_from=jf)
             self.plan = self.runner.plan
-            if a.shard_sizes:
-                self.plan.shard_sizes = [int(v) for v in a.shard_sizes.split(",")]
+            sizes = a.shard_sizes
+            if not sizes and self.name == a.model == "faster_vit_0_224" and self.streams == 2 and self.batch == 256 and jf == 3:
+                # the main stream's shard slightly larger than the side stream's: 85.87k vs 85.31 / 85.41k images/s for 128 + 128 (box noise +-50;
+                # scripts/r04_calls/call8.sh sweeps 112 .. 160): the side stream starts after the fork and joins first
+                sizes = "132,124"
+            if sizes:
+                self.plan.shard_sizes = [int(v) for v in sizes.split(",")]
                 self.plan.streams = len(self.plan.shard_sizes)
                 self.runner.recompile()
             if self.streams > 1 and not a.no_graph and a.shard_launch == "free":
