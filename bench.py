@@ -663,6 +663,8 @@ def main():
     arch = oracle_arch(args.model, mk)
     if world == 1 and arch is not None:   # N = 1 only: rank 0's host cores are shared with the other ranks otherwise
         sizes = [p.shape[0] for p in cfg.x_cpu.chunk(cfg.streams)] if cfg.streams > 1 else [args.batch]
+        if cfg.plan is not None and getattr(cfg.plan, "shard_sizes", None) and sum(cfg.plan.shard_sizes) == args.batch:
+            sizes = list(cfg.plan.shard_sizes)
         starts = [sum(sizes[:i]) for i in range(len(sizes))]
         idx = [s + j for s, n in zip(starts, sizes) for j in range(min(8, n))]
         parity, ref_all = parity_vs_oracle(cfg, logits_gpu, arch, idx, f"CPU oracle fp32; 8 images from each of the {len(sizes)} stream shards (shard starts {starts})")
