@@ -24,7 +24,7 @@ FVIT_PROF_KINDS = 11
 EXPORTED_SYMBOLS = (
     "fvit_abi_version", "fvit_last_error", "fvit_attention_spad", "fvit_attention_dense", "fvit_stage_workspace_bytes",
     "fvit_workspace_init", "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_token_init", "fvit_window_partition",
-    "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_gemm_terms", "fvit_gemm_residual_splitk", "fvit_gemm_terms_lo", "fvit_window_attention_terms", "fvit_gather_layernorm_terms", "fvit_win_mlp_fused_terms", "fvit_win_mlp_split_bytes", "fvit_win_mlp_fused_split", "fvit_win_block_fused_split", "fvit_win_block_fused_terms", "fvit_ct_block_fused_terms", "fvit_window_attention", "fvit_window_attention_long",
+    "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_gemm_terms", "fvit_gemm_residual_splitk", "fvit_gemm_terms_lo", "fvit_window_attention_terms", "fvit_gather_layernorm_terms", "fvit_win_mlp_fused_terms", "fvit_win_mlp_split_bytes", "fvit_win_mlp_fused_split", "fvit_win_block_fused_split", "fvit_win_block_fused_terms", "fvit_attn_block_fused_terms", "fvit_ct_block_fused_terms", "fvit_window_attention", "fvit_window_attention_long",
     "fvit_gather_layernorm", "fvit_ln_gemm_supported", "fvit_ln_gemm", "fvit_attn_block_supported", "fvit_attn_block_fused", "fvit_ct_block_supported", "fvit_ct_block_fused", "fvit_win_block_supported", "fvit_win_block_fused", "fvit_win_mlp_supported", "fvit_win_mlp_fused", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl", "fvit_conv3x3_nhwc", "fvit_conv3x3_nhwc_terms", "fvit_conv3x3_c128_band_supported", "fvit_conv3x3_c128_band", "fvit_stem_conv3x3s2", "fvit_stem_fused",
     "fvit_head_logits", "fvit_head_softmax_xent", "fvit_head_grad", "fvit_sgd_momentum",
     "fvit_debug_lds_poison", "fvit_debug_regs_poison", "fvit_debug_poison_launches", "fvit_debug_rowhash_begin", "fvit_debug_rowhash_end", "fvit_debug_rowhash_dump", "fvit_debug_mlp_trace_begin", "fvit_debug_mlp_trace_end", "fvit_debug_mlp_inputs_begin", "fvit_debug_mlp_inputs_end", "fvit_debug_win_mlp_timeline", "fvit_debug_stem_timeline", "fvit_debug_conv_band_timeline", "fvit_debug_attn_block_timeline", "fvit_debug_ct_block_timeline", "fvit_bwd_blocks", "fvit_bwd_transpose16", "fvit_bwd_scale_cols", "fvit_bwd_gelu", "fvit_bwd_layernorm", "fvit_bwd_colsum_finish", "fvit_bwd_colsum16", "fvit_bwd_window_attention", "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_records", "fvit_prof_kind_name",
@@ -197,6 +197,8 @@ def _declare(lib):
     lib.fvit_ct_block_fused_terms.argtypes = list(lib.fvit_ct_block_fused.argtypes)[:-1] + [i32, vp]
     lib.fvit_win_block_fused_terms.restype = C.c_int
     lib.fvit_win_block_fused_terms.argtypes = list(lib.fvit_attn_block_fused.argtypes)[:-1] + [i32, vp]
+    lib.fvit_attn_block_fused_terms.restype = C.c_int
+    lib.fvit_attn_block_fused_terms.argtypes = list(lib.fvit_attn_block_fused.argtypes)[:-1] + [i32, vp]
     lib.fvit_debug_lds_poison.restype = C.c_int
     lib.fvit_debug_lds_poison.argtypes = [vp, i32, i32, vp]
     lib.fvit_debug_poison_launches.restype = C.c_int

@@ -243,7 +243,9 @@ static int run_attn(const FvitStageDesc& d, const StageLayout& L, const FvitAttn
 // C = 512 / 16 heads (stage 3): the fused instance is correct but loses end to end (66.0k vs 71.9k images/s, r01 sweep r41): one
 // workgroup per 49-token window streams 2 MiB of weights for 49 rows => opt-in (attn_fused512_min_rows)
 static bool fused_attn_ok(const FvitStageDesc& d, const FvitAttnWeights& w, int S, int64_t rows) {
-    return d.weight_terms == 1 && w.w_qkv_frag && w.b_qkv_heads && w.w_proj_frag && d.dpad == 32 && d.C / d.heads == 32 && attnblk_supported(d.C, d.heads, S) &&
+    // two-term weights (r04): the C = 256 window instance takes them ([hi image | lo image] fragment arrays); fvit_tune "attn_fused_x2" = 0 restores the r03 chain
+    const bool terms_ok = d.weight_terms == 1 || (d.weight_terms == 2 && d.C == 256 && S > 48 && tune_get("attn_fused_x2", 1));
+    return terms_ok && w.w_qkv_frag && w.b_qkv_heads && w.w_proj_frag && d.dpad == 32 && d.C / d.heads == 32 && attnblk_supported(d.C, d.heads, S) &&
            rows >= (d.C == 256 ? tune_get("attn_fused_min_rows", 16384) : tune_get("attn_fused512_min_rows", 1 << 30)) && tune_get("attn_fused", 1);
 }
 
@@ -407,6 +409,7 @@ static int run_block(const FvitStageDesc& d, const StageLayout& L, const FvitBlo
         AttnBlkCall ab = {dt, X, rpi, R, L.G, (d.hier ? t.ln1_src : nullptr), t.ln1_add, w.pe_x, w.attn.ln_w, w.attn.ln_b, 1e-5f, rpi,
                           w.attn.w_qkv_frag, w.attn.b_qkv_heads, w.attn.w_proj_frag, w.attn.b_proj, w.attn.gamma, w.attn.bias, X,
                           d.batch * L.nW, L.S, d.heads, d.C, scale};
+        ab.terms = d.weight_terms;
         FVIT_TRY(launch_attnblk(ab, st));
         dbg_rowhash("win.attnblk", X, L.Mx, d.C * 4, st);
     } else if (pe_preadded) {
@@ -776,6 +779,17 @@ int fvit_win_block_fused_terms(int32_t operand_dtype, const float* srcA, int32_t
                       b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
     ab.terms = terms;
     return launch_winblk(ab, (hipStream_t)stream);
+}
+
+int fvit_attn_block_fused_terms(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                                const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
+                                int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
+                                const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
+                                int32_t heads, int32_t C, float scale, int32_t terms, fvit_stream_t stream) {
+    AttnBlkCall ab = {operand_dtype, srcA, rowsA, srcB, rowsB, src_idx, add_idx, add, ln_w, ln_b, eps, rows_per_image, w_qkv_frag,
+                      b_qkv_heads, w_proj_frag, b_proj, gamma, bias, x_out, nwin, S, heads, C, scale};
+    ab.terms = terms;
+    return launch_attnblk(ab, (hipStream_t)stream);
 }
 
 int fvit_ct_block_supported(int32_t C, int32_t heads, int32_t G, int32_t hidden) { return ctblk_supported(C, heads, G, hidden) ? 1 : 0; }

@@ -71,8 +71,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 //      proj / bias pieces) and has the whole head to land; barrier B then waits with a COUNTED vmcnt for the proj / bias pieces only.
 //      Without it the next slice is requested after barrier B and needed ~0.3 us later (P2 + P3), i.e. one exposed LDS-DMA round trip
 //      per head.  Costs 48 KiB of LDS => one workgroup per CU: used with 8-wave workgroups (two windows, two waves per SIMD).
-template <typename T, int CC, int NRB, int NW, bool BIAS_LDS, bool DBQ = false, bool TS = false>
-__global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(AttnBlkParams p) {
+// WT (r04): weight terms.  2 = wqkv_f / wproj_f hold [hi image | lo image] (FvitStageDesc.weight_terms = 2, the x2 operand modes).  Built on the DBQ form
+//      (8 waves, two qkv buffers, bias from L2): buffer 0 takes the hi slice of a head, buffer 1 its lo slice -- requested at the top of the head,
+//      consumed after a third barrier by a second pass of P1 into the SAME q / k / v accumulators --, the proj region holds both proj slices and
+//      P3 runs once per term on the same O^T fragment.  Activations are rounded once, as everywhere in the x2 modes.
+template <typename T, int CC, int NRB, int NW, bool BIAS_LDS, bool DBQ = false, bool TS = false, int WT = 1>
+__global__ __launch_bounds__(64 * NW, (CC == 256 && WT == 1) ? 2 : 1) void attnblk_kernel(AttnBlkParams p) {
+    static_assert(WT == 1 || (WT == 2 && DBQ && !BIAS_LDS && !TS), "two weight terms: DBQ form, bias from L2");
     typedef typename Op16<T>::v8 v8;
 #define FVIT_AB_STAMP(k) if constexpr (TS) { if ((threadIdx.x & 63) == 0) p.ts[((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); }
     FVIT_AB_STAMP(0)
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
     constexpr int QKV_BYTES = QKV_FRAGS * 1024, PROJ_BYTES = CB * 1024, BIAS_BYTES = BIAS_LDS ? SP * SP * 4 : 0;
     constexpr int KX_BYTES = NW * 1024;       // one 1-KiB k fragment per wave
     constexpr int VX_BYTES = WPW * 2 * NKB32 * 1024;
-    constexpr int OFF_PROJ = (DBQ ? 2 : 1) * QKV_BYTES, OFF_BIAS = OFF_PROJ + PROJ_BYTES, OFF_KX = OFF_BIAS + ((BIAS_BYTES + 1023) / 1024) * 1024;
+    constexpr int OFF_PROJ = (DBQ ? 2 : 1) * QKV_BYTES, OFF_BIAS = OFF_PROJ + WT * PROJ_BYTES, OFF_KX = OFF_BIAS + ((BIAS_BYTES + 1023) / 1024) * 1024;
     constexpr int OFF_VX = OFF_KX + KX_BYTES, OFF_BQ = OFF_VX + VX_BYTES;
     constexpr int MAX_HEADS = CC / 32;
     constexpr int OFF_BP = OFF_BQ + MAX_HEADS * 96 * 4;   // proj bias and gamma (2 x C floats): no global loads in the epilogue
@@ -109,8 +114,8 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
     const char* __restrict__ Wq = (const char*)p.wqkv_f;
     const char* __restrict__ Wp = (const char*)p.wproj_f;
 
-    auto dma_qkv = [&](int h, int slot) {   // 48 fragments into qkv buffer `slot` (always 0 without DBQ)
-        const char* src = Wq + (size_t)h * QKV_BYTES + lane16;
+    auto dma_qkv = [&](int h, int slot, int term = 0) {   // 48 fragments into qkv buffer `slot` (always 0 without DBQ); term 1 = the lo image
+        const char* src = Wq + ((size_t)term * p.heads + h) * QKV_BYTES + lane16;
         char* dst = smem + slot * QKV_BYTES;
 #pragma unroll
         for (int i = 0; i < QKV_FRAGS / NW; ++i) glds16(src + (wave + NW * i) * 1024, dst + (wave + NW * i) * 1024);
@@ -119,6 +124,11 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
         const char* src = Wp + (size_t)h * PROJ_BYTES + lane16;
 #pragma unroll
         for (int i = 0; i < CB / NW; ++i) glds16(src + (wave + NW * i) * 1024, smem + OFF_PROJ + (wave + NW * i) * 1024);
+        if constexpr (WT == 2) {
+            const char* src2 = Wp + ((size_t)p.heads + h) * PROJ_BYTES + lane16;
+#pragma unroll
+            for (int i = 0; i < CB / NW; ++i) glds16(src2 + (wave + NW * i) * 1024, smem + OFF_PROJ + PROJ_BYTES + (wave + NW * i) * 1024);
+        }
         if (BIAS_LDS) {
             const char* bsrc = (const char*)(p.bias + (size_t)h * SP * SP) + lane16;
             constexpr int BP = (BIAS_BYTES + 1023) / 1024;   // 16 (SP = 64) or 1 (SP = 16)
@@ -230,8 +240,12 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
         }
         if (!(p.ablate & 1)) dma_proj_bias(h);
         const bool next_q = DBQ && hit + 1 < p.heads && !(p.ablate & 1);
-        if (next_q) dma_qkv(head_of(hit + 1), (hit + 1) & 1);
-        const char* wq_l = wq_base + (DBQ ? (hit & 1) * QKV_BYTES : 0);
+        if constexpr (WT == 2) {
+            dma_qkv(h, 1, 1);                       // this head's lo slice into buffer 1: lands while P1 runs on the hi slice
+        } else {
+            if (next_q) dma_qkv(head_of(hit + 1), (hit + 1) & 1);
+        }
+        const char* wq_l = wq_base + ((DBQ && WT == 1) ? (hit & 1) * QKV_BYTES : 0);   // (WT = 2: buffer 0 = hi slice, buffer 1 = lo slice)
 
         // ---- P1: q^T, k^T, v ----
         // software-pipelined over the k steps with two fragment register sets: the 6 fragments of step kk + 1 are requested before
@@ -240,7 +254,14 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
         f4 acc[6];
 #pragma unroll
         for (int ub = 0; ub < 6; ++ub) acc[ub] = (f4){0.f, 0.f, 0.f, 0.f};
-        {
+#pragma unroll
+        for (int term = 0; term < WT; ++term) {
+            if (WT == 2 && term == 1) {
+                // ---- barrier A2: the lo slice (and this head's proj / bias pieces) landed; every wave is done reading buffer 0 ----
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (next_q) dma_qkv(head_of(hit + 1), 0, 0);   // next head's hi slice: in flight until the next barrier A
+                wq_l = wq_base + QKV_BYTES;
+            }
             v8 wa[6], wb[6];
 #pragma unroll
             for (int ub = 0; ub < 6; ++ub) wa[ub] = *(const v8*)(wq_l + (ub * KK + 0) * 1024);
@@ -350,23 +371,25 @@ __global__ __launch_bounds__(64 * NW, CC == 256 ? 2 : 1) void attnblk_kernel(Att
             of[4 + r] = sat16<T>(o[1][r] * inv);
         }
         // ---- P3: out^T += Wproj[:, head h] . O^T (fragment batches of 4, batch c + 1 requested before the MFMAs of batch c) ----
-        {
+#pragma unroll
+        for (int term = 0; term < WT; ++term) {
             constexpr int PB = 4;
+            const char* wp_t = wp_l + term * PROJ_BYTES;
             v8 pa[PB], pb[PB];
 #pragma unroll
-            for (int i = 0; i < PB; ++i) pa[i] = *(const v8*)(wp_l + i * 1024);
+            for (int i = 0; i < PB; ++i) pa[i] = *(const v8*)(wp_t + i * 1024);
 #pragma unroll
             for (int c0 = 0; c0 < CB; c0 += 2 * PB) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < PB; ++i) pb[i] = *(const v8*)(wp_l + (c0 + PB + i) * 1024);
+                for (int i = 0; i < PB; ++i) pb[i] = *(const v8*)(wp_t + (c0 + PB + i) * 1024);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < PB; ++i) oacc[c0 + i] = Op16<T>::mfma(pa[i], of, oacc[c0 + i]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (c0 + 2 * PB < CB) {
 #pragma unroll
-                    for (int i = 0; i < PB; ++i) pa[i] = *(const v8*)(wp_l + (c0 + 2 * PB + i) * 1024);
+                    for (int i = 0; i < PB; ++i) pa[i] = *(const v8*)(wp_t + (c0 + 2 * PB + i) * 1024);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -437,6 +460,18 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
     ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
     prof_note(c.C == 256 ? (c.S <= 16 ? "attnblk_kernel<256,S16>" : "attnblk_kernel<256,S64>") : "attnblk_kernel<512,S64>", c.nwin);
     const bool small = c.S <= 16;
+    if (c.terms != 1 && (c.terms != 2 || c.C != 256 || small)) {
+        set_error("attn_block: weight terms %d at C=%d S=%d (two terms: C = 256, 48 < S <= 64 only)", c.terms, c.C, c.S);
+        return FVIT_EINVAL;
+    }
+    if (c.terms == 2) {   // [hi image | lo image] weights: the double-buffered 8-wave form with a second P1 / P3 pass per head
+        prof_note("attnblk_kernel<256,S64,2 terms>", (c.nwin + 1) / 2);
+        if (c.ts) { set_error("attn_block timeline: one weight term only"); return FVIT_EINVAL; }
+        if (c.dtype == FVIT_F16) hipLaunchKernelGGL((attnblk_kernel<_Float16, 256, 4, 8, false, true, false, 2>), dim3((c.nwin + 1) / 2), dim3(512), 0, stream, p);
+        else if (c.dtype == FVIT_BF16) hipLaunchKernelGGL((attnblk_kernel<__bf16, 256, 4, 8, false, true, false, 2>), dim3((c.nwin + 1) / 2), dim3(512), 0, stream, p);
+        else { set_error("attn_block: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
+        return check_launch("attnblk_kernel");
+    }
     // 0 (default): 4 waves / 1 window per workgroup, bias from L2, two workgroups per CU;
     // 1: 8 waves / 2 windows, bias table in LDS, one workgroup per CU -- equal on whole-batch launches (99.9 vs 96.7 us: the
     //    sub-block is bound by its three fp32 passes over X), but the smaller workgroups of variant 0 fill the chip better on

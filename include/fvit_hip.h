@@ -336,6 +336,15 @@ int fvit_win_block_fused_terms(int32_t operand_dtype, const float* srcA, int32_t
                                int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
                                const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
                                int32_t heads, int32_t C, float scale, int32_t terms, fvit_stream_t stream);
+/* fvit_attn_block_fused with the weight terms of the fragment arrays (r04): terms = 2 reads [hi image | lo image] of w_qkv_frag / w_proj_frag
+ * (C = 256, windows of 49 .. 64 tokens: the stage-2 window attention of FasterViT-0 in the x2 operand modes) on the double-buffered 8-wave form:
+ * per head the lo slice of the qkv weights lands in the second buffer while the first P1 pass runs, a second pass adds into the same q / k / v
+ * accumulators, and the proj MFMAs run once per term on the same attention output. */
+int fvit_attn_block_fused_terms(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
+                                const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
+                                int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
+                                const float* b_proj, const float* gamma, const float* bias, float* x_out, int32_t nwin, int32_t S,
+                                int32_t heads, int32_t C, float scale, int32_t terms, fvit_stream_t stream);
 
 /* The whole carrier-token branch of one HAT block in one kernel (AR:679-686), one workgroup per image:
  *   ct[b][i] = X[b * rowsA + src_idx[i]] (+ add[i]);  ct += gamma1 * attn(LayerNorm1(ct));  ct += gamma2 * mlp(LayerNorm2(ct))  -> R [batch * G][C]

@@ -557,3 +557,65 @@ def test_ct_block_two_weight_terms(opname, dt, code, batch, G, use_add, use_gamm
     assert (out[:batch * G] - ref1).abs().max().item() < tol
     assert call(0) != 0
     _lib.tune("ct_variant", CT_VARIANT_DEFAULT)
+
+
+@pytest.mark.parametrize("opname,dt,code", OPS)
+@pytest.mark.parametrize("S,nwin,use_gamma,gather", [(53, 344, True, True), (53, 9, False, False), (64, 3, True, False), (49, 2, True, False)])
+def test_attn_block_two_weight_terms(opname, dt, code, S, nwin, use_gamma, gather):
+    """fvit_attn_block_fused_terms (r04; C = 256, the stage-2 window attention of FasterViT-0 in the x2 operand modes): [hi image | lo image] weights on the
+    double-buffered 8-wave form, vs fp32 torch on hi + lo weights; odd window counts (two windows per workgroup), the gather / position-embedding prologue,
+    and bitwise repeatability."""
+    lib = _lib.lib()
+    C, heads = 256, 8
+    g = torch.Generator(device="cpu").manual_seed(S * 11 + nwin)
+    X = (torch.randn(nwin, S, C, generator=g) * 1.3 + 0.2).cuda()
+    lnw = (torch.rand(C, generator=g) + 0.5).cuda()
+    lnb = (torch.randn(C, generator=g) * 0.2).cuda()
+    wqkv = (torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda()
+    bqkv = (torch.randn(3 * C, generator=g) * 0.3).cuda()
+    wproj = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    bproj = (torch.randn(C, generator=g) * 0.3).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda() if use_gamma else None
+    bias = (torch.randn(heads, S, S, generator=g) * 2).cuda()
+    bp = torch.zeros(heads, 64, 64, device="cuda")
+    bp[:, :S, :S] = bias
+    bp[:, :, S:] = _lib.FVIT_MASK_BIAS
+    keep = hat_runtime._Keep(dt, 2)
+    wqf = keep.frag16(hat_runtime.frag_pack_qkv(wqkv, heads))
+    wpf = keep.frag16(hat_runtime.frag_pack_fc2(wproj))
+    bqh = bqkv.view(3, heads, 32).permute(1, 0, 2).reshape(heads, 96).contiguous()
+    xin = X
+    src_idx = add_idx = add = None
+    if gather:   # rows of a window come from a permuted source, every row gets a position-embedding row added (fvit_gather_layernorm semantics)
+        perm = torch.randperm(S, generator=g)
+        src_idx = perm.to(torch.int32).cuda()
+        add = (torch.randn(S, C, generator=g) * 0.5).cuda()
+        add_idx = torch.arange(S, dtype=torch.int32).cuda()
+        xin = X[:, perm.cuda()] + add
+    outs = []
+    for _ in range(2):
+        out = torch.full((nwin * S + 2, C), float("nan"), device="cuda")
+        args = (code, X.data_ptr(), S, None, 0, src_idx.data_ptr() if gather else None, add_idx.data_ptr() if gather else None, add.data_ptr() if gather else None,
+                lnw.data_ptr(), lnb.data_ptr(), ctypes.c_float(1e-5), S, wqf.data_ptr(), bqh.data_ptr(), wpf.data_ptr(), bproj.data_ptr(),
+                gamma.data_ptr() if use_gamma else None, bp.data_ptr(), out.data_ptr(), nwin, S, heads, C, ctypes.c_float(32 ** -0.5))
+        _lib.check(lib.fvit_attn_block_fused_terms(*args, 2, _stream()), "attn_block_fused_terms")
+        outs.append(out)
+    torch.cuda.synchronize()
+    hq, lq = _split(wqkv, dt)
+    hp, lp = _split(wproj, dt)
+    ref2 = _attention_ref(xin, lnw, lnb, hq.float() + lq.float(), bqkv, hp.float() + lp.float(), bproj, gamma, bias, heads, dt).reshape(-1, C)
+    ref1 = _attention_ref(xin, lnw, lnb, hq.float(), bqkv, hp.float(), bproj, gamma, bias, heads, dt).reshape(-1, C)
+    got = outs[0][:nwin * S]
+    assert torch.isfinite(got).all() and torch.isnan(outs[0][nwin * S:]).all() and torch.equal(outs[0][:nwin * S], outs[1][:nwin * S])
+    e2 = (got - ref2).abs().max().item()
+    tol = (4e-3 if dt == torch.float16 else 3e-2) * ref2.abs().max().item()
+    assert e2 < tol, f"{e2} vs {tol}"
+    if dt == torch.bfloat16:
+        assert (got - ref2).abs().mean().item() < (got - ref1).abs().mean().item()
+    # one term through the same entry point = fvit_attn_block_fused on the hi image
+    out1 = torch.full((nwin * S, C), float("nan"), device="cuda")
+    args1 = args[:18] + (out1.data_ptr(),) + args[19:]
+    _lib.check(lib.fvit_attn_block_fused_terms(*args1, 1, _stream()), "attn_block_fused_terms(1)")
+    torch.cuda.synchronize()
+    assert (out1 - ref1).abs().max().item() < tol
+    assert lib.fvit_attn_block_fused_terms(*args1, 3, _stream()) != 0
