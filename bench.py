@@ -140,11 +140,9 @@ class Config:
             jf = a.join_from if (a.join_from > 0 and self.name == a.model and self.streams > 1) else None
             self.runner = self.model.compile_inference(self.x, dtype=self.conv_dt, streams=self.streams, graph=not a.no_graph, join_from=jf)
             self.plan = self.runner.plan
+            # (equal shards: 132 + 124 measured +0.5 % in one box, scripts/r04_calls/call8.sh, but puts the 132-image shard's attnblk launch at 528
+            # workgroups = two rounds of the 512 resident slots, 74 vs 50 us; not adopted)
             sizes = a.shard_sizes
-            if not sizes and self.name == a.model == "faster_vit_0_224" and self.streams == 2 and self.batch == 256 and jf == 3:
-                # the main stream's shard slightly larger than the side stream's: 85.87k vs 85.31 / 85.41k images/s for 128 + 128 (box noise +-50;
-                # scripts/r04_calls/call8.sh sweeps 112 .. 160): the side stream starts after the fork and joins first
-                sizes = "132,124"
             if sizes:
                 self.plan.shard_sizes = [int(v) for v in sizes.split(",")]
                 self.plan.streams = len(self.plan.shard_sizes)
