@@ -657,3 +657,29 @@ def test_train_mode_runs_with_stochastic_depth_and_matches_eval_when_nothing_is_
         model.eval()
         ye = hb.stage_forward_with_grad(lvl, xs)
     assert (yt - ye).abs().max().item() < 1e-2 * ye.abs().max().item()
+
+
+def test_a_few_training_steps_reduce_the_loss():
+    """End to end: faster_vit_0_224 in train mode (BatchNorm batch statistics, stochastic depth on the conv side and inside the HIP stages), AdamW on ALL
+    parameters, a fixed batch of 16 images with random labels: the loss falls step over step (what train.py:820-951 does per iteration, minus its data /
+    scheduler / EMA plumbing, which is out of scope)."""
+    import fastervit_amd
+    torch.manual_seed(0)
+    model = fastervit_amd.create_model("faster_vit_0_224", drop_path_rate=0.1, num_classes=10).cuda().train()
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0.0)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(16, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 10, (16,), generator=g).cuda()
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(model(x), y)
+        loss.backward()
+        assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
+        opt.step()
+        losses.append(loss.item())
+    print("training losses:", [round(v, 4) for v in losses])
+    assert losses[-1] < 0.7 * losses[0], losses
+    model.eval()
+    with torch.no_grad():
+        assert torch.isfinite(model(x)).all()   # the updated weights re-pack for the inference kernels
