@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64 * NW, (CC == 256 && WT == 1) ? 2 : 1) void attnb
     const int hrot = p.stagger ? (int)((blockIdx.x >> 3) % (unsigned)p.heads) : 0;
     auto head_of = [&](int it) { const int hh = it + hrot; return hh >= p.heads ? hh - p.heads : hh; };
     dma_qkv(head_of(0), 0);
+    if constexpr (WT == 2) dma_qkv(head_of(0), 1, 1);   // both slices of the first head
 
     const float* src;
     const float* addp = nullptr;
@@ -240,11 +241,9 @@ __global__ __launch_bounds__(64 * NW, (CC == 256 && WT == 1) ? 2 : 1) void attnb
         }
         if (!(p.ablate & 1)) dma_proj_bias(h);
         const bool next_q = DBQ && hit + 1 < p.heads && !(p.ablate & 1);
-        if constexpr (WT == 2) {
-            dma_qkv(h, 1, 1);                       // this head's lo slice into buffer 1: lands while P1 runs on the hi slice
-        } else {
+        if constexpr (WT == 1) {
             if (next_q) dma_qkv(head_of(hit + 1), (hit + 1) & 1);
-        }
+        }   // WT = 2: both slices of this head landed at barrier A (hi requested after the previous head's barrier A2, lo after its barrier B)
         const char* wq_l = wq_base + ((DBQ && WT == 1) ? (hit & 1) * QKV_BYTES : 0);   // (WT = 2: buffer 0 = hi slice, buffer 1 = lo slice)
 
         // ---- P1: q^T, k^T, v ----
@@ -257,8 +256,8 @@ __global__ __launch_bounds__(64 * NW, (CC == 256 && WT == 1) ? 2 : 1) void attnb
 #pragma unroll
         for (int term = 0; term < WT; ++term) {
             if (WT == 2 && term == 1) {
-                // ---- barrier A2: the lo slice (and this head's proj / bias pieces) landed; every wave is done reading buffer 0 ----
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // ---- barrier A2: every wave is done reading buffer 0 (no memory wait: the lo slice landed before barrier A) ----
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (next_q) dma_qkv(head_of(hit + 1), 0, 0);   // next head's hi slice: in flight until the next barrier A
                 wq_l = wq_base + QKV_BYTES;
             }
@@ -316,6 +315,9 @@ __global__ __launch_bounds__(64 * NW, (CC == 256 && WT == 1) ? 2 : 1) void attnb
             // barrier: __syncthreads() would drain them
             if (next_q) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(QKV_FRAGS / NW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (WT == 2) {
+                if (next_q) dma_qkv(head_of(hit + 1), 1, 1);   // buffer 1 is free (every wave is past its second P1 pass): next head's lo slice
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
