@@ -94,6 +94,10 @@ class DeployPlan:
         # one box, scripts/r04_calls/call5.sh): logits max-abs 7.5e-4 -> 4.7e-4 (f16), 5.0e-4 -> 3.0e-4 (f16x2), 7.9e-4 -> 6.9e-4 (bf16x2) for
         # 81.0k -> 77.7k images/s (twice the K steps of 3 of the 15 convs).  Default 1 = single rounding: the plan that is timed.
         self.down_weight_terms = int(os.environ.get("FVIT_DOWN_WEIGHT_TERMS", "1"))
+        # 2 = two-term weights in EVERY 3x3 conv that runs on the implicit-GEMM kernel (the stem's second conv, the ConvBlock convs, the downsamples;
+        # the halo / band / fused-stem kernels take single-term weights, so those shapes fall back to the implicit GEMM): with the x3 HAT modes the
+        # "precise deploy" configuration -- 16-bit maps, everything else to ~22 bits
+        self.conv_weight_terms = int(os.environ.get("FVIT_CONV_WEIGHT_TERMS", "1"))
         self.fused_stem = os.environ.get("FVIT_NO_FUSED_STEM", "0") != "1"   # both PatchEmbed convs in one kernel when in_dim == dim == 64 (the 112x112x64 map never reaches HBM)
 
     # ---- folding -------------------------------------------------------------------------
@@ -176,7 +180,8 @@ class DeployPlan:
         pe = m.patch_embed.conv_down
         w0, b0 = _fold(pe[0], pe[1])
         w1, b1 = _fold(pe[3], pe[4])
-        t["stem"] = (self._cw(w0), self._padv(b0, self._cp(b0.numel())).contiguous(), self._cw(w1),
+        ct = 2 if self.conv_weight_terms == 2 else 1
+        t["stem"] = (self._cw(w0), self._padv(b0, self._cp(b0.numel())).contiguous(), self._cw(w1, terms=ct),
                      self._padv(b1, self._cp(b1.numel())).contiguous())
         t["stem_k"] = None
         if self.use_hip_conv and tuple(w0.shape) == (64, 3, 3, 3) and pe[0].stride == (2, 2):
@@ -192,7 +197,7 @@ class DeployPlan:
                     wa, ba = _fold(blk.conv1, blk.norm1)
                     wb, bb = _fold(blk.conv2, blk.norm2, blk.gamma if blk.layer_scale else None)
                     cpd = self._cp(ba.numel())
-                    blocks.append((self._cw(wa), self._padv(ba, cpd).contiguous(), self._cw(wb), self._padv(bb, cpd).contiguous()))
+                    blocks.append((self._cw(wa, terms=ct), self._padv(ba, cpd).contiguous(), self._cw(wb, terms=ct), self._padv(bb, cpd).contiguous()))
                 e["blocks"] = blocks
             elif getattr(lvl, "do_gt", False):
                 tk = lvl.global_tokenizer
@@ -203,7 +208,7 @@ class DeployPlan:
                 cin = ds.norm.weight.numel()
                 e["down"] = (self._padv(ds.norm.weight.float(), self._cp(cin)).contiguous(),
                              self._padv(ds.norm.bias.float(), self._cp(cin)).contiguous(), float(ds.norm.eps),
-                             self._cw(ds.reduction[0].weight.float(), terms=2 if self.down_weight_terms == 2 else 1), cin)
+                             self._cw(ds.reduction[0].weight.float(), terms=2 if (self.down_weight_terms == 2 or ct == 2) else 1), cin)
             t["levels"].append(e)
         if isinstance(m.head, torch.nn.Linear):
             hw = m.head.weight.float()
@@ -360,7 +365,7 @@ class DeployPlan:
             if lv_from > 0:
                 pass
             elif (self.fused_stem and t["stem_k"] is not None and x.shape[1] == 3 and x.dtype in hat_runtime._DT and wk1 is not None
-                    and tuple(wk1.shape) == (64, 3, 3, 64)):
+                    and w1[3] == 1 and tuple(wk1.shape) == (64, 3, 3, 64)):
                 B, _, Hi, Wi = x.shape
                 H1, W1 = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
                 y = torch.empty((B, 64, (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1), dtype=self.dtype, device=x.device,
