@@ -149,11 +149,6 @@ class Config:
                 self.runner.recompile()
             if self.streams > 1 and not a.no_graph and a.shard_launch == "free":
                 self.free_runner = self.plan.shard_runner(self.x, self.streams)
-            # part of the set-up, like the capture itself: a few dozen replays bring clocks, L2 / MALL contents and the allocator to the steady state the
-            # W + K steps of the contract then measure (FVIT_BENCH_SETTLE=0 disables; A/B in scripts/r04_calls/call12.sh)
-            for _ in range(int(os.environ.get("FVIT_BENCH_SETTLE", "30"))):
-                self.step()
-            torch.cuda.synchronize()
             return
         self.model.auto_deploy = a.mode == "auto"
         for _ in range(2):
