@@ -284,6 +284,13 @@ def test_gemm_residual_split_k(opname, dt, code, M, N, K):
     (the last shape) is not split and returns the unsplit kernel's bits."""
     lib = _lib.lib()
     lib.fvit_tune(b"gemm_splitk", 1)   # opt-in knob (negative end to end under the stream shards, see fvit_gemm.hip)
+    try:
+        _split_k_body(lib, dt, code, M, N, K)
+    finally:
+        lib.fvit_tune(b"gemm_splitk", 0)
+
+
+def _split_k_body(lib, dt, code, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(dt).cuda()
     W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda()
@@ -303,7 +310,6 @@ def test_gemm_residual_split_k(opname, dt, code, M, N, K):
     plain = x0.clone()
     _lib.check(lib.fvit_gemm_residual(code, Ap.data_ptr(), K, Wp.data_ptr(), K, bias.data_ptr(), gamma.data_ptr(), plain.data_ptr(), N, M, N, K, _stream()), "gemm_residual")
     torch.cuda.synchronize()
-    lib.fvit_tune(b"gemm_splitk", 0)
     ref = x0.double() + gamma.double() * (A.double() @ W.double().t() + bias.double())
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
     scale = ref.abs().max().item()
