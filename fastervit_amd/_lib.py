@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libfvit_hip.so")
 
-FVIT_ABI_VERSION = 6
+FVIT_ABI_VERSION = 7
 FVIT_F32, FVIT_F16, FVIT_BF16 = 0, 1, 2
 FVIT_TILE_N, FVIT_TILE_K = 128, 64
 FVIT_MASK_BIAS = -30000.0
@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "fvit_workspace_init", "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_token_init", "fvit_window_partition",
     "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_gemm_terms", "fvit_gemm_residual_splitk", "fvit_gemm_terms_lo", "fvit_window_attention_terms", "fvit_gather_layernorm_terms", "fvit_win_mlp_fused_terms", "fvit_win_mlp_split_bytes", "fvit_win_mlp_fused_split", "fvit_win_block_fused_split", "fvit_win_block_fused_terms", "fvit_attn_block_fused_terms", "fvit_ct_block_fused_terms", "fvit_window_attention", "fvit_window_attention_long",
     "fvit_gather_layernorm", "fvit_ln_gemm_supported", "fvit_ln_gemm", "fvit_attn_block_supported", "fvit_attn_block_fused", "fvit_ct_block_supported", "fvit_ct_block_fused", "fvit_win_block_supported", "fvit_win_block_fused", "fvit_win_mlp_supported", "fvit_win_mlp_fused", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl", "fvit_conv3x3_nhwc", "fvit_conv3x3_nhwc_terms", "fvit_conv3x3_c128_band_supported", "fvit_conv3x3_c128_band", "fvit_stem_conv3x3s2", "fvit_stem_fused",
+    "fvit_conv3x3_nhwc_px", "fvit_layernorm2d_px", "fvit_stem_conv3x3s2_px",
     "fvit_head_logits", "fvit_head_softmax_xent", "fvit_head_grad", "fvit_sgd_momentum",
     "fvit_debug_lds_poison", "fvit_debug_regs_poison", "fvit_debug_poison_launches", "fvit_debug_rowhash_begin", "fvit_debug_rowhash_end", "fvit_debug_rowhash_dump", "fvit_debug_mlp_trace_begin", "fvit_debug_mlp_trace_end", "fvit_debug_mlp_inputs_begin", "fvit_debug_mlp_inputs_end", "fvit_debug_win_mlp_timeline", "fvit_debug_stem_timeline", "fvit_debug_conv_band_timeline", "fvit_debug_attn_block_timeline", "fvit_debug_ct_block_timeline", "fvit_bwd_blocks", "fvit_bwd_transpose16", "fvit_bwd_scale_cols", "fvit_bwd_gelu", "fvit_bwd_layernorm", "fvit_bwd_colsum_finish", "fvit_bwd_colsum16", "fvit_bwd_window_attention", "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_records", "fvit_prof_kind_name",
 )
@@ -167,6 +168,12 @@ def _declare(lib):
     lib.fvit_conv3x3_nhwc.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.fvit_conv3x3_nhwc_terms.restype = C.c_int
     lib.fvit_conv3x3_nhwc_terms.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.fvit_conv3x3_nhwc_px.restype = C.c_int
+    lib.fvit_conv3x3_nhwc_px.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.fvit_layernorm2d_px.restype = C.c_int
+    lib.fvit_layernorm2d_px.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, f32, C.c_int64, i32, i32, vp]
+    lib.fvit_stem_conv3x3s2_px.restype = C.c_int
+    lib.fvit_stem_conv3x3s2_px.argtypes = [i32, C.POINTER(FvitMapView), vp, vp, vp, vp, i32, i32, i32, vp]
     lib.fvit_stem_conv3x3s2.restype = C.c_int
     lib.fvit_stem_conv3x3s2.argtypes = [i32, C.POINTER(FvitMapView), vp, vp, vp, i32, i32, i32, vp]
     lib.fvit_stem_fused.restype = C.c_int

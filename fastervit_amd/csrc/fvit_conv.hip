@@ -37,6 +37,12 @@ struct ConvParams {
     int ablate;   // experiment knob (wrong results when non-zero): 1 no X gather, 2 no W staging, 4 no MFMA, 8 no epilogue
     int wterms;   // weight terms (conv3x3_kernel only): 2 = rows [hi | lo] of 2 x 9 x Cin columns, every K step of the lo image re-reads the
                   // activation tile of the same (tap, channel) step -- the conv's weights to ~22 bits, its maps still rounded once
+    // two-term MAPS (r05, conv3x3_kernel<.., PX = true>; fvit_conv3x3_nhwc_px): a map is a pair of 16-bit planes, value = hi + lo
+    const void* in_lo;    // lo plane of the input or null.  With it (needs wterms == 2) K has a third segment: in.w_hi + in.w_lo + in_lo.w_hi
+    const void* res_lo;   // lo plane of the residual or null
+    void* out_lo;         // lo plane of the output (lo = round(y - hi)) or null
+    float* out_f32;       // the output as ONE fp32 map instead of out / out_lo, or null
+    int px;               // 1: the two-term-map instance (fvit_conv3x3_nhwc_px)
 };
 
 __device__ __forceinline__ int swz_x(int r) { return (r >> 1) & 7; }
@@ -65,7 +71,7 @@ __device__ __forceinline__ void dispatch_epilogue(int act, bool has_res, F&& bod
 }
 
 // per-wave tile: 64 pixels x 16*NI channels; workgroup tile: 64*WM pixels x 16*NI*WN channels (WM*WN = 4 waves)
-template <typename T, int WM, int WN, int NI>
+template <typename T, int WM, int WN, int NI, bool PX = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int BM = 64 * WM, BN = 16 * NI * WN;
@@ -120,11 +126,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 
     const int cpt = p.Cin / BK;  // K steps per tap
     const int nk1 = 9 * cpt;     // K steps of one weight term
+    // PX: element distance from the hi plane of the input to its lo plane (the third K segment reads the lo plane against the hi weights)
+    const int64_t lo_delta = (PX && p.in_lo) ? ((const T*)p.in_lo - In) : 0;
     auto stage = [&](int kt, char* xbuf, char* wbuf) {
-        const int kta = kt >= nk1 ? kt - nk1 : kt;   // the activation side wraps at the second weight term
+        const int seg = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
+        const int kta = kt - seg * nk1;              // the activation side wraps at every segment
+        const int ktw = seg == 2 ? kta : kt;         // segments 0 / 1 / 2 meet the weight images hi / lo / hi
         const int tap = kta / cpt, ci0 = (kta - tap * cpt) * BK;
         const int ky = tap / 3, kx = tap - ky * 3;
-        const int toff = (ky * p.Wi + kx) * p.Cin + ci0;
+        const int64_t toff = (ky * p.Wi + kx) * p.Cin + ci0 + ((PX && seg == 2) ? lo_delta : 0);
         if (!(p.ablate & 1))
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
             if (piece < WPIECES) {
                 const int r = piece * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ swz_w(r);
-                glds16(W + (size_t)(n0 + r) * ldw + kt * BK + c * 8, wbuf + piece * 1024);
+                glds16(W + (size_t)(n0 + r) * ldw + ktw * BK + c * 8, wbuf + piece * 1024);
             }
         }
     };
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.wterms * nk1;
+    const int nk = (p.wterms + ((PX && p.in_lo) ? 1 : 0)) * nk1;
     stage(0, smem, smem + 2 * X_BYTES);
 
     const int g = lane >> 4, s = lane & 15;
@@ -201,6 +211,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     }
     T* O = (T*)p.out;
     const T* R = (const T*)p.res;
+    if constexpr (PX) {
+        // two-term maps: the residual is hi + lo (fp32 sum), the result leaves as hi = round(y), lo = round(y - hi) -- or as one fp32 map for a
+        // consumer that is not an MFMA operand (the next transformer level's partition).  GELU by the 1.5e-7 erf: the polynomial's 5e-5 is a
+        // systematic error of the same size as the roundings this path removes.
+        const T* RL = (const T*)p.res_lo;
+        T* OL = (T*)p.out_lo;
+        float* OF = p.out_f32;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + s;
+            if (m < p.M) {
+                float y[NC];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[ni][mi][r] + bias[ni * 4 + r];
+                        if (p.act == 1) v = fmaxf(v, 0.f);
+                        else if (p.act == 2) v = gelu_erf(v);
+                        y[ni * 4 + r] = v;
+                    }
+                if (R) {
+                    const vout rv = *(const vout*)(R + (size_t)m * p.Cout + nb);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) y[j] += (float)rv[j];
+                    if (RL) {
+                        const vout rl = *(const vout*)(RL + (size_t)m * p.Cout + nb);
+#pragma unroll
+                        for (int j = 0; j < NC; ++j) y[j] += (float)rl[j];
+                    }
+                }
+                if (OF) {
+#pragma unroll
+                    for (int j = 0; j < NC; j += 4) *(f4*)(OF + (size_t)m * p.Cout + nb + j) = (f4){y[j], y[j + 1], y[j + 2], y[j + 3]};
+                } else {
+                    vout oh, ol;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) {
+                        oh[j] = sat16<T>(y[j]);
+                        ol[j] = sat16<T>(y[j] - (float)oh[j]);
+                    }
+                    *(vout*)(O + (size_t)m * p.Cout + nb) = oh;
+                    if (OL) *(vout*)(OL + (size_t)m * p.Cout + nb) = ol;
+                }
+            }
+        }
+        return;
+    }
     dispatch_epilogue(p.act, R != nullptr, [&](auto act_tag, auto res_tag) {
         constexpr int ACT = decltype(act_tag)::value;
         constexpr bool RES = decltype(res_tag)::value != 0;
@@ -251,6 +309,7 @@ struct StemParams {
     const float* bias;   // [64]
     void* out;           // [B][Ho][Wo][64]
     int B, Hi, Wi, Ho, Wo, M;
+    const void* w_lo;    // PX (fvit_stem_conv3x3s2_px): the second weight term, same layout; the image is split hi + lo in registers
 };
 
 __device__ __forceinline__ float stem_load(const FvitMapView& v, int64_t off) {
@@ -259,16 +318,20 @@ __device__ __forceinline__ float stem_load(const FvitMapView& v, int64_t off) {
     return (float)((const __bf16*)v.data)[off];
 }
 
-template <typename T>
+template <typename T, bool PX = false>
 __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
     typedef typename Op16<T>::v8 v8;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, s = lane & 15;
     // weights: fragment ni, A-row slot s -> channel (s>>2)*16 + ni*4 + (s&3): lane (g, .) owns channels 16g .. 16g+15
     const T* __restrict__ W = (const T*)p.w;
-    v8 wf[4];
+    v8 wf[4], wl[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const v8*)(W + ((s >> 2) * 16 + ni * 4 + (s & 3)) * 32 + g * 8);
+    if constexpr (PX) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) wl[ni] = *(const v8*)((const T*)p.w_lo + ((s >> 2) * 16 + ni * 4 + (s & 3)) * 32 + g * 8);
+    }
     float bias[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -298,19 +361,27 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
         const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
         const int yi = yo * 2 - 1, xi = xo * 2 - 1;
         const int64_t base = bb * p.in.stride_b + yi * p.in.stride_h + xi * p.in.stride_w;
-        v8 xf;
+        v8 xf, xl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int y = yi + tky[e], x = xi + tkx[e];
             const bool inb = y >= 0 && y < p.Hi && x >= 0 && x < p.Wi;
             // always issue the load (clamped to the pixel's own centre tap, which is always inside), then mask
             const int64_t off = inb ? base + toff[e] : base + p.in.stride_h + p.in.stride_w;
-            const float v = stem_load(p.in, off);
-            xf[e] = (T)(inb ? v : 0.f);
+            const float v0 = stem_load(p.in, off);
+            const float v = inb ? v0 : 0.f;
+            xf[e] = (T)v;
+            if constexpr (PX) xl[e] = (T)(v - (float)xf[e]);
         }
         f4 acc[4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = Op16<T>::mfma(wf[ni], xf, (f4){0.f, 0.f, 0.f, 0.f});
+        for (int ni = 0; ni < 4; ++ni) {
+            acc[ni] = Op16<T>::mfma(wf[ni], xf, (f4){0.f, 0.f, 0.f, 0.f});
+            if constexpr (PX) {   // image and weights as two terms each (the lo.lo product dropped): the K = 27 conv to ~22 bits
+                acc[ni] = Op16<T>::mfma(wl[ni], xf, acc[ni]);
+                acc[ni] = Op16<T>::mfma(wf[ni], xl, acc[ni]);
+            }
+        }
         if (ok) {
             v8 o0, o1;
 #pragma unroll
@@ -1058,13 +1129,14 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
 
 template <typename T>
 int launch_t(ConvParams& p, hipStream_t stream) {
-    if (p.Cin == 64 && p.Cout == 64 && p.stride == 1 && p.wterms == 1 && tune_get("conv_halo", 1)) {
+    if (p.Cin == 64 && p.Cout == 64 && p.stride == 1 && p.wterms == 1 && !p.px && tune_get("conv_halo", 1)) {
         if (ablate_skip(64)) return FVIT_OK;
         return launch_halo_t<T>(p, stream);
     }
     if (ablate_skip(32)) return FVIT_OK;
     const double flops = 2.0 * p.M * (double)p.Cout * 9.0 * p.Cin;
-    const double bytes = 2.0 * ((double)p.B * p.Hi * p.Wi * p.Cin + (double)p.M * p.Cout * (p.res ? 2.0 : 1.0) + 9.0 * p.wterms * p.Cin * p.Cout);
+    const double bytes = 2.0 * ((double)p.B * p.Hi * p.Wi * p.Cin * (p.in_lo ? 2.0 : 1.0) + (double)p.M * p.Cout * ((p.res ? (p.res_lo ? 2.0 : 1.0) : 0.0) + ((p.out_lo || p.out_f32) ? 2.0 : 1.0)) +
+                               9.0 * p.wterms * p.Cin * p.Cout);
     ProfScope prof(FVIT_K_CONV, flops, bytes, stream);   // (the second weight term is a precision cost, not algorithmic FLOPs)
     const int variant = tune_get("conv64_variant", 0);
     // 128x128 tiles run two workgroups per CU (64 KiB LDS): 512 slots.  A grid just above a multiple of 512 pays a whole extra
@@ -1073,6 +1145,19 @@ int launch_t(ConvParams& p, hipStream_t stream) {
     // (40.6 vs 44 us at 85-86 images, but 41 vs 30 us at 83), yet end to end they lose (68.1k vs 70.0k images/s: the other stream
     // shards' kernels fill the idle slots of a partial round anyway) => opt-in knob only.
     const int narrow = tune_get("conv128_narrow", 0);
+    if (p.px) {   // two-term maps: the implicit GEMM only (128 x 128 tiles when Cout allows, else 128 x 64)
+        p.tiles_m = (p.M + 127) / 128;
+        if (p.Cout % 128 == 0) {
+            p.tiles_n = p.Cout / 128;
+            prof_note("conv3x3_kernel<2,2,4,px>", p.tiles_m * p.tiles_n);
+            hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+        } else {
+            p.tiles_n = p.Cout / 64;
+            prof_note("conv3x3_kernel<2,2,2,px>", p.tiles_m * p.tiles_n);
+            hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+        }
+        return check_launch("conv3x3_kernel<px>");
+    }
     if (p.Cout % 128 == 0 && !narrow) {
         p.tiles_m = (p.M + 127) / 128;
         p.tiles_n = p.Cout / 128;
@@ -1121,6 +1206,7 @@ extern "C" int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void
     p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.act = act;
     p.ablate = tune_get("conv_ablate", 0);
     p.wterms = weight_terms;
+    p.in_lo = p.res_lo = nullptr; p.out_lo = nullptr; p.out_f32 = nullptr; p.px = 0;
     p.Ho = (Hi + 2 - 3) / stride + 1;
     p.Wo = (Wi + 2 - 3) / stride + 1;
     const int64_t M = (int64_t)B * p.Ho * p.Wo;
@@ -1135,14 +1221,52 @@ extern "C" int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void
     return FVIT_EINVAL;
 }
 
+extern "C" int fvit_conv3x3_nhwc_px(int32_t dtype, const void* in, const void* in_lo, const void* weight, const float* bias, const void* residual,
+                                    const void* residual_lo, void* out, void* out_lo, float* out_f32, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
+                                    int32_t Cout, int32_t stride, int32_t act, int32_t weight_terms, const void* zeros, fvit_stream_t stream) {
+    if (!in || !weight || (!out && !out_f32) || !zeros || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 64) ||
+        (stride != 1 && stride != 2) || act < 0 || act > 2 || (weight_terms != 1 && weight_terms != 2) || (in_lo && weight_terms != 2) ||
+        (residual_lo && !residual) || (out_f32 && out_lo) || (out_lo && !out)) {
+        set_error("conv3x3_px: unsupported arguments Cin=%d Cout=%d stride=%d act=%d weight_terms=%d (need Cin %% 64 == 0, Cout %% 64 == 0, stride 1|2, "
+                  "weight_terms 2 with a two-term input, out or out_f32)", Cin, Cout, stride, act, weight_terms);
+        return FVIT_EINVAL;
+    }
+    ConvParams p;
+    p.in = in; p.w = weight; p.bias = bias; p.res = residual; p.out = out; p.zeros = zeros;
+    p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.act = act;
+    p.ablate = 0;
+    p.wterms = weight_terms;
+    p.in_lo = in_lo; p.res_lo = residual_lo; p.out_lo = out_lo; p.out_f32 = out_f32; p.px = 1;
+    p.Ho = (Hi + 2 - 3) / stride + 1;
+    p.Wo = (Wi + 2 - 3) / stride + 1;
+    const int64_t M = (int64_t)B * p.Ho * p.Wo;
+    if (M > 0x7fffffff) {
+        set_error("conv3x3_px: %lld output pixels exceed the 32-bit row index", (long long)M);
+        return FVIT_EINVAL;
+    }
+    p.M = (int)M;
+    if (dtype == FVIT_F16) return launch_t<_Float16>(p, (hipStream_t)stream);
+    if (dtype == FVIT_BF16) return launch_t<__bf16>(p, (hipStream_t)stream);
+    set_error("conv3x3_px: dtype %d not supported (16-bit planes only)", dtype);
+    return FVIT_EINVAL;
+}
+
+extern "C" int fvit_stem_conv3x3s2_px(int32_t dtype, const FvitMapView* in, const void* weight, const void* weight_lo, const float* bias, void* out,
+                                      int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream);
+
 extern "C" int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const void* weight, const float* bias, void* out, int32_t B,
                                    int32_t Hi, int32_t Wi, fvit_stream_t stream) {
+    return fvit_stem_conv3x3s2_px(dtype, in, weight, nullptr, bias, out, B, Hi, Wi, stream);
+}
+
+extern "C" int fvit_stem_conv3x3s2_px(int32_t dtype, const FvitMapView* in, const void* weight, const void* weight_lo, const float* bias, void* out,
+                                      int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream) {
     if (!in || !in->data || !weight || !bias || !out || B <= 0 || Hi <= 0 || Wi <= 0) {
         set_error("stem_conv: null or empty argument");
         return FVIT_EINVAL;
     }
     StemParams p;
-    p.in = *in; p.w = weight; p.bias = bias; p.out = out; p.B = B; p.Hi = Hi; p.Wi = Wi;
+    p.in = *in; p.w = weight; p.w_lo = weight_lo; p.bias = bias; p.out = out; p.B = B; p.Hi = Hi; p.Wi = Wi;
     p.Ho = (Hi - 1) / 2 + 1;
     p.Wo = (Wi - 1) / 2 + 1;
     const int64_t M = (int64_t)B * p.Ho * p.Wo;
@@ -1156,7 +1280,9 @@ extern "C" int fvit_stem_conv3x3s2(int32_t dtype, const FvitMapView* in, const v
     if (grid > 256 * 32) grid = 256 * 32;
     const double bytes = (double)B * 3 * Hi * Wi * (in->dtype == FVIT_F32 ? 4 : 2) + 2.0 * M * 64;
     ProfScope prof(FVIT_K_CONV, 2.0 * M * 64 * 27, bytes, (hipStream_t)stream);
-    if (dtype == FVIT_F16) hipLaunchKernelGGL((stem_conv_kernel<_Float16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (dtype == FVIT_F16 && weight_lo) hipLaunchKernelGGL((stem_conv_kernel<_Float16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (dtype == FVIT_BF16 && weight_lo) hipLaunchKernelGGL((stem_conv_kernel<__bf16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (dtype == FVIT_F16) hipLaunchKernelGGL((stem_conv_kernel<_Float16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else if (dtype == FVIT_BF16) hipLaunchKernelGGL((stem_conv_kernel<__bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else {
         set_error("stem_conv: dtype %d not supported (16-bit output only)", dtype);

@@ -46,6 +46,8 @@ struct GemmParams {
     float* slab;  // EPI 3: f32 [splits][M][N] partial sums (no bias); splitk_reduce_kernel adds them in split order and applies the residual epilogue
     int tiles_m, tiles_n;
     int stagger;  // 1: workgroup (tm, tn) walks the K tiles starting at a tile-dependent offset (see gemm_kernel)
+    int x3;       // 1 (X3 instances, K = 3 x ka): "dual" K loop -- a K tile is 32 contraction indices of BOTH terms of both operands: LDS rows hold
+                  // [hi k0..k0+31 | lo k0..k0+31] (the lo image at column ka of the same global row), and the tile contributes w_hi.a_hi + w_lo.a_hi + w_hi.a_lo
     const float* add;        // residual epilogue: optional row table added after the update (see GemmCall)
     const int32_t* add_idx;
     int rpi;
@@ -64,7 +66,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 
 template <typename T, bool IS_W, int ROWS, int NW>
 __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int row0, int k0, char* tile,
-                                           int wave, int lane, int rmax) {
+                                           int wave, int lane, int rmax, int lo_col = 0) {
     // ROWS/8 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces PW*w .. PW*w + PW-1.
     constexpr int PW = ROWS / 8 / NW;
     static_assert(PW >= 1, "tile too small for this many waves");
@@ -75,7 +77,9 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
         const int f = IS_W ? swz_w(r) : swz_x(r);
         const int c = (lane & 7) ^ f;
         // rows are clamped to the last row of the (128-row padded) operand: the 256-row tiles reach up to 128 rows further
-        const T* src = g + (size_t)min(row0 + r, rmax) * ld + k0 + c * 8;
+        // lo_col > 0 (dual x3 tiles): chunks 0-3 of the LDS row = 32 columns of the hi image at k0, chunks 4-7 = the same 32 columns of the lo image
+        const int col = lo_col > 0 ? k0 + (c & 3) * 8 + ((c >> 2) ? lo_col : 0) : k0 + c * 8;
+        const T* src = g + (size_t)min(row0 + r, rmax) * ld + col;
         glds16(src, tile + piece * 1024);
     }
 }
@@ -100,7 +104,7 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
 //     them (2.7 MFMAs per ds_read_b128 against 2.0 for the 128 x 128 tile), and a byte staged into LDS is used by 4 (activations) / 2
 //     (weights) waves: the shape for the large Linear layers of FasterViT-4 (K = 832 ... 6272), where the 128 x 128 tile plateaus
 //     at 0.22-0.25 of the MFMA peak.
-template <typename T, int EPI, int NSTAGE, int MI, int NW, int NI = 4>
+template <typename T, int EPI, int NSTAGE, int MI, int NW, int NI = 4, bool X3 = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int BMT = (NW / 2) * 16 * MI;            // rows of the workgroup tile (NW/2 waves along M)
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk_all = p.K / BK;
+    const int nk_all = X3 ? p.ka / 32 : p.K / BK;   // X3: one tile per 32 contraction indices (all three products)
     const int k_lo = EPI == 3 ? sp * nk_all / p.splits : 0;
     const int nk = EPI == 3 ? (sp + 1) * nk_all / p.splits - k_lo : nk_all;
     // K-order stagger: the workgroups of an XCD that share an activation panel (same tm) or a weight panel (same tn) start at
@@ -149,14 +153,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
         rot = (tn * per + tm) % nk;
     }
     auto ktile = [&](int kt) { const int k = kt + rot; return k_lo + (k >= nk ? k - nk : k); };
-    auto acol = [&](int kt) { const int k = ktile(kt) * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1, 2 or 3 x ka: terms [hi w | lo w | hi w] meet A columns [hi | hi | lo]
+    auto acol = [&](int kt) { if (X3) return ktile(kt) * 32; const int k = ktile(kt) * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1, 2 or 3 x ka: terms [hi w | lo w | hi w] meet A columns [hi | hi | lo]
+    auto wcol = [&](int kt) { return ktile(kt) * (X3 ? 32 : BK); };
+    const int lo_col = X3 ? p.ka : 0;
     char* const xring = smem;
     char* const wring = smem + NSTAGE * XT_BYTES;
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st) {
         if (st < nk) {
-            stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(st), xring + st * XT_BYTES, wave, lane, p.arow_max);
-            stage_tile<T, true, BNT, NW>(W, p.ldw, n0, ktile(st) * BK, wring + st * WT_BYTES, wave, lane, p.wrow_max);
+            stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(st), xring + st * XT_BYTES, wave, lane, p.arow_max, lo_col);
+            stage_tile<T, true, BNT, NW>(W, p.ldw, n0, wcol(st), wring + st * WT_BYTES, wave, lane, p.wrow_max, lo_col);
         }
     }
 
@@ -189,13 +195,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             int slot = cur + NSTAGE - 1;
             if (slot >= NSTAGE) slot -= NSTAGE;
             if (nxt < nk) {
-                stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(nxt), xring + slot * XT_BYTES, wave, lane, p.arow_max);
-                stage_tile<T, true, BNT, NW>(W, p.ldw, n0, ktile(nxt) * BK, wring + slot * WT_BYTES, wave, lane, p.wrow_max);
+                stage_tile<T, false, BMT, NW>(A, p.lda, m0, acol(nxt), xring + slot * XT_BYTES, wave, lane, p.arow_max, lo_col);
+                stage_tile<T, true, BNT, NW>(W, p.ldw, n0, wcol(nxt), wring + slot * WT_BYTES, wave, lane, p.wrow_max, lo_col);
             }
         }
         const char* xt = xring + cur * XT_BYTES;
         const char* wt = wring + cur * WT_BYTES;
         if constexpr (NI == 8) {
+            static_assert(!X3, "the dual x3 K loop needs both chunk halves of a tile at once: 128-column tiles or gemm_pp_kernel");
             // 256-column tile: one 32-deep half at a time (12 fragments = 48 registers in flight beside the 128 accumulators); the
             // SIMD's second wave covers the LDS round trip
 #pragma unroll
@@ -225,12 +232,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
             for (int i = 0; i < 4; ++i) wf[kk][i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (X3) {   // chunk half 0 = hi, half 1 = lo of the same 32 contraction indices: w_hi.a_hi + w_lo.a_hi + w_hi.a_lo
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[pr == 1][ni], xf[pr == 2][mi], acc[ni][mi]);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[kk][ni], xf[kk][mi], acc[ni][mi]);
+        }
         }
         if (++cur == NSTAGE) cur = 0;
     }
@@ -375,7 +391,7 @@ template <bool V> struct BoolTag { static constexpr bool value = V; };
 //           still one barrier before group 0 reads K tile t+1.
 // The loads are never drained inside the loop and there is no point where all eight waves wait for memory at once.
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int EPI>
+template <typename T, int EPI, bool X3 = false>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int HT = 128 * BK * 2;            // half-tile bytes
@@ -396,10 +412,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
 
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ W = (const T*)p.W;
-    const int nk = p.K / BK;
-    auto acol = [&](int kt) { const int k = kt * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1, 2 or 3 x ka (see gemm_kernel)
-    auto req_x = [&](int h, int kt, char* buf) { stage_tile<T, false, 128, 8>(A, p.lda, m0 + 128 * h, acol(kt), buf + h * HT, wave, lane, p.arow_max); };
-    auto req_w = [&](int h, int kt, char* buf) { stage_tile<T, true, 128, 8>(W, p.ldw, n0 + 128 * h, kt * BK, buf + (2 + h) * HT, wave, lane, p.wrow_max); };
+    const int nk = X3 ? p.ka / 32 : p.K / BK;   // X3: dual tiles of 32 contraction indices x {hi, lo} (see GemmParams.x3)
+    const int lo_col = X3 ? p.ka : 0;
+    auto acol = [&](int kt) { if (X3) return kt * 32; const int k = kt * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1, 2 or 3 x ka (see gemm_kernel)
+    auto req_x = [&](int h, int kt, char* buf) { stage_tile<T, false, 128, 8>(A, p.lda, m0 + 128 * h, acol(kt), buf + h * HT, wave, lane, p.arow_max, lo_col); };
+    auto req_w = [&](int h, int kt, char* buf) { stage_tile<T, true, 128, 8>(W, p.ldw, n0 + 128 * h, kt * (X3 ? 32 : BK), buf + (2 + h) * HT, wave, lane, p.wrow_max, lo_col); };
 
     f4 acc[4][8];  // [ni][mi]
 #pragma unroll
@@ -441,10 +458,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     if ((a_) == 0 && (b_) == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   /* phase 2: the W reads retire before the barrier */ \
     else asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                           \
     __builtin_amdgcn_s_setprio(1);                                                                                 \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                               \
+    _Pragma("unroll") for (int kk = 0; kk < (X3 ? 3 : 2); ++kk)                                                    \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                           \
             _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                       \
-                acc[(b_) * 2 + ni][(a_) * 4 + mi] = Op16<T>::mfma(wsrc_[kk][ni], xf[kk][mi], acc[(b_) * 2 + ni][(a_) * 4 + mi]); \
+                acc[(b_) * 2 + ni][(a_) * 4 + mi] = Op16<T>::mfma(wsrc_[X3 ? (kk == 1) : kk][ni], xf[X3 ? (kk == 2) : kk][mi], acc[(b_) * 2 + ni][(a_) * 4 + mi]); \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     asm volatile("s_barrier" ::: "memory");                                                                       \
@@ -655,6 +672,11 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     }
     ProfScope prof(kind, flops, bytes, stream);
     const bool pp = big && tune_get("gemm_pp", 1);
+    // "dual" K loop of the x3 operand modes (r05, fvit_tune "gemm_x3_dual" = 0 restores the K-concatenated walk): [hi | hi | lo] x [hi | lo | hi] stages the
+    // hi activation tile twice and the hi weight tile twice -- six operand tiles from L2 for three products; the dual tile holds 32 contraction indices of
+    // both terms of both operands -- four tiles for the same three products, and 24 instead of 16 MFMAs behind every barrier
+    const bool x3 = c.K == 3 * p.ka && c.lda >= 2 * p.ka && (pp || !big) && splits == 1 && !nw8 && !p.stagger && tune_get("gemm_x3_dual", 1);
+    p.x3 = x3 ? 1 : 0;
     prof_note(c.epilogue == 2 ? (pp ? "gemm_pp_kernel<2> 256x256" : big ? "gemm_kernel<2> 256x256" : small ? "gemm_kernel<2> 64-row" : "gemm_kernel<2> 128-row")
                               : c.epilogue == 1 ? (pp ? "gemm_pp_kernel<1> 256x256" : big ? "gemm_kernel<1> 256x256" : small ? "gemm_kernel<1> 64-row" : "gemm_kernel<1> 128-row")
                                                 : (pp ? "gemm_pp_kernel<0> 256x256" : big ? "gemm_kernel<0> 256x256" : small ? "gemm_kernel<0> 64-row" : "gemm_kernel<0> 128-row"), grid);
@@ -670,7 +692,21 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
                                            default: FVIT_GEMM(2, NS, MI_, NW_); break; }
     // the ping-pong form of the 256 x 256 tile (default since r03: 8-25 % faster than the 2-stage form on every shape that selects the tile,
     // bitwise the same result; FasterViT-4 batch 128 + 0.7 %, any-res + 0.6 % end to end -- profiles/r03_gemm_ping_pong_256_tile.log)
-    if (pp) {
+    if (x3) {
+#define FVIT_GEMM_X3(E, MI_) hipLaunchKernelGGL((gemm_kernel<T, E, 2, MI_, 4, 4, true>), dim3(grid), dim3(256), 0, stream, p)
+        if (pp) {
+            switch (c.epilogue) {
+                case 0: hipLaunchKernelGGL((gemm_pp_kernel<T, 0, true>), dim3(grid), dim3(512), 0, stream, p); break;
+                case 1: hipLaunchKernelGGL((gemm_pp_kernel<T, 1, true>), dim3(grid), dim3(512), 0, stream, p); break;
+                default: hipLaunchKernelGGL((gemm_pp_kernel<T, 2, true>), dim3(grid), dim3(512), 0, stream, p); break;
+            }
+        } else if (small) {
+            switch (c.epilogue) { case 0: FVIT_GEMM_X3(0, 2); break; case 1: FVIT_GEMM_X3(1, 2); break; default: FVIT_GEMM_X3(2, 2); break; }
+        } else {
+            switch (c.epilogue) { case 0: FVIT_GEMM_X3(0, 4); break; case 1: FVIT_GEMM_X3(1, 4); break; default: FVIT_GEMM_X3(2, 4); break; }
+        }
+#undef FVIT_GEMM_X3
+    } else if (pp) {
         switch (c.epilogue) {
             case 0: hipLaunchKernelGGL((gemm_pp_kernel<T, 0>), dim3(grid), dim3(512), 0, stream, p); break;
             case 1: hipLaunchKernelGGL((gemm_pp_kernel<T, 1>), dim3(grid), dim3(512), 0, stream, p); break;

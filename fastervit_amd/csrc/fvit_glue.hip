@@ -52,9 +52,12 @@ __global__ __launch_bounds__(256) void bias_kernel(T* __restrict__ x, const T* _
 
 // LPP lanes cooperate on one pixel (64 / LPP pixels per wave); the pixel's C channels live in registers,
 // 8 per lane and per step (MAXV steps).  LPP = 8 for C = 64 so that narrow maps still use every lane.
-template <typename T, int LPP, int MAXV>
+// PX (fvit_layernorm2d_px): the input is a two-term map (in + in_lo, 16-bit planes) or ONE fp32 map (in_f32), the output two planes out / out_lo
+template <typename T, int LPP, int MAXV, bool PX = false>
 __global__ __launch_bounds__(256) void ln2d_kernel(const T* __restrict__ in, T* __restrict__ out, const float* __restrict__ w,
-                                                   const float* __restrict__ b, float eps, int64_t npix, int C, int Cv) {
+                                                   const float* __restrict__ b, float eps, int64_t npix, int C, int Cv,
+                                                   const T* __restrict__ in_lo = nullptr, const float* __restrict__ in_f32 = nullptr,
+                                                   T* __restrict__ out_lo = nullptr) {
     typedef T v8 __attribute__((ext_vector_type(8)));
     constexpr int PPW = 64 / LPP;  // pixels per wave
     const int lane = threadIdx.x & 63;
@@ -62,16 +65,32 @@ __global__ __launch_bounds__(256) void ln2d_kernel(const T* __restrict__ in, T* 
     const int64_t pix = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LPP;
     const bool ok = pix < npix;
     const int C8 = C >> 3;
-    const T* src = in + (ok ? pix : 0) * C;
+    const T* src = (PX && in_f32) ? nullptr : in + (ok ? pix : 0) * C;
     float v[MAXV][8];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c8 = sub + i * LPP;
         if (c8 < C8) {
-            const v8 t = *((const v8*)src + c8);
+            if (PX && in_f32) {
+                const float* sf = in_f32 + (ok ? pix : 0) * C + c8 * 8;
+                const f4 t0 = *(const f4*)sf, t1 = *(const f4*)(sf + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; sum += v[i][j]; }
+                for (int j = 0; j < 4; ++j) { v[i][j] = t0[j]; v[i][4 + j] = t1[j]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += v[i][j];
+            } else {
+                const v8 t = *((const v8*)src + c8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = (float)t[j];
+                if (PX && in_lo) {
+                    const v8 tl = *((const v8*)(in_lo + (ok ? pix : 0) * C) + c8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[i][j] += (float)tl[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += v[i][j];
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
@@ -98,10 +117,15 @@ __global__ __launch_bounds__(256) void ln2d_kernel(const T* __restrict__ in, T* 
     for (int i = 0; i < MAXV; ++i) {
         const int c8 = sub + i * LPP;
         if (c8 < C8) {
-            v8 o;
+            v8 o, ol;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (T)((v[i][j] - mean) * rstd * w[c8 * 8 + j] + b[c8 * 8 + j]);
+            for (int j = 0; j < 8; ++j) {
+                const float y = (v[i][j] - mean) * rstd * w[c8 * 8 + j] + b[c8 * 8 + j];
+                o[j] = (T)y;
+                if (PX) ol[j] = (T)(y - (float)o[j]);
+            }
             *((v8*)dst + c8) = o;
+            if (PX && out_lo) *((v8*)(out_lo + pix * C) + c8) = ol;
         }
     }
 }
@@ -123,17 +147,20 @@ int bias_launch(T* x, const T* y, const float* bias, int64_t n, int C, int act, 
 }
 
 template <typename T>
-int ln2d_launch(const T* in, T* out, const float* w, const float* b, float eps, int64_t npix, int C, int Cv, hipStream_t stream) {
+int ln2d_launch(const T* in, T* out, const float* w, const float* b, float eps, int64_t npix, int C, int Cv, hipStream_t stream, bool px = false,
+                const T* in_lo = nullptr, const float* in_f32 = nullptr, T* out_lo = nullptr) {
     const int c8 = C / 8;
-#define FVIT_LN2D(LPP, MAXV)                                                                                          \
-    hipLaunchKernelGGL((ln2d_kernel<T, LPP, MAXV>), dim3((unsigned)((npix + 4 * (64 / LPP) - 1) / (4 * (64 / LPP)))), \
-                       dim3(256), 0, stream, in, out, w, b, eps, npix, C, Cv)
-    if (c8 <= 8) FVIT_LN2D(8, 1);
-    else if (c8 <= 16) FVIT_LN2D(16, 1);
-    else if (c8 <= 32) FVIT_LN2D(32, 1);
-    else if (c8 <= 64) FVIT_LN2D(64, 1);
-    else if (c8 <= 128) FVIT_LN2D(64, 2);
-    else if (c8 <= 256) FVIT_LN2D(64, 4);
+#define FVIT_LN2D(LPP, MAXV)                                                                                                       \
+    if (px) hipLaunchKernelGGL((ln2d_kernel<T, LPP, MAXV, true>), dim3((unsigned)((npix + 4 * (64 / LPP) - 1) / (4 * (64 / LPP)))), \
+                               dim3(256), 0, stream, in, out, w, b, eps, npix, C, Cv, in_lo, in_f32, out_lo);                        \
+    else hipLaunchKernelGGL((ln2d_kernel<T, LPP, MAXV>), dim3((unsigned)((npix + 4 * (64 / LPP) - 1) / (4 * (64 / LPP)))),           \
+                            dim3(256), 0, stream, in, out, w, b, eps, npix, C, Cv, nullptr, nullptr, nullptr)
+    if (c8 <= 8) { FVIT_LN2D(8, 1); }
+    else if (c8 <= 16) { FVIT_LN2D(16, 1); }
+    else if (c8 <= 32) { FVIT_LN2D(32, 1); }
+    else if (c8 <= 64) { FVIT_LN2D(64, 1); }
+    else if (c8 <= 128) { FVIT_LN2D(64, 2); }
+    else if (c8 <= 256) { FVIT_LN2D(64, 4); }
     else {
         set_error("layernorm2d: C=%d too wide (max 2048)", C);
         return FVIT_EINVAL;
@@ -187,6 +214,22 @@ int fvit_layernorm2d_cl(int32_t dtype, const void* in, void* out, const float* w
     if (dtype == FVIT_F16) return ln2d_launch<_Float16>((const _Float16*)in, (_Float16*)out, weight, bias, eps, n_pixels, C, C_valid, (hipStream_t)stream);
     if (dtype == FVIT_BF16) return ln2d_launch<__bf16>((const __bf16*)in, (__bf16*)out, weight, bias, eps, n_pixels, C, C_valid, (hipStream_t)stream);
     set_error("layernorm2d: dtype %d not supported (16-bit maps only)", dtype);
+    return FVIT_EINVAL;
+}
+
+int fvit_layernorm2d_px(int32_t dtype, const void* in, const void* in_lo, const float* in_f32, void* out, void* out_lo, const float* weight,
+                        const float* bias, float eps, int64_t n_pixels, int32_t C, int32_t C_valid, fvit_stream_t stream) {
+    if (C_valid <= 0) C_valid = C;
+    if ((!in && !in_f32) || (in && in_f32) || (in_lo && !in) || !out || !weight || !bias || n_pixels <= 0 || C <= 0 || (C % 8) || C_valid > C) {
+        set_error("layernorm2d_px: bad arguments (one of in / in_f32, C=%d a multiple of 8, C_valid=%d <= C)", C, C_valid);
+        return FVIT_EINVAL;
+    }
+    ProfScope prof(FVIT_K_OTHER, 0.0, (double)n_pixels * C * ((in_f32 ? 4.0 : (in_lo ? 4.0 : 2.0)) + (out_lo ? 4.0 : 2.0)), (hipStream_t)stream);
+    if (dtype == FVIT_F16) return ln2d_launch<_Float16>((const _Float16*)in, (_Float16*)out, weight, bias, eps, n_pixels, C, C_valid, (hipStream_t)stream, true,
+                                                        (const _Float16*)in_lo, in_f32, (_Float16*)out_lo);
+    if (dtype == FVIT_BF16) return ln2d_launch<__bf16>((const __bf16*)in, (__bf16*)out, weight, bias, eps, n_pixels, C, C_valid, (hipStream_t)stream, true,
+                                                       (const __bf16*)in_lo, in_f32, (__bf16*)out_lo);
+    set_error("layernorm2d_px: dtype %d not supported (16-bit planes only)", dtype);
     return FVIT_EINVAL;
 }
 

@@ -23,11 +23,12 @@ class CompiledInference:
       eval mode), other image sizes raise.
     * the returned logits are a view of the runner's static output buffer: they are overwritten by the next call (clone to keep).
     * ``join_from`` (optional): the stream shards join in front of that level and the rest of the network runs on the whole batch.
+    * ``precise`` (optional): the two-term-stream conv plan (``DeployPlan.precise``).
     * a weight update after compilation is NOT picked up by the graph (its packed copies are baked in); call ``recompile()``.
     """
 
     def __init__(self, model, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True, join_from=None,
-                 conv_down_terms: Optional[int] = None):
+                 conv_down_terms: Optional[int] = None, precise: bool = False):
         if not example.is_cuda:
             raise RuntimeError("compile_inference: the example input must be on a HIP device (no CPU fallback)")
         if model.training:
@@ -40,6 +41,9 @@ class CompiledInference:
         # join_from = L: the shards run levels [0, L) on their streams, join, and levels [L, end) + head run once on the whole batch
         # (DeployPlan._forward_sharded).  FasterViT-0 at batch 256: streams = 2, join_from = 3 is the measured optimum (bench.py)
         self.plan.join_from = join_from
+        # precise = True: two-term / fp32 streams and two-term weights on the conv side (DeployPlan.precise); with the HAT operand mode "f16x3"
+        # (model.set_hat_operand_dtype) the configuration that meets logits max-abs < 1e-3 ABSOLUTE on FasterViT-4 / any-res
+        self.plan.precise = bool(precise)
         if conv_down_terms is not None:   # 2 = two-term weights in the Downsample.reduction convs: the accuracy option of the 16-bit plan (DeployPlan)
             self.plan.down_weight_terms = int(conv_down_terms)
         self.use_graph = bool(graph)

@@ -545,13 +545,15 @@ class FasterViT(nn.Module):
             plans[dt].streams = int(self.auto_deploy_streams)
         return plans[dt], dt
 
-    def compile_inference(self, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True, join_from=None, conv_down_terms=None):
+    def compile_inference(self, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True, join_from=None, conv_down_terms=None,
+                          precise: bool = False):
         """Throughput entry point: the deploy plan with ``streams`` stream shards captured ONCE into a hipGraph
         with static input / output buffers; returns a callable ``runner(x) -> logits`` that copies ``x`` in and replays the
         graph (any batch size up to the example's; shorter batches are zero-padded and the result sliced).  See
         ``fastervit_amd.inference.CompiledInference``."""
         from ..inference import CompiledInference
-        return CompiledInference(self, example, dtype=dtype, streams=streams, graph=graph, join_from=join_from, conv_down_terms=conv_down_terms)
+        return CompiledInference(self, example, dtype=dtype, streams=streams, graph=graph, join_from=join_from, conv_down_terms=conv_down_terms,
+                                 precise=precise)
 
     def enable_hat_backward(self, on: bool = True):
         """Make the transformer stages differentiable in EVAL mode: with grad enabled every HAT stage becomes ONE autograd node whose forward is the HIP

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FVIT_ABI_VERSION 6
+#define FVIT_ABI_VERSION 7
 
 /* error codes */
 #define FVIT_OK 0
@@ -419,6 +419,33 @@ int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weight, const f
 int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual,
                             void* out, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride,
                             int32_t act, int32_t weight_terms, const void* zeros, fvit_stream_t stream);
+
+/* ---- two-term MAPS (r05; the "precise" deploy plan, fastervit_amd/conv_runtime.py) -------------------------------------------------------
+ * A conv-side stream is a pair of 16-bit channels-last planes (value = hi + lo, lo = round(v - hi): ~22 significant bits) or, in front of /
+ * behind a transformer level, one fp32 map.  Why: replaying the fp32 reference with ONE 16-bit rounding at a time (tests/tools/
+ * conv_precision_sim.py, faster_vit_4_224) a rounded conv OPERAND costs 2-8e-5 of logits error, a rounded STORED stream (the residual stream of
+ * the ConvBlocks FV:502-512, the Downsample outputs FV:437-440, a transformer level's output map) 3-4e-4 each, the LayerNorm2d -> strided conv
+ * operand 3.6e-4.  The reference keeps all of these in fp32.
+ *
+ * fvit_conv3x3_nhwc_px: fvit_conv3x3_nhwc_terms on such maps.
+ *   in / in_lo          input planes; in_lo NULL = the input as ONE term (the hi plane is the MFMA operand).  With in_lo (needs weight_terms 2)
+ *                       the contraction runs in.w_hi + in.w_lo + in_lo.w_hi (the lo.lo product dropped, relative 2^-22)
+ *   residual / _lo      residual planes (lo optional), added in fp32; may alias out / out_lo (in-place update of the stream)
+ *   out / out_lo        output planes: hi = round(y); lo = round(y - hi) when out_lo is given
+ *   out_f32             instead of out / out_lo: the output as one fp32 map [B][Ho][Wo][Cout]
+ *   act 2 uses the 1.5e-7-accurate erf GELU (the 16-bit entry points use a 5e-5 polynomial). */
+int fvit_conv3x3_nhwc_px(int32_t dtype, const void* in, const void* in_lo, const void* weight, const float* bias, const void* residual,
+                         const void* residual_lo, void* out, void* out_lo, float* out_f32, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
+                         int32_t Cout, int32_t stride, int32_t act, int32_t weight_terms, const void* zeros, fvit_stream_t stream);
+/* fvit_layernorm2d_cl on a two-term map (in + in_lo; in_lo may be NULL) or an fp32 map (in_f32, then in = in_lo = NULL); the result as two
+ * planes (out_lo may be NULL).  Statistics and affine in fp32 (timm LayerNorm2d, FV:432,438). */
+int fvit_layernorm2d_px(int32_t dtype, const void* in, const void* in_lo, const float* in_f32, void* out, void* out_lo, const float* weight,
+                        const float* bias, float eps, int64_t n_pixels, int32_t C, int32_t C_valid, fvit_stream_t stream);
+/* fvit_stem_conv3x3s2 with the K = 27 weights as two terms (weight_lo: same [64][32] layout; NULL = fvit_stem_conv3x3s2) and the image split
+ * hi + lo in registers: w_hi.x_hi + w_lo.x_hi + w_hi.x_lo.  The first conv's weight rounding is systematic (2.2e-4 of logits error on
+ * faster_vit_4_224), its image rounding 1.2e-4. */
+int fvit_stem_conv3x3s2_px(int32_t dtype, const FvitMapView* in, const void* weight, const void* weight_lo, const float* bias, void* out,
+                           int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream);
 
 /* The same convolution for Cin = Cout = 128, stride 1, maps up to 30 pixels wide (level 1 of FasterViT-0: 28 x 28), one ROW BAND of an
  * image per workgroup: the band's input rows + halo go to LDS once, the weights stream from L2 into registers in MFMA fragment order.

@@ -66,7 +66,7 @@ def test_printed_line_is_compact_and_carries_the_contract():
     The full r03 record goes through the compaction the live run uses: < 8 KB, valid JSON, contract keys + roofline + cpu_baseline."""
     import bench
     full = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_final.json")).read().strip().splitlines()[-1])
-    line = bench.compact_line(full, "profiles/bench_last.json")
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
     assert len(line) < bench.LINE_BUDGET <= 8000 and "\n" not in line
     c = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -81,3 +81,24 @@ def test_printed_line_is_compact_and_carries_the_contract():
     # a record bloated with prose still fits: optional blocks are dropped before the contract keys
     full["secondary"] = full["secondary"] * 20
     assert len(bench.compact_line(full)) < bench.LINE_BUDGET
+
+
+def test_one_slow_launch_does_not_flip_the_dominant_kernel():
+    """in the r04 driver run ONE outlier launch moved ctblk8's mean event time from 34 to 58 us and the parsed roofline named
+    the wrong kernel.  The per-launch duration is now the average of the launches within 1.5 x the median of their (kernel, shape)."""
+    import bench
+    recs = []
+    for step in range(3):
+        for i in range(12):
+            recs.append(dict(kind="win_mlp", name="winmlp_kernel<256>", grid=424, flops=28.454e9, bytes=56.6e6, ms=0.0545))
+            ms = 0.900 if (step == 0 and i == 0) else 0.0326      # one launch stalls for 0.9 ms
+            recs.append(dict(kind="ct_block", name="ctblk8_kernel<256,G16>", grid=128, flops=0.9e9, bytes=5.8e6, ms=ms))
+    shapes = bench.summarize_launches(recs, 3)
+    dom, fam_ms = bench.dominant_by_time(bench.shapes_cu(shapes))
+    assert dom["kernel"] == "winmlp_kernel<256>" and dom["launches_per_step"] == 12
+    ct = next(r for r in shapes if r["kernel"].startswith("ctblk8"))
+    assert abs(ct["avg_launch_us"] - 32.6) < 0.1 and ct["outlier_launches_dropped"] == 1
+    # ... and a live timer that disagrees with the committed kernel trace by more than 25 % is flagged in the line
+    e = bench.roofline_entry(dict(dom, avg_launch_us=100.0), "f16", fam_ms)
+    if "avg_launch_us_rocprof" in e:
+        assert "timer_mismatch" in e and e["event_vs_rocprof"] > 0.25

@@ -61,17 +61,19 @@ def test_deploy_forward_is_bitwise_repeatable_across_graph_replays():
     assert (y1.float() - a.float()).abs().max().item() < 2e-4
 
 
-def test_bench_configuration_is_bitwise_repeatable_across_calls():
-    """Batch 256 as 3 concurrent stream shards (the bench configuration): every call / replay gives the same bits, eager and from
-    the hipGraph -- including the side-stream shards.  r02 (profiles/r02_repeatability_hunt.log): single waves of the fused MLP
-    kernel returned a wrong LayerNorm row mean (a ds_bpermute lane exchange issued while LDS-DMA was landing) when kernels of other
-    shards shared the CU; whether it showed depended on the plan's streams (4 of 6 plans), so several plans are tried.  The lane
-    reductions are VALU swaps since."""
+@pytest.mark.parametrize("streams,join_from", [(2, 3), (3, None)], ids=["timed-2shards-join3", "3shards-nojoin"])
+def test_bench_configuration_is_bitwise_repeatable_across_calls(streams, join_from):
+    """Batch 256 as concurrent stream shards -- the configuration bench.py times (2 shards joined in front of level 3) and the r03 form (3 shards,
+    no join): every call / replay gives the same bits, eager and from the hipGraph, including the side-stream shards and the cross-stream join +
+    torch.cat + whole-batch level 3.  r02 (profiles/r02_repeatability_hunt.log): single waves of the fused MLP kernel returned a wrong LayerNorm row
+    mean (a ds_bpermute lane exchange issued while LDS-DMA was landing) when kernels of other shards shared the CU; whether it showed depended on
+    the plan's streams (4 of 6 plans), so several plans are tried.  The lane reductions are VALU swaps since."""
     model = _model("faster_vit_0_224").to(memory_format=torch.channels_last)
     x = torch.randn(256, 3, 224, 224, generator=torch.Generator().manual_seed(1000)).cuda().contiguous(memory_format=torch.channels_last)
     first = None
     for graph in (False, True, False, True):
-        runner = model.compile_inference(x, dtype=torch.float16, streams=3, graph=graph)
+        runner = model.compile_inference(x, dtype=torch.float16, streams=streams, graph=graph, join_from=join_from)
+        assert runner.plan.join_from == join_from
         outs = [runner(x).clone() for _ in range(6)]
         torch.cuda.synchronize()
         first = outs[0] if first is None else first

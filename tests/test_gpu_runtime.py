@@ -22,30 +22,38 @@ def _native_loaded():
         return "libfvit_hip.so" in f.read()
 
 
-def test_bench_configuration_every_shard_vs_oracle():
-    """The configuration bench.py times -- deploy plan, fp16, 3 stream shards, batch 256, inside ONE hipGraph -- checked against the
-    fp32 CPU oracle on 8 images FROM EACH SHARD (shards are images [0,86), [86,172), [172,256)): logits max-abs < 1e-3."""
+@pytest.mark.parametrize("streams,join_from,sizes", [(2, 3, [128, 128]), (3, None, [86, 86, 84])], ids=["timed-2shards-join3", "3shards-nojoin"])
+def test_bench_configuration_every_shard_vs_oracle(streams, join_from, sizes):
+    """The configuration bench.py TIMES -- deploy plan, fp16, batch 256 as 2 stream shards through levels 0-2, joined (torch.cat on the
+    caller's stream behind the cross-stream join) in front of level 3, inside ONE hipGraph -- checked against the fp32 CPU oracle on 8
+    images FROM EACH SHARD: logits max-abs < 1e-3; the replay is bit-repeatable and equals the eager forward of the same plan bit for bit
+    (the join is where a race between the side stream's last kernel and the cat would show).  The r03 form (3 shards, no join) beside it."""
     model, sd = build_product_model("fvit0_224", "cuda")
     model = model.to(memory_format=torch.channels_last)
     g = torch.Generator(device="cpu").manual_seed(1000)
     x_cpu = torch.randn(256, 3, 224, 224, generator=g)
     x = x_cpu.cuda().contiguous(memory_format=torch.channels_last)
-    runner = model.compile_inference(x, dtype=torch.float16, streams=3)
+    runner = model.compile_inference(x, dtype=torch.float16, streams=streams, join_from=join_from)
     assert isinstance(runner, CompiledInference) and runner.graph is not None
+    assert runner.plan.streams == streams and runner.plan.join_from == join_from
     y = runner(x).float().cpu().clone()
-    y_again = runner(x).float().cpu()
-    assert torch.equal(y, y_again)                      # replay is bit-repeatable
+    for _ in range(4):
+        assert torch.equal(y, runner(x).float().cpu())   # replays are bit-repeatable
+    with torch.no_grad():
+        y_eager = runner.plan.forward(x).float().cpu()    # the same plan eagerly (fork / join with events, no graph)
+    assert torch.equal(y, y_eager)
     assert _native_loaded()
-    sizes = [p.shape[0] for p in x_cpu.chunk(3)]
-    assert sizes == [86, 86, 84]
-    worst = 0.0
-    for shard, start in enumerate((0, 86, 172)):
+    assert [p.shape[0] for p in x_cpu.chunk(streams)] == sizes
+    starts = [sum(sizes[:i]) for i in range(len(sizes))]
+    for shard, start in enumerate(starts):
         idx = list(range(start + 3, start + 11))        # 8 images inside the shard (not only its first rows)
         ref = model_forward(sd, x_cpu[idx], CASES["fvit0_224"]["arch"])
         err = max_abs(y[idx], ref)
-        worst = max(worst, err)
-        print(f"bench configuration, shard {shard} images {idx[0]}..{idx[-1]}: logits max-abs err {err:.3e} (|logits| max {ref.abs().max():.3f})")
+        print(f"bench configuration streams={streams} join_from={join_from}, shard {shard} images {idx[0]}..{idx[-1]}: logits max-abs err {err:.3e} (|logits| max {ref.abs().max():.3f})")
         assert err < 1e-3, f"shard {shard}"
+    # the joined plan and a single-stream plan run the same kernels on the same rows up to the launch shape: same logits to rounding order
+    y1 = model.compile_inference(x, dtype=torch.float16, streams=1, graph=False)(x).float().cpu()
+    assert max_abs(y1, y) < 2e-4
     # a shorter batch through the same graph: zero-padded, sliced
     y40 = runner(x[:40]).float().cpu()
     assert y40.shape == (40, 1000) and max_abs(y40, y[:40]) < 2e-4
