@@ -170,13 +170,17 @@ static bool make_layout(const FvitStageDesc& d, StageLayout& L) {
     }
     // deterministic split-K of the small-grid residual GEMMs (fvit_gemm.hip): fp32 partials [splits <= 8][rows][C] for the row counts whose 128 x 128
     // tile grid is small (the carrier-token branch; a narrow window branch such as stage 3 of FasterViT-4 at batch 43)
+    // Reserved only when the opt-in knob is set AT LAYOUT TIME (fvit_tune "gemm_splitk" = 1 before the workspace is sized; ADVICE r04: the slab was
+    // up to ~30 MB per stage, slot and geometry for a default-off feature).  Sized for the worst case launch_t can pick: 64-row tiles double the
+    // tile count, so the split count computed here from 128-row tiles is an upper bound; launch_t re-checks splitk_bytes and falls back to no split.
     L.off_SPLITK = 0;
     L.splitk_bytes = 0;
-    {
+    if (tune_get("gemm_splitk", 0)) {
+        const int slots = tune_get("gemm_splitk_slots", 460);
         auto need = [&](int64_t rows) -> size_t {
             if (rows <= 0) return 0;
             const int64_t tiles = ((rows + 127) / 128) * ((d.C + 127) / 128);
-            const int64_t sp = std::min<int64_t>(8, 460 / std::max<int64_t>(tiles, 1));
+            const int64_t sp = std::min<int64_t>(8, slots / std::max<int64_t>(tiles, 1));
             return sp >= 2 ? (size_t)sp * rows * d.C * 4 : 0;
         };
         const size_t nb = std::max(need(L.Mx), d.hier ? need(L.Mc) : (size_t)0);

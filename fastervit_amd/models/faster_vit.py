@@ -403,9 +403,11 @@ class FasterViTLayer(nn.Module):
             elif want_grad and self.__dict__.get("hat_backward", False):
                 from .. import hat_backward   # the stage as one autograd node: HIP forward, kernel-sequence backward (FasterViT.enable_hat_backward)
                 x = hat_backward.stage_forward_with_grad(self, x)   # raises HERE (forward time) if the geometry has no backward
-            elif want_grad and x.requires_grad and not x.is_leaf and len(self.blocks):
-                # eval-mode forward without torch.no_grad(): the stage input carries a graph (the conv side's parameters require grad).  Where the
-                # kernel-sequence backward covers the stage the gradient flows (PyTorch's own behaviour); elsewhere hat_runtime warns and detaches.
+            elif want_grad and len(self.blocks) and ((x.requires_grad and not x.is_leaf) or any(p.requires_grad for p in self.blocks.parameters())):
+                # eval-mode forward without torch.no_grad(): the stage input carries a graph (the conv side's parameters require grad) or the stage's
+                # OWN parameters do (frozen conv side, trainable HAT blocks: ADVICE r04).  Where the kernel-sequence backward covers the stage the
+                # gradient flows (PyTorch's own behaviour); elsewhere hat_runtime warns and detaches (FasterViT._check_grad_request raises first when
+                # the caller's own input requires grad).
                 from .. import hat_backward
                 if hat_backward.backward_unsupported_reason(self, x.shape[2], x.shape[3]) is None:
                     x = hat_backward.stage_forward_with_grad(self, x)
@@ -501,9 +503,15 @@ class FasterViT(nn.Module):
         if x.is_cuda and not self.training and torch.is_grad_enabled() and x.requires_grad:
             from .. import hat_backward
             from ..hat_runtime import check_user_input
-            for lvl in self.levels:   # d/dx through every HAT stage, or an error -- never a silently cut gradient
-                if lvl.transformer_block and len(lvl.blocks) and hat_backward.backward_unsupported_reason(lvl) is not None:
+            # map size in front of level i: two stride-2 stem convs, one stride-2 Downsample conv per level (all 3x3, pad 1)
+            H, W = x.shape[-2], x.shape[-1]
+            for _ in range(2):
+                H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            for lvl in self.levels:   # d/dx through every HAT stage AT THIS INPUT SIZE, or an error -- never a silently cut gradient
+                if lvl.transformer_block and len(lvl.blocks) and hat_backward.backward_unsupported_reason(lvl, H, W) is not None:
                     check_user_input(x)
+                if lvl.downsample is not None:
+                    H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
 
     def forward_features(self, x):
         self._check_grad_request(x)
