@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC_DIR, "libfvit_hip.so")
+DIAG = os.environ.get("FVIT_DIAG", "0") == "1"   # diagnosis build (scripts/timeline_*.py, scripts/poison_check.py, the poison test's subprocess)
+LIB_PATH = os.path.join(CSRC_DIR, "libfvit_hip_diag.so" if DIAG else "libfvit_hip.so")
 
 FVIT_ABI_VERSION = 7
 FVIT_F32, FVIT_F16, FVIT_BF16 = 0, 1, 2
@@ -22,13 +23,27 @@ FVIT_PROF_KINDS = 11
 
 # every symbol include/fvit_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = (
-    "fvit_abi_version", "fvit_last_error", "fvit_attention_spad", "fvit_attention_dense", "fvit_stage_workspace_bytes",
-    "fvit_workspace_init", "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_token_init", "fvit_window_partition",
-    "fvit_window_reverse", "fvit_gemm_bias_act", "fvit_gemm_residual", "fvit_gemm_terms", "fvit_gemm_residual_splitk", "fvit_gemm_terms_lo", "fvit_window_attention_terms", "fvit_gather_layernorm_terms", "fvit_win_mlp_fused_terms", "fvit_win_mlp_split_bytes", "fvit_win_mlp_fused_split", "fvit_win_block_fused_split", "fvit_win_block_fused_terms", "fvit_attn_block_fused_terms", "fvit_ct_block_fused_terms", "fvit_window_attention", "fvit_window_attention_long",
-    "fvit_gather_layernorm", "fvit_ln_gemm_supported", "fvit_ln_gemm", "fvit_attn_block_supported", "fvit_attn_block_fused", "fvit_ct_block_supported", "fvit_ct_block_fused", "fvit_win_block_supported", "fvit_win_block_fused", "fvit_win_mlp_supported", "fvit_win_mlp_fused", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl", "fvit_conv3x3_nhwc", "fvit_conv3x3_nhwc_terms", "fvit_conv3x3_c128_band_supported", "fvit_conv3x3_c128_band", "fvit_stem_conv3x3s2", "fvit_stem_fused",
-    "fvit_conv3x3_nhwc_px", "fvit_layernorm2d_px", "fvit_stem_conv3x3s2_px",
-    "fvit_head_logits", "fvit_head_softmax_xent", "fvit_head_grad", "fvit_sgd_momentum",
-    "fvit_debug_lds_poison", "fvit_debug_regs_poison", "fvit_debug_poison_launches", "fvit_debug_rowhash_begin", "fvit_debug_rowhash_end", "fvit_debug_rowhash_dump", "fvit_debug_mlp_trace_begin", "fvit_debug_mlp_trace_end", "fvit_debug_mlp_inputs_begin", "fvit_debug_mlp_inputs_end", "fvit_debug_win_mlp_timeline", "fvit_debug_stem_timeline", "fvit_debug_conv_band_timeline", "fvit_debug_attn_block_timeline", "fvit_debug_ct_block_timeline", "fvit_bwd_blocks", "fvit_bwd_transpose16", "fvit_bwd_scale_cols", "fvit_bwd_gelu", "fvit_bwd_layernorm", "fvit_bwd_colsum_finish", "fvit_bwd_colsum16", "fvit_bwd_window_attention", "fvit_tune", "fvit_prof_enable", "fvit_prof_collect", "fvit_prof_records", "fvit_prof_kind_name",
+    "fvit_abi_version", "fvit_last_error", "fvit_attention_spad", "fvit_attention_dense", "fvit_stage_workspace_bytes", "fvit_workspace_init",
+    "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_token_init", "fvit_window_partition", "fvit_window_reverse", "fvit_gemm_bias_act",
+    "fvit_gemm_residual", "fvit_gemm_terms", "fvit_gemm_residual_splitk", "fvit_gemm_terms_lo", "fvit_window_attention_terms",
+    "fvit_gather_layernorm_terms", "fvit_win_mlp_fused_terms", "fvit_win_mlp_split_bytes", "fvit_win_mlp_fused_split", "fvit_win_block_fused_split",
+    "fvit_win_block_fused_terms", "fvit_attn_block_fused_terms", "fvit_ct_block_fused_terms", "fvit_window_attention", "fvit_window_attention_long",
+    "fvit_gather_layernorm", "fvit_ln_gemm_supported", "fvit_ln_gemm", "fvit_attn_block_supported", "fvit_attn_block_fused",
+    "fvit_ct_block_supported", "fvit_ct_block_fused", "fvit_win_block_supported", "fvit_win_block_fused", "fvit_win_mlp_supported",
+    "fvit_win_mlp_fused", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl",
+    "fvit_conv3x3_nhwc", "fvit_conv3x3_nhwc_terms", "fvit_conv3x3_c128_band_supported", "fvit_conv3x3_c128_band", "fvit_stem_conv3x3s2",
+    "fvit_stem_fused", "fvit_conv3x3_nhwc_px", "fvit_layernorm2d_px", "fvit_stem_conv3x3s2_px", "fvit_head_logits", "fvit_head_softmax_xent",
+    "fvit_head_grad", "fvit_sgd_momentum", "fvit_bwd_blocks", "fvit_bwd_transpose16", "fvit_bwd_scale_cols", "fvit_bwd_gelu", "fvit_bwd_layernorm",
+    "fvit_bwd_colsum_finish", "fvit_bwd_colsum16", "fvit_bwd_window_attention", "fvit_tune", "fvit_prof_enable", "fvit_prof_collect",
+    "fvit_prof_records", "fvit_prof_kind_name",
+)
+# only in libfvit_hip_diag.so (the same sources with -DFVIT_DIAG; FVIT_DIAG=1 selects it): diagnosis entry points of include/fvit_hip.h's #ifdef FVIT_DIAG
+# section.  The shipped library exports none of them and compiles the ablation knobs out (tests/test_abi.py).
+DIAG_SYMBOLS = (
+    "fvit_debug_lds_poison", "fvit_debug_regs_poison", "fvit_debug_poison_launches", "fvit_debug_rowhash_begin", "fvit_debug_rowhash_end",
+    "fvit_debug_rowhash_dump", "fvit_debug_mlp_trace_begin", "fvit_debug_mlp_trace_end", "fvit_debug_mlp_inputs_begin", "fvit_debug_mlp_inputs_end",
+    "fvit_debug_win_mlp_timeline", "fvit_debug_stem_timeline", "fvit_debug_conv_band_timeline", "fvit_debug_attn_block_timeline",
+    "fvit_debug_ct_block_timeline",
 )
 
 
@@ -129,10 +144,6 @@ def _declare(lib):
     lib.fvit_gather_layernorm_terms.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, f32, i32, i32, i32, vp]
     lib.fvit_win_mlp_fused_terms.restype = C.c_int
     lib.fvit_win_mlp_fused_terms.argtypes = [i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, i32, vp]
-    lib.fvit_debug_stem_timeline.restype = C.c_int
-    lib.fvit_debug_stem_timeline.argtypes = [C.POINTER(FvitMapView), vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
-    lib.fvit_debug_win_mlp_timeline.restype = C.c_int
-    lib.fvit_debug_win_mlp_timeline.argtypes = [vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
     lib.fvit_win_mlp_split_bytes.restype = C.c_size_t
     lib.fvit_win_mlp_split_bytes.argtypes = [i32, i32, i32]
     lib.fvit_win_mlp_fused_split.restype = C.c_int
@@ -206,36 +217,10 @@ def _declare(lib):
     lib.fvit_win_block_fused_terms.argtypes = list(lib.fvit_attn_block_fused.argtypes)[:-1] + [i32, vp]
     lib.fvit_attn_block_fused_terms.restype = C.c_int
     lib.fvit_attn_block_fused_terms.argtypes = list(lib.fvit_attn_block_fused.argtypes)[:-1] + [i32, vp]
-    lib.fvit_debug_lds_poison.restype = C.c_int
-    lib.fvit_debug_lds_poison.argtypes = [vp, i32, i32, vp]
-    lib.fvit_debug_poison_launches.restype = C.c_int
-    lib.fvit_debug_poison_launches.argtypes = [vp, C.c_uint32]
-    lib.fvit_debug_regs_poison.restype = C.c_int
-    lib.fvit_debug_regs_poison.argtypes = [vp, i32, i32, C.c_uint32, vp]
-    lib.fvit_debug_rowhash_begin.restype = C.c_int
-    lib.fvit_debug_rowhash_begin.argtypes = [vp, C.c_int64]
-    lib.fvit_debug_rowhash_end.restype = C.c_int
-    lib.fvit_debug_rowhash_end.argtypes = [C.POINTER(FvitDebugRowhashRecord), i32]
-    lib.fvit_debug_rowhash_dump.restype = C.c_int
-    lib.fvit_debug_rowhash_dump.argtypes = [i32, vp, C.c_int64]
-    lib.fvit_debug_mlp_trace_begin.restype = C.c_int
-    lib.fvit_debug_mlp_trace_begin.argtypes = [vp, C.c_int64]
-    lib.fvit_debug_mlp_trace_end.restype = C.c_int
-    lib.fvit_debug_mlp_trace_end.argtypes = [C.POINTER(C.c_int64), C.POINTER(i32), i32]
-    lib.fvit_debug_mlp_inputs_begin.restype = C.c_int
-    lib.fvit_debug_mlp_inputs_begin.argtypes = [vp, C.c_int64]
-    lib.fvit_debug_mlp_inputs_end.restype = C.c_int
-    lib.fvit_debug_mlp_inputs_end.argtypes = [C.POINTER(C.c_int64), C.POINTER(i32), i32]
     lib.fvit_conv3x3_c128_band_supported.restype = C.c_int
     lib.fvit_conv3x3_c128_band_supported.argtypes = [i32, i32]
     lib.fvit_conv3x3_c128_band.restype = C.c_int
     lib.fvit_conv3x3_c128_band.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
-    lib.fvit_debug_conv_band_timeline.restype = C.c_int
-    lib.fvit_debug_conv_band_timeline.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
-    lib.fvit_debug_attn_block_timeline.restype = C.c_int
-    lib.fvit_debug_attn_block_timeline.argtypes = list(lib.fvit_attn_block_fused.argtypes)[1:-1] + [vp, vp]
-    lib.fvit_debug_ct_block_timeline.restype = C.c_int
-    lib.fvit_debug_ct_block_timeline.argtypes = list(lib.fvit_ct_block_fused.argtypes)[1:-1] + [vp, vp]
     lib.fvit_bwd_blocks.restype = C.c_int32
     lib.fvit_bwd_blocks.argtypes = [i32]
     lib.fvit_bwd_transpose16.restype = C.c_int
@@ -264,6 +249,40 @@ def _declare(lib):
     lib.fvit_prof_kind_name.argtypes = [C.c_int]
 
 
+def _declare_diag(lib):
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    lib.fvit_debug_stem_timeline.restype = C.c_int
+    lib.fvit_debug_stem_timeline.argtypes = [C.POINTER(FvitMapView), vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.fvit_debug_win_mlp_timeline.restype = C.c_int
+    lib.fvit_debug_win_mlp_timeline.argtypes = [vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
+    lib.fvit_debug_lds_poison.restype = C.c_int
+    lib.fvit_debug_lds_poison.argtypes = [vp, i32, i32, vp]
+    lib.fvit_debug_poison_launches.restype = C.c_int
+    lib.fvit_debug_poison_launches.argtypes = [vp, C.c_uint32]
+    lib.fvit_debug_regs_poison.restype = C.c_int
+    lib.fvit_debug_regs_poison.argtypes = [vp, i32, i32, C.c_uint32, vp]
+    lib.fvit_debug_rowhash_begin.restype = C.c_int
+    lib.fvit_debug_rowhash_begin.argtypes = [vp, C.c_int64]
+    lib.fvit_debug_rowhash_end.restype = C.c_int
+    lib.fvit_debug_rowhash_end.argtypes = [C.POINTER(FvitDebugRowhashRecord), i32]
+    lib.fvit_debug_rowhash_dump.restype = C.c_int
+    lib.fvit_debug_rowhash_dump.argtypes = [i32, vp, C.c_int64]
+    lib.fvit_debug_mlp_trace_begin.restype = C.c_int
+    lib.fvit_debug_mlp_trace_begin.argtypes = [vp, C.c_int64]
+    lib.fvit_debug_mlp_trace_end.restype = C.c_int
+    lib.fvit_debug_mlp_trace_end.argtypes = [C.POINTER(C.c_int64), C.POINTER(i32), i32]
+    lib.fvit_debug_mlp_inputs_begin.restype = C.c_int
+    lib.fvit_debug_mlp_inputs_begin.argtypes = [vp, C.c_int64]
+    lib.fvit_debug_mlp_inputs_end.restype = C.c_int
+    lib.fvit_debug_mlp_inputs_end.argtypes = [C.POINTER(C.c_int64), C.POINTER(i32), i32]
+    lib.fvit_debug_conv_band_timeline.restype = C.c_int
+    lib.fvit_debug_conv_band_timeline.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.fvit_debug_attn_block_timeline.restype = C.c_int
+    lib.fvit_debug_attn_block_timeline.argtypes = list(lib.fvit_attn_block_fused.argtypes)[1:-1] + [vp, vp]
+    lib.fvit_debug_ct_block_timeline.restype = C.c_int
+    lib.fvit_debug_ct_block_timeline.argtypes = list(lib.fvit_ct_block_fused.argtypes)[1:-1] + [vp, vp]
+
+
 def lib():
     """Load (once) and return the ctypes handle; raises RuntimeError when the library is absent."""
     global _lib
@@ -277,10 +296,12 @@ def lib():
         handle = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 missing
         raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
-    missing = [s for s in EXPORTED_SYMBOLS if not hasattr(handle, s)]
+    missing = [s for s in EXPORTED_SYMBOLS + (DIAG_SYMBOLS if DIAG else ()) if not hasattr(handle, s)]
     if missing:
         raise RuntimeError(f"{LIB_PATH} lacks symbols {missing}; rebuild it")
     _declare(handle)
+    if DIAG:
+        _declare_diag(handle)
     if handle.fvit_abi_version() != FVIT_ABI_VERSION:
         raise RuntimeError(f"ABI mismatch: library {handle.fvit_abi_version()} vs binding {FVIT_ABI_VERSION}")
     _lib = handle

@@ -696,6 +696,7 @@ int fvit_attn_block_fused(int32_t operand_dtype, const float* srcA, int32_t rows
     return launch_attnblk(ab, (hipStream_t)stream);
 }
 
+#ifdef FVIT_DIAG
 int fvit_debug_attn_block_timeline(const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
                                    const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
                                    int32_t rows_per_image, const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag,
@@ -707,6 +708,7 @@ int fvit_debug_attn_block_timeline(const float* srcA, int32_t rowsA, const float
     ab.ts = stamps;
     return launch_attnblk(ab, (hipStream_t)stream);
 }
+#endif  // FVIT_DIAG
 
 int fvit_win_mlp_supported(int32_t C, int32_t hidden) { return winmlp_supported(C, hidden) ? 1 : 0; }
 
@@ -750,6 +752,7 @@ int fvit_win_block_fused(int32_t operand_dtype, const float* srcA, int32_t rowsA
     return launch_winblk(ab, (hipStream_t)stream);
 }
 
+#ifdef FVIT_DIAG
 int fvit_debug_win_mlp_timeline(float* x, int32_t M, int32_t C, int32_t hidden, const float* ln_w, const float* ln_b, float eps,
                                 const void* w_fc1_frag, const float* b_fc1, const void* w_fc2_frag, const float* b_fc2, const float* gamma,
                                 void* stamps, fvit_stream_t stream) {
@@ -758,6 +761,7 @@ int fvit_debug_win_mlp_timeline(float* x, int32_t M, int32_t C, int32_t hidden, 
     mc.ts = stamps;
     return launch_winmlp(mc, (hipStream_t)stream);
 }
+#endif  // FVIT_DIAG
 
 int fvit_win_block_fused_split(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB, const int32_t* src_idx,
                                const int32_t* add_idx, const float* add, const float* ln_w, const float* ln_b, float eps,
@@ -818,6 +822,7 @@ int fvit_ct_block_fused_terms(int32_t operand_dtype, const float* X, int32_t row
     return launch_ctblk(cb, (hipStream_t)stream);
 }
 
+#ifdef FVIT_DIAG
 int fvit_debug_ct_block_timeline(const float* X, int32_t rowsA, const int32_t* src_idx, const float* add, float* R,
                                  int32_t batch, int32_t G, int32_t heads, int32_t C, int32_t hidden, const float* ln1_w, const float* ln1_b,
                                  const void* w_qkv_frag, const float* b_qkv_heads, const void* w_proj_frag, const float* b_proj, const float* gamma1,
@@ -829,6 +834,7 @@ int fvit_debug_ct_block_timeline(const float* X, int32_t rowsA, const int32_t* s
     cb.ts = stamps;
     return launch_ctblk(cb, (hipStream_t)stream);
 }
+#endif  // FVIT_DIAG
 
 int fvit_mlp_fused_supported(int32_t C, int32_t hidden) { return mlp_fused_supported(C, hidden) ? 1 : 0; }
 

@@ -453,7 +453,7 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
     p.eps = c.eps; p.rowsA = c.rowsA; p.rowsB = c.rowsB; p.rows_per_image = c.rows_per_image > 0 ? c.rows_per_image : 1;
     p.wqkv_f = c.wqkv_f; p.bqkv = c.bqkv; p.wproj_f = c.wproj_f; p.bproj = c.bproj; p.gamma = c.gamma; p.bias = c.bias;
     p.x_out = c.x_out; p.nwin = c.nwin; p.S = c.S; p.heads = c.heads; p.scale = c.scale;
-    p.ablate = tune_get("ab_ablate", 0);
+    p.ablate = diag_knob("ab_ablate");
     p.stagger = tune_get("ab_stagger", 0);
     p.ts = (unsigned long long*)c.ts;
     const double rows = (double)c.nwin * c.S;

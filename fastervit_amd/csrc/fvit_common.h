@@ -159,7 +159,15 @@ int tune_get(const char* key, int dflt);
 // timing ablation (results are WRONG when non-zero; bench A/B only): skip the launches of a kernel family to measure its marginal cost
 // inside the concurrent stream shards.  bits: 1 winmlp<256>, 2 winmlp<512>, 4 winblk, 8 attnblk, 16 ctblk, 32 conv3x3 implicit GEMM,
 // 64 halo conv, 128 fused stem
+// Measurement hazards live only in the DIAGNOSIS build (libfvit_hip_diag.so, -DFVIT_DIAG): the shipped library has no knob that
+// can make a kernel skip work and no fvit_debug_* entry point.
+#ifdef FVIT_DIAG
 inline bool ablate_skip(int bit) { return (tune_get("ablate_skip", 0) & bit) != 0; }
+inline int diag_knob(const char* key) { return tune_get(key, 0); }   // per-kernel ablation masks ("conv_ablate", "mlp_ablate", ...): results are WRONG when non-zero
+#else
+inline bool ablate_skip(int) { return false; }
+inline int diag_knob(const char*) { return 0; }
+#endif
 
 // ---- diagnostics state (kernel timer records, row-hash / MLP traces, poison sink) is process-global: every access -- including
 // the ones inside ProfScope, i.e. on every launch -- takes this mutex, so that host threads driving different devices / streams
@@ -176,8 +184,13 @@ struct ProfScope {
 // names the launch the innermost live ProfScope brackets: kernel family + launch shape (workgroups), so that the per-launch records
 // (fvit_prof_records) can be matched with a rocprofv3 kernel trace / PMC row of the same (kernel, grid).  No-op when the timer is off.
 void prof_note(const char* kernel, int grid);
+#ifdef FVIT_DIAG
 void dbg_poison_before_launch(hipStream_t st);   // diagnosis: register / LDS poison kernel in front of every launch (fvit_debug_poison_launches)
 void dbg_rowhash(const char* tag, const void* ptr, long long rows, int row_bytes, hipStream_t st);   // no-op unless fvit_debug_rowhash_begin is active
+#else
+inline void dbg_poison_before_launch(hipStream_t) {}
+inline void dbg_rowhash(const char*, const void*, long long, int, hipStream_t) {}
+#endif
 
 // ---- launchers (defined in the .hip files) ----
 struct GemmCall {

@@ -617,7 +617,7 @@ int launch_halo_t(const ConvParams& c, hipStream_t stream) {
     p.tiles_x = (c.Wi + HALO_TW - 1) / HALO_TW;
     p.tiles_y = (c.Hi + HALO_TH - 1) / HALO_TH;
     p.tiles = c.B * p.tiles_x * p.tiles_y;   // <= M, which the caller checked against int32
-    p.ablate = tune_get("conv_halo_ablate", 0);
+    p.ablate = diag_knob("conv_halo_ablate");
     int maxgrid = tune_get("conv_halo_grid", 512);   // 2 workgroups per CU (230 VGPRs, 46 KiB LDS each)
     if (maxgrid < 8) maxgrid = 8;                    // every XCD's tile range needs at least one workgroup
     const int grid = p.tiles < maxgrid ? p.tiles : maxgrid;
@@ -1204,7 +1204,7 @@ extern "C" int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void
     ConvParams p;
     p.in = in; p.w = weight; p.bias = bias; p.res = residual; p.out = out; p.zeros = zeros;
     p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.act = act;
-    p.ablate = tune_get("conv_ablate", 0);
+    p.ablate = diag_knob("conv_ablate");
     p.wterms = weight_terms;
     p.in_lo = p.res_lo = nullptr; p.out_lo = nullptr; p.out_f32 = nullptr; p.px = 0;
     p.Ho = (Hi + 2 - 3) / stride + 1;
@@ -1301,11 +1301,13 @@ extern "C" int fvit_stem_fused(int32_t dtype, const FvitMapView* in, const void*
 
 // diagnosis: the fp16 kernel with per-wave phase accumulators (u64 [workgroups <= 512][4 waves][8]: ticks in phase A, barrier after A, phase B,
 // epilogue, barrier before A, tiles processed, total)
+#ifdef FVIT_DIAG
 extern "C" int fvit_debug_stem_timeline(const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2, void* out,
                                         int32_t B, int32_t Hi, int32_t Wi, void* stamps, fvit_stream_t stream) {
     if (!stamps) { set_error("debug_stem_timeline: null stamp buffer"); return FVIT_EINVAL; }
     return stem_fused_impl(FVIT_F16, in, w1, b1, w2, b2, out, B, Hi, Wi, stream, stamps);
 }
+#endif  // FVIT_DIAG
 
 static int stem_fused_impl(int32_t dtype, const FvitMapView* in, const void* w1, const float* b1, const void* w2, const float* b2,
                            void* out, int32_t B, int32_t Hi, int32_t Wi, fvit_stream_t stream, void* stamps) {
@@ -1381,6 +1383,7 @@ extern "C" int fvit_conv3x3_c128_band(int32_t dtype, const void* in, const void*
 }
 
 // diagnosis: the fp16 kernel with s_memtime stamps, u64 [B * bands][4 waves][8] (see BandParams.ts); bands = ceil(H / (224 / (W + 2)))
+#ifdef FVIT_DIAG
 extern "C" int fvit_debug_conv_band_timeline(const void* in, const void* w_frag, const float* bias, const void* residual, void* out, int32_t B,
                                              int32_t H, int32_t W, int32_t act, const void* zeros, void* stamps, fvit_stream_t stream) {
     if (!in || !w_frag || !out || !zeros || !stamps || B <= 0 || !band_supported(H, W) || act < 0 || act > 2) {
@@ -1389,3 +1392,4 @@ extern "C" int fvit_debug_conv_band_timeline(const void* in, const void* w_frag,
     }
     return launch_band_t<_Float16>(in, w_frag, bias, residual, out, zeros, B, H, W, act, (hipStream_t)stream, stamps);
 }
+#endif  // FVIT_DIAG

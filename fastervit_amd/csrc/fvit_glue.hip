@@ -233,6 +233,7 @@ int fvit_layernorm2d_px(int32_t dtype, const void* in, const void* in_lo, const 
     return FVIT_EINVAL;
 }
 
+#ifdef FVIT_DIAG
 /* Test / diagnosis aid: fills the LDS and the registers of every CU it lands on with a NaN pattern and exits.  Launched on a side
  * stream beside a forward, it turns any read of uninitialised LDS (whose content is otherwise whatever the previous workgroup left --
  * repeatable on one stream, timing-dependent with concurrent streams) into NaNs / large errors. */
@@ -299,8 +300,11 @@ __global__ __launch_bounds__(256) void rowhash_kernel(const unsigned* __restrict
     for (int o = 32; o; o >>= 1) h ^= __shfl_xor(h, o);
     if (lane == 0) out[row] = h;
 }
+#endif  // FVIT_DIAG
 
 }  // extern "C"
+
+#ifdef FVIT_DIAG
 
 namespace fvit {
 struct DbgTrace { unsigned* buf = nullptr; long long cap = 0, used = 0; int nrec = 0; int ndump = 0; int dump_rec[64]; void* dump_dst[64]; long long dump_cap[64]; FvitDebugRowhashRecord rec[FVIT_DEBUG_MAX_RECORDS]; };
@@ -357,3 +361,4 @@ int fvit_debug_rowhash_end(FvitDebugRowhashRecord* out, int32_t max_records) {
     return n;
 }
 }  // extern "C"
+#endif  // FVIT_DIAG

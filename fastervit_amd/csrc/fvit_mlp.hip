@@ -418,7 +418,7 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
     // (r02 first blamed it for run-to-run differences under concurrent stream shards; the cause was the ds_bpermute lane exchange of the
     // LayerNorm prologue, see fvit_common.h / profiles/r02_repeatability_hunt.log -- the stagger only moved the timing.)
     p.stagger = tune_get("mlp_stagger", 0);
-    p.ablate = tune_get("mlp_ablate", 0);
+    p.ablate = diag_knob("mlp_ablate");
     p.dbg = nullptr;
     p.dbgx = nullptr;
     std::lock_guard<std::recursive_mutex> dlock(diag_mutex());   // trace bookkeeping + the timer record of this launch
@@ -503,6 +503,7 @@ int launch_mlp_fused(const MlpFusedCall& c, hipStream_t stream) {
 
 }  // namespace fvit
 
+#ifdef FVIT_DIAG
 extern "C" {
 /* diagnosis: while active, every default-variant C = 256 fused-MLP launch writes per-lane hashes of its intermediate state (see dq in the
  * kernel) to consecutive slices of buf; _end returns the number of traced launches with their slice offsets (words) and row counts */
@@ -531,3 +532,4 @@ int fvit_debug_mlp_trace_end(int64_t* offsets, int32_t* rows, int32_t max_launch
     return n;
 }
 }
+#endif  // FVIT_DIAG

@@ -37,6 +37,8 @@ _DT = {torch.float32: FVIT_F32, torch.float16: FVIT_F16, torch.bfloat16: FVIT_BF
 # q / k / v / P, exact-erf GELU): ~22 significant bits through the HAT stages -- the route to logits max-abs < 1e-3 ABSOLUTE on
 # FasterViT-4 / any-res, whose logits reach |7| (the single rounding of the fp16 activations alone is ~1e-3 there).  Runs the
 # unfused kernel chain (LayerNorm, GEMM, attention) with three times the MFMA work.
+from ._lib import FVIT_MAX_DENSE_SEQ  # noqa: E402
+
 _OP = {"f16": (FVIT_F16, torch.float16, 1), "bf16": (FVIT_BF16, torch.bfloat16, 1),
        "f16x2": (FVIT_F16, torch.float16, 2), "bf16x2": (FVIT_BF16, torch.bfloat16, 2),
        "f16x3": (FVIT_F16, torch.float16, 3), "bf16x3": (FVIT_BF16, torch.bfloat16, 3)}
@@ -370,6 +372,16 @@ def _prepare(layer, x_dev, Hp: int, Wp: int):
                              dev_t["up_idx"].data_ptr())
         st.tables[tkey] = (tb, dev_t, ct)
     tb, _, ctables = st.tables[tkey]
+    if terms == 3:
+        # the x3 modes run the in-register attention kernel with two-term q / k / v / P: dense windows only (fvit_attention_dense).  Say so HERE, in
+        # Python, naming the level's geometry -- not as a kernel argument error from inside the stage call
+        lib0 = _lib.lib()
+        for what, n in (("window", tb["S"]),) + ((("carrier grid", tb["G"]),) if hier else ()):
+            if not lib0.fvit_attention_dense(int(n), int(dpad)):
+                raise NotImplementedError(
+                    f"operand mode {op_name!r}: this stage's {what} has {n} tokens at head_dim {d} (padded {dpad}); the two-term attention kernel covers "
+                    f"sequences up to {FVIT_MAX_DENSE_SEQ} tokens ({128} at the 96-wide head padding). Use 'f16x2' / 'bf16x2' (two-term weights) for this "
+                    "geometry (the 21k 384 / 512 / 768 fine-tunes, FasterViT-5 / -6 with large windows).")
     sig = _signature(layer.blocks, x_dev, op_name, bool(getattr(layer, "_is_replica", False))) + (tb["S"], tb["G"])
     if st.sig != sig:
         keep = _Keep(op_dtype, terms)

@@ -525,10 +525,13 @@ int fvit_sgd_momentum(float* param, float* momentum, const float* grad, int64_t 
  *   "mlp_fused", "attn_fused" 0/1; "mlp_fused_min_rows", "attn_fused_min_rows", "mlp_fused512_min_rows", "attn_fused512_min_rows";
  *   "mlp_variant" (-1 auto), "ab_variant", "ct_fused" 0/1 (carrier branch in one kernel), "win_fused" 0/1 (stage-3 attention sub-block in one kernel), "win_fused256" 0/1 (its 4-wave C = 256 instance for stage 2, off), "win_mlp" 0/1 (stage-3 MLP sub-block in one kernel), "win_mlp256" 0/1/2 (its C = 256 instances for stage 2: 2 = 4-wave 64-row workgroups (default), 1 = 8-wave 128-row, 0 = fvit_mlp_fused's kernel), "ct_variant", "ct_touch", "ln_gemm" 0/1, "ln_gemm_max_rows", "lngemm_nt", "gemm_ring", "mlp_ring4_max_grid", "gemm_stagger", "ab_stagger", "mlp_stagger" (0 / 1 / 2), "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
  *   "conv_halo_grid", "conv64_variant", "conv128_narrow", "stem_fused_grid".
- * The "*_ablate" keys ("mlp_ablate", "ab_ablate", "conv_ablate", "conv_halo_ablate") switch off parts of a kernel for timing and
- * DO produce wrong results.  Guarded by a mutex; launches read the values at launch time. */
+ * Guarded by a mutex; launches read the values at launch time.
+ * DIAGNOSIS BUILD ONLY (libfvit_hip_diag.so, compiled with -DFVIT_DIAG; selected by FVIT_DIAG=1 in the Python binding): the "*_ablate" keys
+ * ("mlp_ablate", "ab_ablate", "conv_ablate", "conv_halo_ablate") and "ablate_skip" switch off parts of a kernel / whole kernels for timing and
+ * DO produce wrong results; in the shipped library they are compiled out (the keys are accepted and ignored). */
 int fvit_tune(const char* key, int32_t value);
 
+#ifdef FVIT_DIAG   /* ---- diagnosis entry points: libfvit_hip_diag.so only (r05); the shipped libfvit_hip.so does not export them ---- */
 /* Diagnosis aid (tests / scripts only): `blocks` workgroups that fill 64 KiB of LDS each with a NaN pattern, spin `spin` iterations and
  * exit; run beside a forward on another stream, it exposes reads of uninitialised LDS.  sink: >= 4 bytes of device memory. */
 int fvit_debug_lds_poison(void* sink, int32_t blocks, int32_t spin, fvit_stream_t stream);
@@ -588,6 +591,7 @@ int fvit_debug_mlp_trace_end(int64_t* offsets, int32_t* rows, int32_t max_launch
 /* same protocol: every C = 256 fused-MLP launch stores its input rows exactly as its own loads returned them ([M][256] floats per launch) */
 int fvit_debug_mlp_inputs_begin(void* buf, int64_t capacity_floats);
 int fvit_debug_mlp_inputs_end(int64_t* offsets, int32_t* rows, int32_t max_launches);
+#endif /* FVIT_DIAG */
 
 /* ---- built-in kernel timer (HIP events around every launch, on the launch stream) ---- */
 #define FVIT_PROF_KINDS 11

@@ -1,4 +1,6 @@
 """Micro-benchmark of the fused attention block kernel (with timing-only ablations) vs the unfused 4-kernel path."""
+import os
+os.environ.setdefault("FVIT_DIAG", "1")   # diagnosis build of the library (fvit_debug_* entry points, ablation knobs)
 import ctypes
 import os
 import sys

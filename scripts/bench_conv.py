@@ -3,6 +3,8 @@
 usage: python scripts/bench_conv.py [B] [H] [W] [variants]      variants: comma list of halo[:grid] | gemm
 """
 import os
+os.environ.setdefault("FVIT_DIAG", "1")   # diagnosis build of the library (fvit_debug_* entry points, ablation knobs)
+import os
 import sys
 
 import torch

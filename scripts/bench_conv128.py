@@ -1,5 +1,7 @@
 """Micro-benchmark: row-band 128 -> 128 conv (fvit_conv3x3_c128_band) vs the implicit-GEMM kernel at level-1 shapes of FasterViT-0."""
 import os
+os.environ.setdefault("FVIT_DIAG", "1")   # diagnosis build of the library (fvit_debug_* entry points, ablation knobs)
+import os
 import sys
 
 import torch

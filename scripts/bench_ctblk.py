@@ -1,5 +1,7 @@
 """Micro-benchmark of the carrier-branch kernel (fvit_ct_block_fused): warm weights (same launch repeated) vs cold (L2 thrashed
 between launches), per variant."""
+import os
+os.environ.setdefault("FVIT_DIAG", "1")   # diagnosis build of the library (fvit_debug_* entry points, ablation knobs)
 import ctypes
 import os
 import sys

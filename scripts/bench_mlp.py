@@ -1,4 +1,6 @@
 """Micro-benchmark of the fused MLP kernel vs the unfused LN + 2 GEMM path (interleaved A/B in one process)."""
+import os
+os.environ.setdefault("FVIT_DIAG", "1")   # diagnosis build of the library (fvit_debug_* entry points, ablation knobs)
 import ctypes
 import os
 import sys

@@ -1,4 +1,6 @@
 """Micro-benchmark: fused two-conv stem vs stem kernel + stride-2 conv kernel (FasterViT-0 shapes)."""
+import os
+os.environ.setdefault("FVIT_DIAG", "1")   # diagnosis build of the library (fvit_debug_* entry points, ablation knobs)
 import ctypes as C
 import os
 import sys

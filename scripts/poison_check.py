@@ -1,6 +1,8 @@
 """Do any kernels read registers or LDS they never wrote?  One stream, a poison kernel in front of every launch (all 512 vector registers
 of every SIMD and all LDS set to a pattern): the logits must not depend on the pattern.  Then per kernel family (knobs) to narrow it."""
 import os
+os.environ.setdefault("FVIT_DIAG", "1")   # diagnosis build of the library (fvit_debug_* entry points, ablation knobs)
+import os
 import sys
 
 import torch

@@ -1,6 +1,8 @@
 """Phase timeline of attnblk_kernel<256> (stage-2 window attention of FasterViT-0) at shard size: fvit_debug_attn_block_timeline.
 s_memtime is per XCD and unsynchronized: only differences inside one wave are used; the tick rate comes from the longest wave against
 the launch's event time."""
+import os
+os.environ.setdefault("FVIT_DIAG", "1")   # diagnosis build of the library (fvit_debug_* entry points, ablation knobs)
 import ctypes
 import os
 import sys

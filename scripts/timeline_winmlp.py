@@ -1,5 +1,7 @@
 """Phase timeline of the N-split MLP kernel (fvit_debug_win_mlp_timeline): where the time of a workgroup goes.
 usage: python scripts/timeline_winmlp.py"""
+import os
+os.environ.setdefault("FVIT_DIAG", "1")   # diagnosis build of the library (fvit_debug_* entry points, ablation knobs)
 import ctypes
 import os
 import sys

@@ -20,14 +20,30 @@ def lib():
 
 
 def test_header_symbols_are_exported(lib):
-    """Every function include/fvit_hip.h declares is exported by libfvit_hip.so (and vice versa for the binding)."""
+    """Every function include/fvit_hip.h declares is exported by libfvit_hip.so (and vice versa for the binding); the fvit_debug_* entry points of
+    its #ifdef FVIT_DIAG section are exported ONLY by the diagnosis build libfvit_hip_diag.so."""
     hdr = open(os.path.join(ROOT, "include", "fvit_hip.h")).read()
-    declared = set(re.findall(r"\b(fvit_[a-z0-9_]+)\s*\(", hdr))
+    a, b = hdr.index("#ifdef FVIT_DIAG"), hdr.index("#endif /* FVIT_DIAG */")
+    diag_decl = set(re.findall(r"\b(fvit_[a-z0-9_]+)\s*\(", hdr[a:b]))
+    declared = set(re.findall(r"\b(fvit_[a-z0-9_]+)\s*\(", hdr[:a] + hdr[b:]))
     declared.discard("fvit_stream_t")
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    raw = ctypes.CDLL(_lib.LIB_PATH)
+    assert diag_decl == set(_lib.DIAG_SYMBOLS) and all(s.startswith("fvit_debug_") for s in diag_decl)
+    shipped = ctypes.CDLL(os.path.join(_lib.CSRC_DIR, "libfvit_hip.so"))
     for s in declared:
-        assert hasattr(raw, s), s
+        assert hasattr(shipped, s), s
+    for s in diag_decl:
+        assert not hasattr(shipped, s), f"{s} is exported by the shipped library"
+    diag = ctypes.CDLL(os.path.join(_lib.CSRC_DIR, "libfvit_hip_diag.so"))
+    for s in declared | diag_decl:
+        assert hasattr(diag, s), s
+
+
+def test_shipped_library_has_no_ablation_knobs():
+    """"ablate_skip" / "*_ablate" make kernels skip work (wrong results): the strings must not even be present in the shipped library."""
+    blob = open(os.path.join(_lib.CSRC_DIR, "libfvit_hip.so"), "rb").read()
+    assert b"ablate_skip" not in blob and b"conv_ablate" not in blob and b"mlp_ablate" not in blob
+    assert b"ablate_skip" in open(os.path.join(_lib.CSRC_DIR, "libfvit_hip_diag.so"), "rb").read()
 
 
 def test_abi_version_and_struct_sizes(lib):

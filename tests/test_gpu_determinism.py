@@ -85,25 +85,44 @@ def test_bench_configuration_is_bitwise_repeatable_across_calls(streams, join_fr
 def test_results_do_not_depend_on_leftover_registers_or_lds():
     """A poison kernel in front of every launch fills all 512 vector registers of every SIMD and all LDS with a pattern
     (fvit_debug_poison_launches): a kernel that reads a register or an LDS byte it never wrote would change its result with the
-    pattern (on one stream such a read is repeatable and passes every other test)."""
-    from fastervit_amd.conv_runtime import DeployPlan
-    lib = _lib.lib()
-    sink = torch.zeros(16, dtype=torch.int32, device="cuda")
-    for entry, bs in (("faster_vit_0_224", 86), ("faster_vit_1_224", 4)):
-        model = _model(entry).to(memory_format=torch.channels_last)
-        x = torch.randn(bs, 3, 224, 224, generator=torch.Generator().manual_seed(3)).cuda().contiguous(memory_format=torch.channels_last)
-        plan = DeployPlan(model, torch.float16)
-        plan.streams = 1
-        with torch.no_grad():
-            base = plan.forward(x).clone()
-            try:
-                for pattern in (0x7fc07fc0, 0x40004000, 0):
-                    lib.fvit_debug_poison_launches(sink.data_ptr(), pattern)
-                    y = plan.forward(x).clone()
-                    torch.cuda.synchronize()
-                    assert torch.isfinite(y).all() and torch.equal(y, base), f"{entry}: result depends on the register / LDS poison {pattern:#x}"
-            finally:
-                lib.fvit_debug_poison_launches(None, 0)
+    pattern (on one stream such a read is repeatable and passes every other test).  The hook exists only in the DIAGNOSIS build of the
+    library (libfvit_hip_diag.so: the same sources with -DFVIT_DIAG), so the check runs in a subprocess with FVIT_DIAG=1."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import torch
+import fastervit_amd
+from fastervit_amd import _lib
+from fastervit_amd.conv_runtime import DeployPlan
+assert _lib.DIAG and _lib.LIB_PATH.endswith("libfvit_hip_diag.so")
+lib = _lib.lib()
+sink = torch.zeros(16, dtype=torch.int32, device="cuda")
+for entry, bs, precise in (("faster_vit_0_224", 86, False), ("faster_vit_1_224", 4, False), ("faster_vit_0_224", 8, True)):
+    torch.manual_seed(0)
+    model = fastervit_amd.create_model(entry).eval().cuda().to(memory_format=torch.channels_last)
+    if precise:
+        model.set_hat_operand_dtype("f16x3")
+    x = torch.randn(bs, 3, 224, 224, generator=torch.Generator().manual_seed(3)).cuda().contiguous(memory_format=torch.channels_last)
+    plan = DeployPlan(model, torch.float16)
+    plan.streams = 1
+    plan.precise = precise
+    with torch.no_grad():
+        base = plan.forward(x).clone()
+        try:
+            for pattern in (0x7fc07fc0, 0x40004000, 0):
+                lib.fvit_debug_poison_launches(sink.data_ptr(), pattern)
+                y = plan.forward(x).clone()
+                torch.cuda.synchronize()
+                assert torch.isfinite(y).all() and torch.equal(y, base), f"{entry} precise={precise}: result depends on the register / LDS poison {pattern:#x}"
+        finally:
+            lib.fvit_debug_poison_launches(None, 0)
+print("POISON-OK")
+"""
+    env = dict(os.environ, FVIT_DIAG="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    res = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert res.returncode == 0 and "POISON-OK" in res.stdout, res.stdout[-3000:]
 
 
 _DEFAULTS = {"gemm_stagger": 0, "ab_stagger": 0, "mlp_stagger": 0, "ab_variant": 0, "gemm_ring": 2, "mlp_ring4_max_grid": 0,
