@@ -94,6 +94,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline sample")
     ap.add_argument("--prof-steps", type=int, default=3, help="eager HIP-event passes for the roofline rows (0: skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 3 and 5")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step throughput entry (faster_vit_0_224, batch 64; N = 1 only)")
     ap.add_argument("--no-rank-parity", action="store_true", help="N > 1: skip the per-rank parity check against the CPU oracle")
     ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--secondary-streams", type=int, default=0, help="stream shards of the secondary configs' precise plan (0: the default, 2)")
@@ -511,6 +512,44 @@ def run_secondary(args, dev):
     return res
 
 
+def run_train_step(args, dev, batch=64, steps=5, warmup=2):
+    """SURVEY.md section 8 row f-4, the part one GPU can verify: one TRAINING step of faster_vit_0_224 = forward in train mode
+    (BatchNorm batch statistics, stochastic depth; HAT stages = the unit-kernel chain as ONE autograd node each) + backward (kernel-sequence backward of
+    fastervit_amd.hat_backward for the HAT stages, PyTorch-ROCm autograd for the conv side) + AdamW on ALL parameters, batch 64, fp32 master weights,
+    16-bit MFMA operands.  What train.py:820-951 does per iteration minus data / scheduler / EMA plumbing (out of scope).  A secondary number: the
+    training path is correct and trainable (tests/test_gpu_backward.py), not tuned."""
+    import fastervit_amd
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    model = fastervit_amd.create_model("faster_vit_0_224", drop_path_rate=0.1).to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(batch, 3, 224, 224, generator=g).to(dev)
+    y = torch.randint(0, 1000, (batch,), generator=g).to(dev)
+    losses = []
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(model(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(loss)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ls = [round(float(v), 4) for v in losses]
+    return {"workload": f"faster_vit_0_224 TRAINING step (forward train mode + backward + AdamW, all parameters), batch {batch}, 224x224, synthetic data",
+            "value": round(batch * steps / el, 1), "unit": "images/s", "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 2),
+            "loss_first_last": [ls[0], ls[-1]], "finite": bool(all(v == v and abs(v) < 1e9 for v in ls)),
+            "note": "HAT stages: unit-kernel forward + kernel-sequence backward (hat_backward.py), conv side: PyTorch-ROCm autograd; not tuned"}
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # the printed line: ONE compact JSON object (driver-parsed; < 8 KB, tests/test_bench_launch.py); everything else goes to a file
 # ------------------------------------------------------------------------------------------------------------------------
@@ -565,10 +604,13 @@ def compact_line(out, detail_path=None):
             if s.get("roofline"):
                 e["roofline"] = _pick(s["roofline"], ("kernel", "bound", "frac", "avg_launch_us", "traffic_over_algorithmic"))
             c["secondary"].append(e)
+    if out.get("train_step"):
+        c["train_step"] = _pick(out["train_step"], ("value", "unit", "ms_per_step", "steps", "loss_first_last", "finite", "error"))
+        c["train_step"]["workload"] = "faster_vit_0_224 fwd+bwd+AdamW, batch 64"
     c["detail"] = detail_path
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > LINE_BUDGET:   # never let prose grow the line past what the driver's stdout tail holds
-        for k in ("secondary", "step_ms", "parity_f16x2", "parity_bf16", "hat_ms_per_step", "kernel_ms_per_step_serialized", "launches_per_step"):
+        for k in ("train_step", "secondary", "step_ms", "parity_f16x2", "parity_bf16", "hat_ms_per_step", "kernel_ms_per_step_serialized", "launches_per_step"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) <= LINE_BUDGET:
@@ -764,6 +806,11 @@ def main():
         del cfg
         torch.cuda.empty_cache()
         out["secondary"] = run_secondary(args, dev)
+        if not args.no_train_step:
+            try:
+                out["train_step"] = run_train_step(args, dev)
+            except Exception as e:   # never take the headline line down
+                out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     emit(out, args.record)
     finish()
 

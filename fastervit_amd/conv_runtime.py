@@ -256,6 +256,21 @@ class DeployPlan:
                                                     _stream(self.dev)), "fvit_bias_residual_cl")
         return x
 
+    def _pool_head(self, x, hw, hb):
+        """AdaptiveAvgPool2d(1) + flatten + head (FV:955-960; final BatchNorm folded into hw / hb) on a channels_last map: fvit_global_avgpool_cl +
+        fvit_head_logits (exact-fp32 MFMA) -- no library kernel in the captured graph.  Maps that are not dense channels_last (a strided stage output)
+        or whose channel count is not a multiple of 16 take the PyTorch ops."""
+        B, C, H, W = x.shape
+        if x.dtype in hat_runtime._DT and x.permute(0, 2, 3, 1).is_contiguous() and C % 16 == 0 and hw.shape[1] == C and hw.is_contiguous():
+            feat = torch.empty((B, C), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().fvit_global_avgpool_cl(hat_runtime._DT[x.dtype], x.data_ptr(), feat.data_ptr(), B, H * W, C, _stream(self.dev)),
+                       "fvit_global_avgpool_cl")
+            out = torch.empty((B, hw.shape[0]), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().fvit_head_logits(feat.data_ptr(), hw.data_ptr(), hb.data_ptr(), out.data_ptr(), B, hw.shape[0], C, _stream(self.dev)),
+                       "fvit_head_logits")
+            return out
+        return F.linear(x.float().mean(dim=(2, 3)), hw, hb)
+
     def _ln2d(self, x, w, b, eps, c_valid=None):
         """LayerNorm2d over the first c_valid (default: all) channels of a channels_last map; pad channels stay zero."""
         B, C, H, W = x.shape
@@ -485,8 +500,7 @@ class DeployPlan:
             if ln is not None:
                 nh, nl = self._ln2d_px(None, None, f32.contiguous(memory_format=torch.channels_last), *ln, f32.shape[1])
                 f32 = nh.float() + nl.float()
-            feat = f32.mean(dim=(2, 3))
-            return F.linear(feat, hw, hb)
+            return self._pool_head(f32, hw, hb)
 
     def _forward_one(self, x, lv_from=0, lv_to=None):
         """Levels [lv_from, lv_to) of the plan; the stem runs in front of level 0, final norm + pool + head after the last level
@@ -549,8 +563,7 @@ class DeployPlan:
             hw, hb, ln = t["head"]
             if ln is not None:
                 x = self._ln2d(x, *ln)
-            feat = x.float().mean(dim=(2, 3))
-            return F.linear(feat, hw, hb)
+            return self._pool_head(x, hw, hb)
 
 
 class ShardRunner:

@@ -130,6 +130,23 @@ __global__ __launch_bounds__(256) void ln2d_kernel(const T* __restrict__ in, T* 
     }
 }
 
+// AdaptiveAvgPool2d(1) of a channels-last map (FV:926, 955): feat[b][c] = mean over the HW pixels of in[b][.][c], fp32 sums in a fixed order
+// (lane-serial over pixels, then a fixed tree over the 4 waves of the workgroup): bitwise repeatable.  One workgroup per (image, 64-channel group);
+// wave w takes pixels w, w + 4, ...; lane = channel.
+template <typename TIN>
+__global__ __launch_bounds__(256) void avgpool_kernel(const TIN* __restrict__ in, float* __restrict__ out, int HW, int C) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C) {
+        const TIN* src = in + (size_t)b * HW * C + c;
+        for (int p = w; p < HW; p += 4) s += (float)src[(size_t)p * C];
+    }
+    part[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C) out[(size_t)b * C + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x])) / (float)HW;
+}
+
 template <typename T>
 int bias_launch(T* x, const T* y, const float* bias, int64_t n, int C, int act, int mode, hipStream_t stream) {
     const int vec = (C % 8 == 0) ? 8 : 4;
@@ -215,6 +232,17 @@ int fvit_layernorm2d_cl(int32_t dtype, const void* in, void* out, const float* w
     if (dtype == FVIT_BF16) return ln2d_launch<__bf16>((const __bf16*)in, (__bf16*)out, weight, bias, eps, n_pixels, C, C_valid, (hipStream_t)stream);
     set_error("layernorm2d: dtype %d not supported (16-bit maps only)", dtype);
     return FVIT_EINVAL;
+}
+
+int fvit_global_avgpool_cl(int32_t dtype, const void* in, float* out, int32_t B, int32_t HW, int32_t C, fvit_stream_t stream) {
+    if (!in || !out || B <= 0 || HW <= 0 || C <= 0) { set_error("global_avgpool: bad arguments"); return FVIT_EINVAL; }
+    ProfScope prof(FVIT_K_OTHER, 0.0, (double)B * HW * C * (dtype == FVIT_F32 ? 4.0 : 2.0), (hipStream_t)stream);
+    const dim3 grid((C + 63) / 64, B);
+    if (dtype == FVIT_F32) hipLaunchKernelGGL((avgpool_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, out, HW, C);
+    else if (dtype == FVIT_F16) hipLaunchKernelGGL((avgpool_kernel<_Float16>), grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)in, out, HW, C);
+    else if (dtype == FVIT_BF16) hipLaunchKernelGGL((avgpool_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)in, out, HW, C);
+    else { set_error("global_avgpool: dtype %d", dtype); return FVIT_EINVAL; }
+    return check_launch("avgpool_kernel");
 }
 
 int fvit_layernorm2d_px(int32_t dtype, const void* in, const void* in_lo, const float* in_f32, void* out, void* out_lo, const float* weight,

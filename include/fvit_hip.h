@@ -401,6 +401,10 @@ int fvit_bias_residual_cl(int32_t dtype, void* x, const void* y, const float* bi
 int fvit_layernorm2d_cl(int32_t dtype, const void* in, void* out, const float* weight, const float* bias, float eps,
                         int64_t n_pixels, int32_t C, int32_t C_valid, fvit_stream_t stream);
 
+/* AdaptiveAvgPool2d(1) + flatten (FV:926, 955-956) of a channels-last map: out f32 [B][C] = mean over the HW pixels of in [B][HW][C] (fp32 / fp16 / bf16),
+ * fp32 sums in a fixed order (bitwise repeatable).  With fvit_head_logits the tail of the deploy plan: no library kernel in the timed graph. */
+int fvit_global_avgpool_cl(int32_t dtype, const void* in, float* out, int32_t B, int32_t HW, int32_t C, fvit_stream_t stream);
+
 /* 3x3 convolution, pad 1, stride 1 or 2, on channels-last 16-bit maps as an implicit GEMM on the MFMA cores with the
  * epilogue fused: out = act(conv(in, weight) + bias) (+ residual).  Replaces (deploy mode, BatchNorm folded into
  * weight/bias) conv + BN + ReLU of PatchEmbed (FV:462-464), conv-BN-GELU / conv-BN-gamma-residual of ConvBlock

@@ -276,3 +276,28 @@ def test_precise_plan_tiny_configs_vs_oracle():
         err = max_abs(y, ref)
         print(f"{name} precise plan: {err:.3e} on |{ref.abs().max().item():.2f}|")
         assert err < 3e-4 * max(ref.abs().max().item(), 1.0)   # 'stress' weights; measured 3e-5 .. 1.2e-4 relative
+
+
+@pytest.mark.parametrize("dt,code,B,HW,C", [(torch.float16, 1, 5, 49, 512), (torch.float32, 0, 3, 49, 1568), (torch.bfloat16, 2, 2, 1, 64), (torch.float16, 1, 4, 196, 200)])
+def test_global_avgpool_and_head(dt, code, B, HW, C):
+    """Tail of the deploy plan: AdaptiveAvgPool2d(1) + flatten (fvit_global_avgpool_cl) and the head (fvit_head_logits, exact-fp32 MFMA) vs torch fp64."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(C + HW)
+    x = torch.randn(B, HW, C, generator=g).to(dt).cuda()
+    feat = torch.full((B, C), float("nan"), device="cuda")
+    _lib.check(lib.fvit_global_avgpool_cl(code, x.data_ptr(), feat.data_ptr(), B, HW, C, _stream()), "avgpool")
+    torch.cuda.synchronize()
+    ref = x.double().mean(dim=1)
+    assert (feat.double() - ref).abs().max().item() < 1e-6 * max(ref.abs().max().item(), 1.0)
+    feat2 = torch.empty_like(feat)
+    _lib.check(lib.fvit_global_avgpool_cl(code, x.data_ptr(), feat2.data_ptr(), B, HW, C, _stream()), "avgpool")
+    torch.cuda.synchronize()
+    assert torch.equal(feat, feat2)
+    if C % 16 == 0:
+        w = (torch.randn(1000, C, generator=g) / C ** 0.5).cuda()
+        b = torch.randn(1000, generator=g).cuda()
+        out = torch.empty(B, 1000, device="cuda")
+        _lib.check(lib.fvit_head_logits(feat.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, 1000, C, _stream()), "head")
+        torch.cuda.synchronize()
+        refl = feat.double() @ w.double().t() + b.double()
+        assert (out.double() - refl).abs().max().item() < 2e-6 * max(refl.abs().max().item(), 1.0)

@@ -130,8 +130,21 @@ def test_device_and_mode_errors():
     xin = torch.randn(2, C, 14, 14, device="cuda")
     with pytest.raises(RuntimeError, match="no CPU"):
         lvl(xin.cpu())
+    # a stage whose own parameters require grad is differentiable in eval mode with grad enabled (r05, ADVICE r04: a frozen conv side with
+    # trainable HAT blocks used to get detached outputs): the gradient flows to a leaf input and to the stage's parameters
+    xl = xin.clone().requires_grad_(True)
+    yl = lvl(xl)
+    assert yl.grad_fn is not None
+    yl.sum().backward()
+    assert xl.grad is not None and lvl.blocks[0].attn.qkv.weight.grad is not None
+    model.zero_grad(set_to_none=True)
+    # ... with the stage frozen, the forward-only entry point is what runs: a leaf input that asks for a gradient is an error, not a cut graph
+    for p_ in lvl.parameters():
+        p_.requires_grad_(False)
     with pytest.raises(RuntimeError, match="requires grad"):
         lvl(xin.clone().requires_grad_(True))
+    for p_ in lvl.parameters():
+        p_.requires_grad_(True)
     # an eval-mode whole-model forward WITHOUT torch.no_grad() runs and -- r04 -- is differentiable wherever hat_backward covers the
     # stages (tiny_hier: head_dim 24, 53-token windows): same numbers as under no_grad, and the gradient w.r.t. the input flows instead of being cut
     with torch.no_grad():
