@@ -218,45 +218,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
         const T* RL = (const T*)p.res_lo;
         T* OL = (T*)p.out_lo;
         float* OF = p.out_f32;
+        // the activation is dispatched ONCE (a runtime `act` inside the unrolled per-element loops keeps every body in the instruction stream)
+        auto px_epilogue = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 64 + mi * 16 + s;
-            if (m < p.M) {
-                float y[NC];
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = m0 + wm * 64 + mi * 16 + s;
+                if (m < p.M) {
+                    float y[NC];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[ni][mi][r] + bias[ni * 4 + r];
-                        if (p.act == 1) v = fmaxf(v, 0.f);
-                        else if (p.act == 2) v = gelu_erf(v);
-                        y[ni * 4 + r] = v;
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[ni][mi][r] + bias[ni * 4 + r];
+                            if (ACT == 1) v = fmaxf(v, 0.f);
+                            else if (ACT == 2) v = gelu_erf(v);
+                            y[ni * 4 + r] = v;
+                        }
+                    if (R) {
+                        const vout rv = *(const vout*)(R + (size_t)m * p.Cout + nb);
+#pragma unroll
+                        for (int j = 0; j < NC; ++j) y[j] += (float)rv[j];
+                        if (RL) {
+                            const vout rl = *(const vout*)(RL + (size_t)m * p.Cout + nb);
+#pragma unroll
+                            for (int j = 0; j < NC; ++j) y[j] += (float)rl[j];
+                        }
                     }
-                if (R) {
-                    const vout rv = *(const vout*)(R + (size_t)m * p.Cout + nb);
+                    if (OF) {
 #pragma unroll
-                    for (int j = 0; j < NC; ++j) y[j] += (float)rv[j];
-                    if (RL) {
-                        const vout rl = *(const vout*)(RL + (size_t)m * p.Cout + nb);
+                        for (int j = 0; j < NC; j += 4) *(f4*)(OF + (size_t)m * p.Cout + nb + j) = (f4){y[j], y[j + 1], y[j + 2], y[j + 3]};
+                    } else {
+                        vout oh, ol;
 #pragma unroll
-                        for (int j = 0; j < NC; ++j) y[j] += (float)rl[j];
+                        for (int j = 0; j < NC; ++j) {
+                            oh[j] = sat16<T>(y[j]);
+                            ol[j] = sat16<T>(y[j] - (float)oh[j]);
+                        }
+                        *(vout*)(O + (size_t)m * p.Cout + nb) = oh;
+                        if (OL) *(vout*)(OL + (size_t)m * p.Cout + nb) = ol;
                     }
-                }
-                if (OF) {
-#pragma unroll
-                    for (int j = 0; j < NC; j += 4) *(f4*)(OF + (size_t)m * p.Cout + nb + j) = (f4){y[j], y[j + 1], y[j + 2], y[j + 3]};
-                } else {
-                    vout oh, ol;
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) {
-                        oh[j] = sat16<T>(y[j]);
-                        ol[j] = sat16<T>(y[j] - (float)oh[j]);
-                    }
-                    *(vout*)(O + (size_t)m * p.Cout + nb) = oh;
-                    if (OL) *(vout*)(OL + (size_t)m * p.Cout + nb) = ol;
                 }
             }
-        }
+        };
+        if (p.act == 0) px_epilogue(IntTag<0>{});
+        else if (p.act == 1) px_epilogue(IntTag<1>{});
+        else px_epilogue(IntTag<2>{});
         return;
     }
     dispatch_epilogue(p.act, R != nullptr, [&](auto act_tag, auto res_tag) {

@@ -53,6 +53,8 @@ struct GemmParams {
     int rpi;
 };
 
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+
 // swizzle of the 16-byte chunk index inside a 128-byte LDS row.
 //  X tile: fragments read 16 consecutive rows           -> f = (r >> 1) & 7
 //  W tile: fragments read rows {g*16 + ni*4 + r'}        -> f = perm(g) | (r' >> 1) << 2
@@ -330,48 +332,47 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
         }
         }
     } else {
+        // one dispatch on "two-term output" per column group (r05): the per-element form `lo_off > 0 ? gelu_erf : gelu_fast` inside the unrolled loops
+        // kept BOTH bodies (and a second evaluation for the lo term) in the instruction stream: 21k instructions, ~2 erf per value
         T* O = (T*)p.out;
+        auto store16 = [&](auto lo_tag) {
+            constexpr bool LO = decltype(lo_tag)::value;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int m = m0 + wm * (16 * MI) + mi * 16 + s;
-            if (m < p.M) {
-                v8 o0, o1;
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    f4 a = acc[cg * 4 + ni][mi];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float y = a[r] + bias[ni * 4 + r];
-                        if (EPI == 1) y = p.lo_off > 0 ? gelu_erf(y) : gelu_fast(y);
-                        if (ni < 2) o0[ni * 4 + r] = sat16<T>(y); else o1[(ni - 2) * 4 + r] = sat16<T>(y);
-                    }
-                }
-                T* po = O + (size_t)m * p.ldo + nb;
-                *(v8*)po = o0;
-                *(v8*)(po + 8) = o1;
-                if (p.lo_off > 0) {   // two-term activations (weight_terms 3): the rounding remainder as a second 16-bit term
-                    v8 l0, l1;
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = m0 + wm * (16 * MI) + mi * 16 + s;
+                if (m < p.M) {
+                    float y[16];
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) {
-                        f4 a = acc[cg * 4 + ni][mi];
+                        const f4 a = acc[cg * 4 + ni][mi];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float y = a[r] + bias[ni * 4 + r];
-                            if (EPI == 1) y = p.lo_off > 0 ? gelu_erf(y) : gelu_fast(y);
-                            const float hi = (float)(ni < 2 ? o0[ni * 4 + r] : o1[(ni - 2) * 4 + r]);
-                            if (ni < 2) l0[ni * 4 + r] = sat16<T>(y - hi); else l1[(ni - 2) * 4 + r] = sat16<T>(y - hi);
+                            float v = a[r] + bias[ni * 4 + r];
+                            if (EPI == 1) v = LO ? gelu_erf(v) : gelu_fast(v);
+                            y[ni * 4 + r] = v;
                         }
                     }
-                    *(v8*)(po + p.lo_off) = l0;
-                    *(v8*)(po + p.lo_off + 8) = l1;
+                    v8 o0, o1;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { o0[j] = sat16<T>(y[j]); o1[j] = sat16<T>(y[8 + j]); }
+                    T* po = O + (size_t)m * p.ldo + nb;
+                    *(v8*)po = o0;
+                    *(v8*)(po + 8) = o1;
+                    if constexpr (LO) {   // two-term activations (weight_terms 3): the rounding remainder as a second 16-bit term
+                        v8 l0, l1;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { l0[j] = sat16<T>(y[j] - (float)o0[j]); l1[j] = sat16<T>(y[8 + j] - (float)o1[j]); }
+                        *(v8*)(po + p.lo_off) = l0;
+                        *(v8*)(po + p.lo_off + 8) = l1;
+                    }
                 }
             }
-        }
+        };
+        if (p.lo_off > 0) store16(BoolTag<true>{}); else store16(BoolTag<false>{});
     }
     }
 }
 
-template <bool V> struct BoolTag { static constexpr bool value = V; };
 
 // ------------------------------------------------------------------------------------------------------------
 // 256 x 256 x 64 tile, two wave groups in PING-PONG (r03): while the four waves of one group issue the 16 MFMAs of a phase, the four waves
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
         bias[j * 4 + 0] = t[0]; bias[j * 4 + 1] = t[1]; bias[j * 4 + 2] = t[2]; bias[j * 4 + 3] = t[3];
     }
     const int mw = m0 + wm * 128 + s;
-    auto finish = [&](auto full_tag, auto add_tag) {
+    auto finish = [&](auto full_tag, auto add_tag, auto lo_tag) {
         constexpr bool FULL = decltype(full_tag)::value, ADD = decltype(add_tag)::value;
         if constexpr (EPI == 2) {
             float gam[16];
@@ -554,37 +555,32 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
             }
         } else {
             T* O = (T*)p.out;
+            constexpr bool LO = decltype(lo_tag)::value;   // two-term output: dispatched ONCE (see gemm_kernel)
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 const int m = mw + mi * 16;
                 if (FULL || m < p.M) {
-                    v8 o0, o1;
+                    float y[16];
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) {
                         const f4 a = acc[ni][mi];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float y = a[r] + bias[ni * 4 + r];
-                            if (EPI == 1) y = p.lo_off > 0 ? gelu_erf(y) : gelu_fast(y);
-                            if (ni < 2) o0[ni * 4 + r] = sat16<T>(y); else o1[(ni - 2) * 4 + r] = sat16<T>(y);
+                            float v = a[r] + bias[ni * 4 + r];
+                            if (EPI == 1) v = LO ? gelu_erf(v) : gelu_fast(v);
+                            y[ni * 4 + r] = v;
                         }
                     }
+                    v8 o0, o1;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { o0[j] = sat16<T>(y[j]); o1[j] = sat16<T>(y[8 + j]); }
                     T* po = O + (size_t)m * p.ldo + nb;
                     *(v8*)po = o0;
                     *(v8*)(po + 8) = o1;
-                    if (p.lo_off > 0) {   // two-term activations: see gemm_kernel
+                    if constexpr (LO) {
                         v8 l0, l1;
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) {
-                            const f4 a = acc[ni][mi];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                float y = a[r] + bias[ni * 4 + r];
-                                if (EPI == 1) y = p.lo_off > 0 ? gelu_erf(y) : gelu_fast(y);
-                                const float hi = (float)(ni < 2 ? o0[ni * 4 + r] : o1[(ni - 2) * 4 + r]);
-                                if (ni < 2) l0[ni * 4 + r] = sat16<T>(y - hi); else l1[(ni - 2) * 4 + r] = sat16<T>(y - hi);
-                            }
-                        }
+                        for (int j = 0; j < 8; ++j) { l0[j] = sat16<T>(y[j] - (float)o0[j]); l1[j] = sat16<T>(y[8 + j] - (float)o1[j]); }
                         *(v8*)(po + p.lo_off) = l0;
                         *(v8*)(po + p.lo_off + 8) = l1;
                     }
@@ -593,9 +589,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
         }
     };
     const bool full = m0 + wm * 128 + 128 <= p.M;
-    if (EPI == 2 && p.add) { if (full) finish(BoolTag<true>{}, BoolTag<true>{}); else finish(BoolTag<false>{}, BoolTag<true>{}); }
-    else if (full) finish(BoolTag<true>{}, BoolTag<false>{});
-    else finish(BoolTag<false>{}, BoolTag<false>{});
+    if (EPI == 2 && p.add) { if (full) finish(BoolTag<true>{}, BoolTag<true>{}, BoolTag<false>{}); else finish(BoolTag<false>{}, BoolTag<true>{}, BoolTag<false>{}); }
+    else if (EPI != 2 && p.lo_off > 0) { if (full) finish(BoolTag<true>{}, BoolTag<false>{}, BoolTag<true>{}); else finish(BoolTag<false>{}, BoolTag<false>{}, BoolTag<true>{}); }
+    else if (full) finish(BoolTag<true>{}, BoolTag<false>{}, BoolTag<false>{});
+    else finish(BoolTag<false>{}, BoolTag<false>{}, BoolTag<false>{});
 }
 
 // split-K second pass: x[m][n] += gamma[n] * (sum_s slab[s][m][n] + bias[n]), partial sums added in split order (fixed: bitwise repeatable)
