@@ -288,7 +288,8 @@ def pmc_file_for(model_name):
     """Committed PMC summary of a configuration: the headline file, or profiles/r03_pmc_hbm_traffic_by_kernel_<model>.json."""
     if model_name in (None, "faster_vit_0_224"):
         return PMC_FILE
-    return os.path.join("profiles", f"r03_pmc_hbm_traffic_by_kernel_{model_name}.json")
+    cands = [os.path.join("profiles", f"r0{r}_pmc_hbm_traffic_by_kernel_{model_name}.json") for r in ROUNDS]   # the newest committed round wins
+    return next((f for f in cands if os.path.exists(os.path.join(ROOT, f))), cands[-1])
 
 
 def pmc_row(kernel, workgroups, pmc_file=None):
@@ -533,7 +534,7 @@ def run_train_step(args, dev, batch=64, steps=5, warmup=2):
         loss = F.cross_entropy(model(x), y)
         loss.backward()
         opt.step()
-        losses.append(loss)
+        losses.append(loss.detach())
 
     for _ in range(warmup):
         step()
