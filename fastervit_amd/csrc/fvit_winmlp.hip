@@ -431,9 +431,19 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
         if (c.C == 512) hipLaunchKernelGGL((winmlp_kernel<_Float16, 512, 2048, 4, 2, 8, 1, 1, true>), dim3(grid), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((winmlp_kernel<_Float16, 256, 1024, 4, 2, 4, 1, 1, true>), dim3(grid), dim3(256), 0, stream, p);
     } else if (c.C == 512 && nsplit == 2) FVIT_WINMLP_ST(2);
+    // (a 4-deep ring for C = 512 needs 105 spilled registers at 8 waves x 256: not instantiated)
     else if (c.C == 512) FVIT_WINMLP_T(512, 2048, 4, 8);
     else if (wide == 5) FVIT_WINMLP_T(256, 1024, 5, 8);
     else if (wide == 6) FVIT_WINMLP_T(256, 1024, 6, 8);
+    else if (small && tune_get("win_mlp256_depth", 2) == 4) {
+        // r05 experiment: a 4-deep weight ring (a whole super-chunk of fragments in flight per wave: 32 KiB instead of 16): 256 registers, 12 accumulator
+        // dwords spilled once per super-chunk.  The phase timeline (profiles/r03_winmlp_phase_timeline.log) has 3.85 us per super-chunk against 0.85 us of
+        // MFMA issue: two 8 KiB steps in flight per wave / ~1.9 us = the rate of the 2-deep ring.
+#define FVIT_WINMLP_D4(T, SP_) hipLaunchKernelGGL((winmlp_kernel<T, 256, 1024, 4, 4, 4, SP_>), dim3(grid), dim3(256), 0, stream, p)
+        if (c.dtype == FVIT_F16) { if (c.terms == 2) FVIT_WINMLP_D4(_Float16, 2); else FVIT_WINMLP_D4(_Float16, 1); }
+        else { if (c.terms == 2) FVIT_WINMLP_D4(__bf16, 2); else FVIT_WINMLP_D4(__bf16, 1); }
+#undef FVIT_WINMLP_D4
+    }
     else if (small) FVIT_WINMLP_T(256, 1024, 4, 4);
     else FVIT_WINMLP_T(256, 1024, 8, 8);
 #undef FVIT_WINMLP_ST

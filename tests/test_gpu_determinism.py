@@ -126,12 +126,12 @@ print("POISON-OK")
 
 
 _DEFAULTS = {"gemm_stagger": 0, "ab_stagger": 0, "mlp_stagger": 0, "ab_variant": 0, "gemm_ring": 2, "mlp_ring4_max_grid": 0,
-             "attn_fused_min_rows": 16384, "mlp_fused_min_rows": 16384, "ln_gemm": 0, "ct_fused": 1, "ct_variant": 3, "ct_touch": 0, "win_fused": 1, "win_mlp": 1, "win_mlp256": 2, "win_fused256": 0}
+             "attn_fused_min_rows": 16384, "mlp_fused_min_rows": 16384, "ln_gemm": 0, "ct_fused": 1, "ct_variant": 3, "ct_touch": 0, "win_fused": 1, "win_mlp": 1, "win_mlp256": 2, "win_fused256": 0, "win_mlp256_depth": 2}
 
 
 @pytest.mark.parametrize("knobs", [dict(gemm_stagger=1), dict(ab_stagger=1, mlp_stagger=1), dict(mlp_stagger=2), dict(ab_variant=2),
                                    dict(ab_variant=1), dict(gemm_ring=3), dict(gemm_ring=4), dict(mlp_ring4_max_grid=320),
-                                   dict(attn_fused_min_rows=0, mlp_fused_min_rows=0), dict(ln_gemm=1), dict(ct_fused=0), dict(ct_variant=0), dict(ct_variant=1), dict(ct_variant=2), dict(ct_variant=0, ct_touch=1), dict(win_fused=0), dict(win_mlp=0), dict(win_mlp=0, win_fused=0, ln_gemm=1), dict(win_mlp256=1), dict(win_mlp256=0), dict(win_fused256=1)])
+                                   dict(attn_fused_min_rows=0, mlp_fused_min_rows=0), dict(ln_gemm=1), dict(ct_fused=0), dict(ct_variant=0), dict(ct_variant=1), dict(ct_variant=2), dict(ct_variant=0, ct_touch=1), dict(win_fused=0), dict(win_mlp=0), dict(win_mlp=0, win_fused=0, ln_gemm=1), dict(win_mlp256=1), dict(win_mlp256=0), dict(win_fused256=1), dict(win_mlp256_depth=4)])
 def test_order_stagger_knobs_keep_the_result(knobs):
     """Kernel-selection knobs (K / chunk / head order stagger, LDS ring depths, workgroup shapes, fused vs unfused carrier branch) only
     permute fp32 sums or change who computes what: same stage output within summation-order noise, still bit-repeatable."""
