@@ -42,7 +42,7 @@ def main():
                      "valu_insts_per_launch": round(c.get("SQ_INSTS_VALU", 0.0) / n, 0), "lds_bank_conflict_per_launch": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / n, 0),
                      "wave_quad_cycles_per_launch": round(wc / n, 0)})
     rows.sort(key=lambda r: -r["total_us"])
-    json.dump({"note": "SQ counters per launch from one rocprofv3 PMC pass of `bench.py --no-graph` (eager, 3 stream shards); ratios to SQ_WAVE_CYCLES",
+    json.dump({"note": "SQ counters per launch from one rocprofv3 PMC pass of `bench.py --no-graph` (eager, the default launch structure: 2 stream shards joined in front of level 3); ratios to SQ_WAVE_CYCLES",
                "kernels": rows}, open(sys.argv[2], "w"), indent=1)
     print(f"{len(rows)} (kernel, grid) rows -> {sys.argv[2]}")
     for r in rows[:10]:
