@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     const int cpt = p.Cin / BK;  // K steps per tap
     const int nk1 = 9 * cpt;     // K steps of one weight term
     // PX: element distance from the hi plane of the input to its lo plane (the third K segment reads the lo plane against the hi weights)
-    const int64_t lo_delta = (PX && p.in_lo) ? ((const T*)p.in_lo - In) : 0;
+    const int64_t lo_delta = (PX && p.in_lo) ? ((int64_t)((intptr_t)p.in_lo - (intptr_t)p.in) / (int64_t)sizeof(T)) : 0;   // two separate allocations: integer arithmetic
     auto stage = [&](int kt, char* xbuf, char* wbuf) {
         const int seg = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
         const int kta = kt - seg * nk1;              // the activation side wraps at every segment
