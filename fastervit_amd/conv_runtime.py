@@ -478,7 +478,11 @@ class DeployPlan:
                         hat_runtime.stage_forward(lvl, xin, out=xo[:, :creal])
                         f32 = xo
                     else:
-                        f32 = hat_runtime.stage_forward(lvl, xin)
+                        # (an explicit channels_last output: empty_like of the strided channel slice `xin` would be NCHW-contiguous -- uncoalesced
+                        # window_reverse stores and no dense [B][HW][C] image for the pool kernel)
+                        xo = torch.empty((f32.shape[0], creal, f32.shape[2], f32.shape[3]), dtype=torch.float32, device=f32.device,
+                                         memory_format=torch.channels_last)
+                        f32 = hat_runtime.stage_forward(lvl, xin, out=xo)
                     hi = lo = None
                 if "down" in e:
                     lw, lb, eps, wd, cin = e["down"]
@@ -554,7 +558,8 @@ class DeployPlan:
                         hat_runtime.stage_forward(lvl, xin, out=xo[:, :creal])  # TokenInitializer: fvit_token_init in both modes
                         x = xo
                     else:
-                        x = hat_runtime.stage_forward(lvl, xin)
+                        xo = torch.empty((x.shape[0], creal, x.shape[2], x.shape[3]), dtype=self.dtype, device=x.device, memory_format=torch.channels_last)
+                        x = hat_runtime.stage_forward(lvl, xin, out=xo)   # (explicit channels_last output: see _forward_one_precise)
                 if "down" in e:
                     lw, lb, eps, wd, cin = e["down"]
                     x = self._conv(self._ln2d(x, lw, lb, eps, cin), wd, None, 2, 0)
