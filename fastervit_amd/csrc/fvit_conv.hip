@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
             if (piece < WPIECES) {
                 const int r = piece * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ swz_w(r);
-                glds16(W + (size_t)(n0 + r) * ldw + ktw * BK + c * 8, wbuf + piece * 1024);
+                glds16(W + (size_t)min(n0 + r, p.Cout - 1) * ldw + ktw * BK + c * 8, wbuf + piece * 1024);   // (ragged last N tile: rows clamped, never stored)
             }
         }
     };
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     constexpr int NC = 4 * NI;  // consecutive channels per lane (16 or 8)
     typedef T vout __attribute__((ext_vector_type(NC)));
     const int nb = n0 + wn * 16 * NI + g * NC;
+    if (nb >= p.Cout) return;   // ragged last N tile (Cout % 128 == 64 on 128-column tiles): these channels do not exist; no barrier follows
     float bias[NC];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -1154,8 +1155,8 @@ int launch_t(ConvParams& p, hipStream_t stream) {
     const int narrow = tune_get("conv128_narrow", 0);
     if (p.px) {   // two-term maps: the implicit GEMM only (128 x 128 tiles when Cout allows, else 128 x 64)
         p.tiles_m = (p.M + 127) / 128;
-        if (p.Cout % 128 == 0) {
-            p.tiles_n = p.Cout / 128;
+        if (p.Cout % 128 == 0 || (p.Cout > 128 && tune_get("conv_n128_ragged", 1))) {
+            p.tiles_n = (p.Cout + 127) / 128;
             prof_note("conv3x3_kernel<2,2,4,px>", p.tiles_m * p.tiles_n);
             hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
         } else {
@@ -1165,9 +1166,13 @@ int launch_t(ConvParams& p, hipStream_t stream) {
         }
         return check_launch("conv3x3_kernel<px>");
     }
-    if (p.Cout % 128 == 0 && !narrow) {
+    // r05 (fvit_tune "conv_n128_ragged", default 1): Cout % 128 == 64 (FasterViT-4: 448 / 832 / 1600 padded channels) also takes the 128 x 128 tile with a
+    // RAGGED last N tile (weight rows clamped, the missing 64 channels never stored: 1 / (2 n) of the MFMAs wasted) instead of 128 x 64 tiles: half the
+    // workgroups, each weight byte staged for 128 pixels feeds twice the MFMAs, and the weight matrix -- 7.2 MB with two terms at 448 channels, more than an
+    // XCD's 4 MB L2 -- is re-streamed from the Infinity Cache per ROUND of resident workgroups: 3 rounds instead of 11 (PMC: 580 MB read per launch)
+    if ((p.Cout % 128 == 0 || (p.Cout > 128 && tune_get("conv_n128_ragged", 1))) && !narrow) {
         p.tiles_m = (p.M + 127) / 128;
-        p.tiles_n = p.Cout / 128;
+        p.tiles_n = (p.Cout + 127) / 128;
         prof_note("conv3x3_kernel<2,2,4>", p.tiles_m * p.tiles_n);
         hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
     } else if (variant == 1) {  // 256 pixels x 64 channels, 80 KiB LDS

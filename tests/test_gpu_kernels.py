@@ -360,6 +360,8 @@ def test_layernorm2d_channel_padded(C, Cv):
     (2, 64, 64, 14, 14, 1, 2, False), (3, 64, 64, 9, 13, 1, 0, True), (2, 64, 64, 16, 16, 2, 1, False),
     (2, 64, 128, 12, 10, 2, 0, False), (2, 128, 128, 7, 9, 1, 2, False), (1, 128, 128, 28, 28, 1, 0, True),
     (2, 128, 256, 14, 14, 2, 0, False), (1, 256, 512, 14, 14, 2, 0, False), (5, 64, 64, 56, 56, 1, 0, True),
+    # Cout % 128 == 64: 128 x 128 tiles with a ragged last N tile (r05; FasterViT-4's 448 / 832 padded channels)
+    (2, 128, 192, 9, 11, 1, 2, True), (1, 256, 448, 14, 14, 1, 0, True), (2, 448, 832, 8, 6, 2, 0, False),
     # halo-tiled kernel (Cin = Cout = 64, stride 1): ragged tiles in both directions, single pixel rows/columns, many tiles per workgroup
     (1, 64, 64, 8, 16, 1, 0, False), (2, 64, 64, 1, 1, 1, 1, True), (1, 64, 64, 3, 40, 1, 2, True), (3, 64, 64, 37, 5, 1, 0, False),
     (2, 64, 64, 17, 33, 1, 2, True), (40, 64, 64, 56, 56, 1, 1, True)])
@@ -392,6 +394,16 @@ def test_conv3x3_fused(dt, code, B, Ci, Co, H, W, stride, act, res):
                                          stride, act, zeros.data_ptr(), _stream()), "conv3x3 in place")
         torch.cuda.synchronize()
         assert torch.equal(r2, out)
+    if Co % 128 == 64 and Co > 128:   # the 128 x 64-tile walk (fvit_tune conv_n128_ragged = 0) sums every output over the same K steps: same bits
+        out2 = torch.full_like(out, float("nan"))
+        try:
+            _lib.tune("conv_n128_ragged", 0)
+            _lib.check(lib.fvit_conv3x3_nhwc(code, x.data_ptr(), wk.data_ptr(), bias.data_ptr(), r.data_ptr() if res else None, out2.data_ptr(), B, H, W,
+                                             Ci, Co, stride, act, zeros.data_ptr(), _stream()), "conv3x3 128x64 tiles")
+        finally:
+            _lib.tune("conv_n128_ragged", 1)
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out)
 
 
 @pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
