@@ -696,14 +696,12 @@ def main():
     rank_parity = None
     if dist is not None and not args.no_rank_parity and args.prof_steps > 0:
         arch_r = oracle_arch(args.model, mk)
-        err_t = torch.full((1,), -1.0, dtype=torch.float64, device=dev)
+        err_r = -1.0
         if arch_r is not None:
             idx_r = sorted(set(list(range(min(4, args.batch))) + list(range(max(args.batch - 4, 0), args.batch))))
             par_r, _ = parity_vs_oracle(cfg, logits_gpu, arch_r, idx_r, "", threads=max(1, min(16, (os.cpu_count() or 1) // world)))
-            err_t[0] = par_r["logits_max_abs_err"]
-        errs = [torch.zeros_like(err_t) for _ in range(world)]
-        dist.all_gather(errs, err_t)
-        per_rank = [float(f"{e.item():.3e}") for e in errs]
+            err_r = par_r["logits_max_abs_err"]
+        per_rank = [float(f"{e:.3e}") for e in dp.gather_values(err_r, dist, dev)]
         if min(per_rank) >= 0:
             rank_parity = {"logits_max_abs_err": max(per_rank), "per_rank": per_rank, "images": 8, "meets_1e-3": bool(max(per_rank) < 1e-3),
                            "vs": "CPU oracle fp32, 8 images (first and last 4) of EVERY rank's batch, each rank on its own host threads"}

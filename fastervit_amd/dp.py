@@ -99,3 +99,14 @@ def whole_job_rate(items_this_rank: int, elapsed_max: float, dist=None, device=N
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total = float(t.item())
     return total / elapsed_max
+
+
+def gather_values(value: float, dist=None, device=None) -> list:
+    """One float per rank, in rank order, on every rank ([value] without a group): per-rank parity errors of ``bench.py --gpus N``."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]

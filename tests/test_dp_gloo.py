@@ -21,6 +21,8 @@ def _worker(rank, world, port, out):
 
     elapsed = dp.timed_steps(step, steps=5, warmup=2, sync=lambda: None, dist=dist)
     rate = dp.whole_job_rate(items_this_rank=5 * (3 + rank), elapsed_max=elapsed, dist=dist)
+    vals = dp.gather_values(1e-4 * (rank + 1), dist)   # per-rank parity errors as bench.py --gpus N gathers them
+    assert vals == [1e-4 * (r + 1) for r in range(world)]
     out.put((rank, len(calls), elapsed, rate))
     dist.barrier()
     dist.destroy_process_group()
@@ -59,3 +61,4 @@ def test_single_process_needs_no_group():
     assert dp.init_process_group("gloo") is None
     e = dp.timed_steps(lambda: None, steps=3, warmup=1, sync=lambda: None)
     assert dp.whole_job_rate(30, e) == 30 / e
+    assert dp.gather_values(0.5) == [0.5]
