@@ -113,9 +113,44 @@ def _unpack_proj(g: torch.Tensor, heads: int, d: int, dp: int) -> torch.Tensor:
     return g[:, :heads * dp].reshape(C_, heads, dp)[:, :, :d].reshape(C_, heads * d)
 
 
-def _rows(scale: Optional[torch.Tensor], group: int) -> Optional[torch.Tensor]:
-    """Per-group DropPath factors (one per window / per image) -> one per row."""
-    return None if scale is None else scale.repeat_interleave(group)
+class _RS:
+    """What scales a sub-block's residual update in TRAIN mode: ``rows`` fp32 [M] = DropPath (one factor per window / image, repeated per row), ``out`` fp32
+    [M][C] = the Dropout mask of the sub-block's OUTPUT (0 or 1 / keep: ``Mlp.drop`` after fc2, FV:406; ``WindowAttention.proj_drop``, FV:567), ``hid``
+    operand-dtype [M][hidden] = the Dropout mask of GELU(fc1) (``Mlp.drop`` after the activation, FV:404).  y = x + rows * out * gamma * f(x): the output mask is
+    an elementwise form of the DropPath factor, so forward and backward treat the two alike; ``hid`` multiplies the hidden activation (and dh in the backward)."""
+    __slots__ = ("rows", "out", "hid")
+
+    def __init__(self, rows=None, out=None, hid=None):
+        self.rows, self.out, self.hid = rows, out, hid
+
+
+def _rows(scale, group: int, out=None, hid=None):
+    """Per-group DropPath factors (one per window / per image) -> one per row; with Dropout masks an ``_RS``."""
+    rows = None if scale is None else scale.repeat_interleave(group)
+    if out is None and hid is None:
+        return rows
+    return _RS(rows, out, hid)
+
+
+def _rs(mk: Optional[dict], key: str, group: int):
+    mk = mk or {}
+    return _rows(mk.get(key), group, mk.get(key + "_out"), mk.get(key + "_hid"))
+
+
+def _out_scale(rs, M: int) -> Optional[torch.Tensor]:
+    """fp32 factor of the sub-block's output, broadcastable to [M][C] (None: 1)."""
+    if rs is None:
+        return None
+    if isinstance(rs, torch.Tensor):
+        return rs.float().view(M, 1)
+    sc = None if rs.rows is None else rs.rows.float().view(M, 1)
+    if rs.out is not None:
+        sc = rs.out.float() if sc is None else sc * rs.out.float()
+    return sc
+
+
+def _hid_mask(rs):
+    return rs.hid if isinstance(rs, _RS) else None
 
 
 def mlp_block_backward(x: torch.Tensor, dy: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, fc1_w: torch.Tensor, fc1_b: torch.Tensor,
@@ -154,7 +189,8 @@ def mlp_block_backward(x: torch.Tensor, dy: torch.Tensor, ln_w: torch.Tensor, ln
     dxn = torch.zeros(M, C_, dtype=torch.float32, device=dev)
     dx = torch.empty(M, C_, dtype=torch.float32, device=dev)
     stats = torch.empty(M, 2, dtype=torch.float32, device=dev)
-    dyi = dy if row_scale is None else (dy * row_scale.to(dy.dtype).view(M, 1)).contiguous()   # what the sub-block sees
+    osc, hmask = _out_scale(row_scale, M), _hid_mask(row_scale)
+    dyi = dy if osc is None else (dy * osc).contiguous()   # what the sub-block sees
     p = lambda t: None if t is None else t.data_ptr()   # noqa: E731
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream
@@ -164,6 +200,8 @@ def mlp_block_backward(x: torch.Tensor, dy: torch.Tensor, ln_w: torch.Tensor, ln
                                      C.c_float(eps), M, M, C_, st), "layernorm")
         ck(lib.fvit_gemm_bias_act(code, xn.data_ptr(), Ck, W1.data_ptr(), Ck, b1.data_ptr(), a.data_ptr(), hid, M, hid, Ck, 0, st), "fc1")
         ck(lib.fvit_bwd_gelu(code, a.data_ptr(), hid, None, 0, h.data_ptr(), hid, None, M, hid, st), "gelu")
+        if hmask is not None:
+            h[:M] *= hmask          # Dropout on GELU(fc1) (FV:404): the same mask as in the forward
         ck(lib.fvit_gemm_bias_act(code, h.data_ptr(), hid, W2.data_ptr(), hid, b2.data_ptr(), z.data_ptr(), C_, M, C_, hid, 0, st), "fc2")
         # ---- gamma, fc2 bias, dz = gamma * dy ----
         ck(lib.fvit_bwd_scale_cols(code, dyi.data_ptr(), z.data_ptr(), C_, p(g), dz.data_ptr(), Ck, part.data_ptr(), M, C_, st), "scale_cols")
@@ -176,6 +214,8 @@ def mlp_block_backward(x: torch.Tensor, dy: torch.Tensor, ln_w: torch.Tensor, ln
         ck(lib.fvit_bwd_transpose16(code, h.data_ptr(), hid, hT.data_ptr(), Mk, M, hid, st), "h^T")
         ck(lib.fvit_gemm_residual(code, dzT.data_ptr(), Mk, hT.data_ptr(), Mk, None, None, grads.fc2_w.data_ptr(), hid, C_, hid, Mk, st), "dW2")
         # ---- GELU, fc1 bias ----
+        if hmask is not None:
+            dh[:M] *= hmask         # adjoint of the hidden Dropout
         ck(lib.fvit_bwd_gelu(code, a.data_ptr(), hid, dh.data_ptr(), hid, da.data_ptr(), hid, part.data_ptr(), M, hid, st), "gelu_bwd")
         ck(lib.fvit_bwd_colsum_finish(part.data_ptr(), blocks, hid, grads.fc1_b.data_ptr(), hid, 1, st), "db1")
         # ---- fc1: dW1 += da^T xn, dxn = da W1 ----
@@ -272,7 +312,8 @@ def attn_block_backward(x: torch.Tensor, dy: torch.Tensor, ln_w: torch.Tensor, l
     gq_w = torch.zeros(C3p, C_, dtype=torch.float32, device=dev) if padded else grads.qkv_w
     gq_b = torch.zeros(C3p, dtype=torch.float32, device=dev) if padded else grads.qkv_b
     gp_w = torch.zeros(C_, Kao, dtype=torch.float32, device=dev) if padded else grads.proj_w
-    dyi = dy if row_scale is None else (dy * row_scale.to(dy.dtype).view(M, 1)).contiguous()
+    osc = _out_scale(row_scale, M)
+    dyi = dy if osc is None else (dy * osc).contiguous()
     p = lambda t: None if t is None else t.data_ptr()   # noqa: E731
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream
@@ -319,9 +360,10 @@ def attn_block_backward(x: torch.Tensor, dy: torch.Tensor, ln_w: torch.Tensor, l
 
 def _lerp_rows(x: torch.Tensor, y0: torch.Tensor, row_scale: Optional[torch.Tensor]) -> torch.Tensor:
     """Stochastic depth on top of the residual epilogue: y0 = x + f  ->  x + row_scale[m] * f."""
-    if row_scale is None:
+    sc = _out_scale(row_scale, x.shape[0])
+    if sc is None:
         return y0
-    return torch.addcmul(x, y0 - x, row_scale.to(x.dtype).view(-1, 1))
+    return torch.addcmul(x, y0 - x, sc.to(x.dtype).expand_as(x))
 
 
 def attn_block_forward(x: torch.Tensor, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, gamma, bias, heads: int, S: int, eps: float = 1e-5,
@@ -368,7 +410,7 @@ def local_block_backward(x: torch.Tensor, dy: torch.Tensor, attn: dict, mlp: dic
     ``attn`` = dict(ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b, gamma, bias[, scale]), ``mlp`` = dict(ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, gamma);
     ``masks`` = dict(attn=, mlp=) per-WINDOW DropPath factors or None (train mode).  x1 is recomputed by the forward kernels, then the two sub-block
     backwards run in reverse order.  Returns dx."""
-    ra, rm = _rows((masks or {}).get("attn"), S), _rows((masks or {}).get("mlp"), S)
+    ra, rm = _rs(masks, "attn", S), _rs(masks, "mlp", S)
     x1 = attn_block_forward(x, attn["ln_w"], attn["ln_b"], attn["qkv_w"], attn.get("qkv_b"), attn["proj_w"], attn["proj_b"], attn.get("gamma"),
                             attn.get("bias"), heads, S, eps, attn.get("scale"), operand_dtype, ra)
     dx1 = mlp_block_backward(x1, dy, mlp["ln_w"], mlp["ln_b"], mlp["fc1_w"], mlp["fc1_b"], mlp["fc2_w"], mlp["fc2_b"], mlp.get("gamma"), mlp_grads, eps,
@@ -400,6 +442,8 @@ def mlp_block_forward(x: torch.Tensor, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, g
         ck(lib.fvit_gather_layernorm(code, x.data_ptr(), M, None, 0, None, None, None, None, xn.data_ptr(), Ck, lw.data_ptr(), lb.data_ptr(),
                                      C.c_float(eps), M, M, C_, st), "layernorm")
         ck(lib.fvit_gemm_bias_act(code, xn.data_ptr(), Ck, W1.data_ptr(), Ck, b1.data_ptr(), h.data_ptr(), hid, M, hid, Ck, 1, st), "fc1 + GELU")
+        if _hid_mask(row_scale) is not None:
+            h[:M] *= _hid_mask(row_scale)   # Dropout on GELU(fc1) (FV:404)
         ck(lib.fvit_gemm_residual(code, h.data_ptr(), hid, W2.data_ptr(), hid, b2.data_ptr(), None if g is None else g.data_ptr(), y.data_ptr(), C_,
                                   M, C_, hid, st), "fc2")
     return _lerp_rows(x, y, row_scale)
@@ -432,7 +476,7 @@ def _hier_forward_parts(x, ct, hat_attn, hat_mlp, attn, mlp, heads, ws, cw, sr, 
     dev = x.device
     dew, win = _carrier_permutations(sr0, sr1, cw, dev)
     mk = masks or {}
-    r_ha, r_hm, r_a, r_m = _rows(mk.get("hat_attn"), G), _rows(mk.get("hat_mlp"), G), _rows(mk.get("attn"), S), _rows(mk.get("mlp"), S)
+    r_ha, r_hm, r_a, r_m = _rs(mk, "hat_attn", G), _rs(mk, "hat_mlp", G), _rs(mk, "attn", S), _rs(mk, "mlp", S)
     x0 = (x + pe_x.to(dev)) if pe_x is not None else x
     ct0 = ct[:, dew]
     if pe_ct is not None:
@@ -577,10 +621,13 @@ def _table_grads(sink: Optional[dict], outs, gouts, mods) -> None:
             _emit(sink, prm, g)
 
 
-def drop_path_masks(layer, batch: int, windows_per_image: int, device, generator=None):
-    """Per-block stochastic-depth factors of a stage in TRAIN mode (timm DropPath semantics, FV:630, 652, 690-691: one Bernoulli(keep) / keep draw per
-    sample of the tensor the DropPath is applied to -- per WINDOW for the window branch (x is (B nW, S, C)), per IMAGE for the carrier branch):
-    a list with one dict per block, entries None where the block's drop probability is 0."""
+def drop_path_masks(layer, batch: int, windows_per_image: int, device, generator=None, operand_dtype=torch.float16):
+    """Per-block stochastic factors of a stage in TRAIN mode: a list with one dict per block.
+      * DropPath (timm semantics, FV:630, 652, 690-691: one Bernoulli(keep) / keep draw per sample of the tensor the DropPath is applied to -- per WINDOW for
+        the window branch (x is (B nW, S, C)), per IMAGE for the carrier branch): entries ``attn`` / ``mlp`` / ``hat_attn`` / ``hat_mlp``, None where p = 0;
+      * Dropout inside the blocks (r05; ``drop_rate`` of the entrypoints -> ``Mlp.drop`` after GELU and after fc2, FV:404-406, and ``WindowAttention.proj_drop``,
+        FV:567): elementwise masks ``<key>_out`` fp32 [rows][C] and ``mlp_hid`` / ``hat_mlp_hid`` operand-dtype [rows][hidden], values 0 or 1 / keep, only where p > 0
+        (``attn_drop`` > 0 -- Dropout on the softmax probabilities inside the attention kernel -- is not implemented: ``backward_unsupported_reason``)."""
     out = []
     for blk in layer.blocks:
         def draw(n, mod):
@@ -589,9 +636,24 @@ def drop_path_masks(layer, batch: int, windows_per_image: int, device, generator
                 return None
             keep = 1.0 - p_
             return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep, generator=generator) / keep
-        m = dict(attn=draw(batch * windows_per_image, blk.drop_path), mlp=draw(batch * windows_per_image, blk.drop_path))
+
+        def elem(rows, cols, mod, dt=torch.float32):
+            p_ = float(getattr(mod, "p", 0.0) or 0.0)
+            if p_ <= 0.0:
+                return None
+            keep = 1.0 - p_
+            return (torch.empty(rows, cols, dtype=torch.float32, device=device).bernoulli_(keep, generator=generator) / keep).to(dt)
+
+        C_, hid = blk.attn.qkv.in_features, blk.mlp.fc1.out_features
+        ncw = blk.cr_window ** 2 if blk.do_sr_hat else 0
+        rows = batch * windows_per_image * (blk.window_size ** 2 + ncw)
+        m = dict(attn=draw(batch * windows_per_image, blk.drop_path), mlp=draw(batch * windows_per_image, blk.drop_path),
+                 attn_out=elem(rows, C_, blk.attn.proj_drop), mlp_out=elem(rows, C_, blk.mlp.drop), mlp_hid=elem(rows, hid, blk.mlp.drop, operand_dtype))
         if blk.do_sr_hat:
-            m.update(hat_attn=draw(batch, blk.hat_drop_path), hat_mlp=draw(batch, blk.hat_drop_path))
+            crow = batch * windows_per_image * ncw
+            m.update(hat_attn=draw(batch, blk.hat_drop_path), hat_mlp=draw(batch, blk.hat_drop_path),
+                     hat_attn_out=elem(crow, C_, blk.hat_attn.proj_drop), hat_mlp_out=elem(crow, C_, blk.hat_mlp.drop),
+                     hat_mlp_hid=elem(crow, hid, blk.hat_mlp.drop, operand_dtype))
         out.append(m)
     return out
 
@@ -644,9 +706,9 @@ def _local_stage_run(layer, x: torch.Tensor, operand_dtype, masks=None):
         ins.append(xin)
         ps.append((a, m, bias_t, pe_t))
         x1 = attn_block_forward(xin, a["ln_w"], a["ln_b"], a["qkv_w"], a["qkv_b"], a["proj_w"], a["proj_b"], a["gamma"], a["bias"], heads, S, 1e-5,
-                                a["scale"], operand_dtype, _rows((mk or {}).get("attn"), S))
+                                a["scale"], operand_dtype, _rs(mk, "attn", S))
         rows = mlp_block_forward(x1, m["ln_w"], m["ln_b"], m["fc1_w"], m["fc1_b"], m["fc2_w"], m["fc2_b"], m["gamma"], 1e-5, operand_dtype,
-                                 _rows((mk or {}).get("mlp"), S))
+                                 _rs(mk, "mlp", S))
     return reverse(rows)[:, :, :H, :W], ins, ps, (partition, reverse, heads, S, Hp, Wp)
 
 
@@ -856,8 +918,9 @@ def backward_unsupported_reason(layer, H: Optional[int] = None, W: Optional[int]
             return f"{ncw * sr[0] * sr[1]} carrier tokens per image (at most 64)"
         if H is not None and (-(-H // ws), -(-W // ws)) != sr:
             return f"map {H}x{W} does not pad into the stage's {sr[0]}x{sr[1]} windows of {ws}"
-    if layer.training and any(getattr(m, "p", 0.0) > 0 for m in layer.blocks.modules() if isinstance(m, torch.nn.Dropout)):
-        return "Dropout with p > 0 inside the HAT blocks in train mode (only stochastic depth is implemented)"
+    if layer.training and any(float(getattr(b.attn.attn_drop, "p", 0.0)) > 0 or (hier and float(getattr(b.hat_attn.attn_drop, "p", 0.0)) > 0) for b in blocks):
+        return ("attn_drop > 0 in train mode: Dropout on the softmax probabilities inside the attention kernel is not implemented (drop_rate -- Mlp.drop and "
+                "proj_drop -- and stochastic depth are)")
     return None
 
 
@@ -882,7 +945,7 @@ class HatStageFunction(torch.autograd.Function):
             b0 = layer.blocks[0]
             ws = b0.window_size
             nW = (-(-x.shape[2] // ws)) * (-(-x.shape[3] // ws))
-            ctx.masks = drop_path_masks(layer, x.shape[0], nW, x.device)
+            ctx.masks = drop_path_masks(layer, x.shape[0], nW, x.device, operand_dtype=operand_dtype)
             return stage_forward_train(layer, x.detach(), operand_dtype, ctx.masks)
         return hat_runtime.stage_forward(layer, x.detach())
 

@@ -683,3 +683,94 @@ def test_a_few_training_steps_reduce_the_loss():
     model.eval()
     with torch.no_grad():
         assert torch.isfinite(model(x)).all()   # the updated weights re-pack for the inference kernels
+
+
+def test_dropout_masks_in_the_sub_blocks_vs_autograd():
+    """Dropout inside the blocks in train mode (r05; ``drop_rate`` of the entrypoints): ``Mlp.drop`` after GELU and after fc2 (FV:404-406) and
+    ``WindowAttention.proj_drop`` (FV:567) enter the sub-block forward / backward as explicit masks (``hat_backward._RS``): forward and every gradient vs
+    torch.autograd on the fp32 sub-block with the SAME masks, combined with a DropPath row factor."""
+    dt, tol = torch.float16, 5e-3
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, C, hid, keep = 300, 256, 1024, 0.8
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.2).cuda()
+    dy = torch.randn(M, C, generator=g).cuda()
+    lnw, lnb = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    w1, b1 = (torch.randn(hid, C, generator=g) / C ** 0.5).cuda(), (torch.randn(hid, generator=g) * 0.3).cuda()
+    w2, b2 = (torch.randn(C, hid, generator=g) / hid ** 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    rows = (torch.bernoulli(torch.full((M,), 0.7), generator=g) / 0.7).cuda()
+    m_hid = (torch.bernoulli(torch.full((M, hid), keep), generator=g) / keep).to(dt).cuda()
+    m_out = (torch.bernoulli(torch.full((M, C), keep), generator=g) / keep).cuda()
+    rs = hat_backward._RS(rows, m_out, m_hid)
+    # reference
+    ps = [t.clone().requires_grad_(True) for t in (x, lnw, lnb, w1, b1, w2, b2, gamma)]
+    xr, lw, lb, W1, B1, W2, B2, G = ps
+    h = F.gelu(F.linear(F.layer_norm(xr, (C,), lw, lb, 1e-5), W1, B1)) * m_hid.float()
+    out = xr + rows.view(M, 1) * (G * (F.linear(h, W2, B2) * m_out))
+    out.backward(dy)
+    ref = [t.grad for t in ps]
+    y = hat_backward.mlp_block_forward(x, lnw, lnb, w1, b1, w2, b2, gamma, operand_dtype=dt, row_scale=rs)
+    assert (y - out.detach()).abs().max().item() < tol * out.abs().max().item()
+    grads = hat_backward.MlpGrads.zeros(C, hid, x.device, with_gamma=True)
+    dx = hat_backward.mlp_block_backward(x, dy, lnw, lnb, w1, b1, w2, b2, gamma, grads, operand_dtype=dt, row_scale=rs)
+    torch.cuda.synchronize()
+    got = [dx, grads.ln_w, grads.ln_b, grads.fc1_w, grads.fc1_b, grads.fc2_w, grads.fc2_b, grads.gamma]
+    for name, a, b in zip(["dx", "d ln_w", "d ln_b", "dW1", "db1", "dW2", "db2", "dgamma"], got, ref):
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert torch.isfinite(a).all() and err < tol * scale, f"mlp {name}: {err:.3e} vs {scale:.3e}"
+    # attention sub-block with proj_drop (an output mask) and DropPath
+    nwin, S, heads = 6, 49, 8
+    M2 = nwin * S
+    x2 = (torch.randn(M2, C, generator=g) * 1.2).cuda()
+    dy2 = torch.randn(M2, C, generator=g).cuda()
+    wq, bq = (torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda(), (torch.randn(3 * C, generator=g) * 0.2).cuda()
+    wp, bp = (torch.randn(C, C, generator=g) / C ** 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    bias = (torch.rand(heads, S, S, generator=g) * 4).cuda()
+    rows2 = (torch.bernoulli(torch.full((nwin,), 0.7), generator=g) / 0.7).cuda().repeat_interleave(S)
+    m2 = (torch.bernoulli(torch.full((M2, C), keep), generator=g) / keep).cuda()
+    rs2 = hat_backward._RS(rows2, m2, None)
+    leaves = [t.clone().requires_grad_(True) for t in (x2, lnw, lnb, wq, bq, wp, bp, gamma)]
+    xr, lw, lb, Wq, Bq, Wp, Bp, G = leaves
+    d = C // heads
+    qkv = F.linear(F.layer_norm(xr, (C,), lw, lb, 1e-5), Wq, Bq).view(nwin, S, 3, heads, d).permute(2, 0, 3, 1, 4)
+    att = ((qkv[0] @ qkv[1].transpose(-1, -2)) * d ** -0.5 + bias).softmax(-1)
+    o = (att @ qkv[2]).transpose(1, 2).reshape(M2, C)
+    out2 = xr + rows2.view(M2, 1) * (G * (F.linear(o, Wp, Bp) * m2))
+    out2.backward(dy2)
+    y2 = hat_backward.attn_block_forward(x2, lnw, lnb, wq, bq, wp, bp, gamma, bias, heads, S, operand_dtype=dt, row_scale=rs2)
+    assert (y2 - out2.detach()).abs().max().item() < tol * out2.abs().max().item()
+    ag = hat_backward.AttnGrads.zeros(C, heads, S, x2.device, with_gamma=True)
+    dx2 = hat_backward.attn_block_backward(x2, dy2, lnw, lnb, wq, bq, wp, bp, gamma, bias, heads, S, ag, operand_dtype=dt, row_scale=rs2)
+    torch.cuda.synchronize()
+    for name, a, b in zip(["dx", "d ln_w", "d ln_b", "dWqkv", "dbqkv", "dWproj", "dbproj", "dgamma"],
+                          [dx2, ag.ln_w, ag.ln_b, ag.qkv_w, ag.qkv_b, ag.proj_w, ag.proj_b, ag.gamma], [t.grad for t in leaves]):
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert torch.isfinite(a).all() and err < 1.5 * tol * scale, f"attn {name}: {err:.3e} vs {scale:.3e}"
+
+
+def test_training_with_drop_rate_runs_and_attn_drop_is_refused():
+    """``drop_rate`` > 0 (Mlp.drop + proj_drop inside the HAT blocks) trains end to end: finite gradients for every parameter, different draws step to step, the
+    loss falls on a fixed batch; ``attn_drop_rate`` > 0 raises at forward time with the reason (not built: Dropout on P inside the attention kernel)."""
+    import fastervit_amd
+    torch.manual_seed(0)
+    model = fastervit_amd.create_model("faster_vit_0_224", drop_path_rate=0.1, drop_rate=0.1, num_classes=10).cuda().train()
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0.0)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(8, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 10, (8,), generator=g).cuda()
+    with torch.no_grad():
+        a, b = model(x), model(x)
+    assert not torch.equal(a, b)   # Dropout draws differ call to call
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(model(x), y)
+        loss.backward()
+        assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
+        opt.step()
+        losses.append(loss.item())
+    print("training losses with drop_rate 0.1:", [round(v, 4) for v in losses])
+    assert losses[-1] < 0.85 * losses[0], losses
+    bad = fastervit_amd.create_model("faster_vit_0_224", attn_drop_rate=0.1, num_classes=10).cuda().train()
+    with pytest.raises(RuntimeError, match="attn_drop"):
+        bad(x)
