@@ -657,6 +657,17 @@ int fvit_window_attention(int32_t operand_dtype, const void* qkv, int32_t ldq, v
     return launch_attention(a, (hipStream_t)stream);
 }
 
+int fvit_window_attention_drop(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, const float* bias, int32_t nwin, int32_t S,
+                               int32_t heads, int32_t dpad, float scale, const void* drop_mask, fvit_stream_t stream) {
+    if (!attention_dense(S, dpad)) {
+        set_error("window_attention_drop: S=%d at dpad=%d is outside the dense-bias kernel", S, dpad);
+        return FVIT_EINVAL;
+    }
+    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, bias, nwin, S, heads, dpad, scale, nullptr, 0, 0, 0};
+    a.drop_mask = drop_mask;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
 int fvit_window_attention_long(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, const float* rel_table,
                                int32_t rel_w, int32_t rel_ng, int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale,
                                fvit_stream_t stream) {

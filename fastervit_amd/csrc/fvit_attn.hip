@@ -35,6 +35,7 @@ struct AttnParams {
     int nwin, S, heads;
     float scale;
     int q_lo_off, o_lo_off;   // TT instances: column offset (elements) of the lo image inside a qkv row / an output row
+    const void* drop;         // attn_drop mask op16 [item][S][SP] (0 or 1 / keep) applied to the probabilities AFTER the softmax sum, or null
 };
 
 // SB: number of 16-token blocks (Spad / 16); DP: padded head dim (32, 64 or 96)
@@ -178,6 +179,16 @@ __global__ __launch_bounds__(TT ? 128 : 256) void attn_kernel(AttnParams p) {
         }
         sum = sum_xor32(sum_xor16(sum));
         const float inv = 1.0f / sum;
+        if (p.drop) {   // attn_drop (train mode): P <- P . mask after the normalisation constant is fixed (FV:563-564: softmax, then Dropout)
+            typedef typename Op16<T>::v4 v4;
+            const T* dm = (const T*)p.drop + ((size_t)item * S + min(qi, S - 1)) * SP + g * 4;
+#pragma unroll
+            for (int jb = 0; jb < SB; ++jb) {
+                const v4 m = *(const v4*)(dm + jb * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[jb][r] *= (float)m[r];
+            }
+        }
 
         // O^T[dim][q] = V^T . P^T
         f4 o[DB];
@@ -296,6 +307,8 @@ int launch_attention(const AttnCall& c, hipStream_t stream) {
     p.qkv = c.qkv; p.out = c.out; p.bias = c.bias; p.ldq = c.ldq; p.ldo = c.ldo;
     p.nwin = c.nwin; p.S = c.S; p.heads = c.heads; p.scale = c.scale;
     p.q_lo_off = c.q_lo_off; p.o_lo_off = c.o_lo_off;
+    p.drop = c.drop_mask;
+    if (c.drop_mask && tt) { set_error("attention: an attn_drop mask with two-term activations is not supported"); return FVIT_EINVAL; }
     // algorithmic FLOPs count the real head_dim (49 of FasterViT-4 runs on dpad = 64; padding work is not credited)
     const double flops = 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * (c.d > 0 && c.d <= c.dpad ? c.d : c.dpad);
     const double bytes = 2.0 * c.nwin * (double)c.S * c.heads * c.dpad * 4.0;  // q,k,v read + o write (16-bit)

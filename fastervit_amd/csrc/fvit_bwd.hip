@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const T* __restrict__ in,
 // training path's correctness reference, not a tuned kernel (2 MFLOP per workgroup).
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, int ld, const T* __restrict__ dO, int ldo, const float* __restrict__ bias,
-                                                        int spad, float scale, T* __restrict__ dqkv, float* __restrict__ dbias_part, int S, int heads) {
+                                                        int spad, float scale, T* __restrict__ dqkv, float* __restrict__ dbias_part, int S, int heads,
+                                                        const T* __restrict__ drop = nullptr) {
+    // drop (train mode, r05): attn_drop mask op16 [win * heads + h][S][spad] (0 or 1 / keep).  O = (P . M) V:  dP = (dO V^T) . M,  dV = (P . M)^T dO
     constexpr int SM = 64;
     __shared__ float q[SM][D + 1], k[SM][D + 1], v[SM][D + 1], g[SM][D + 1];   // g = dO
     __shared__ float P[SM][SM + 1], dS[SM][SM + 1];
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
             dp += g[i][d] * v[j][d];
         }
         P[i][j] = sc * scale + (bias ? bias[((size_t)h * spad + i) * spad + j] : 0.f);
-        dS[i][j] = dp;
+        dS[i][j] = drop ? dp * (float)drop[((size_t)blockIdx.x * S + i) * spad + j] : dp;
     }
     __syncthreads();
     // softmax per row (thread per row), then rowsum(dP * P)
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         for (int j = 0; j < S; ++j) {
             dq += dS[r][j] * k[j][d];
             dk += dS[j][r] * q[j][d];
-            dv += P[j][r] * g[j][d];
+            dv += (drop ? P[j][r] * (float)drop[((size_t)blockIdx.x * S + j) * spad + r] : P[j][r]) * g[j][d];
         }
         T* pw = dqkv + (row0 + r) * ld + h * D + d;
         pw[0] = (T)(dq * scale);
@@ -281,14 +283,25 @@ int fvit_bwd_colsum16(int32_t dtype, const void* in, int32_t ld, float* part, in
     return check_launch("colsum16_kernel");
 }
 
+int fvit_bwd_window_attention_drop(int32_t dtype, const void* qkv, int32_t ld, const void* dO, int32_t ldo, const float* bias, int32_t spad, float scale,
+                                   void* dqkv, float* dbias_part, int32_t nwin, int32_t S, int32_t heads, int32_t D, const void* drop_mask,
+                                   fvit_stream_t stream);
+
 int fvit_bwd_window_attention(int32_t dtype, const void* qkv, int32_t ld, const void* dO, int32_t ldo, const float* bias, int32_t spad, float scale,
                               void* dqkv, float* dbias_part, int32_t nwin, int32_t S, int32_t heads, int32_t D, fvit_stream_t stream) {
+    return fvit_bwd_window_attention_drop(dtype, qkv, ld, dO, ldo, bias, spad, scale, dqkv, dbias_part, nwin, S, heads, D, nullptr, stream);
+}
+
+int fvit_bwd_window_attention_drop(int32_t dtype, const void* qkv, int32_t ld, const void* dO, int32_t ldo, const float* bias, int32_t spad, float scale,
+                                   void* dqkv, float* dbias_part, int32_t nwin, int32_t S, int32_t heads, int32_t D, const void* drop_mask,
+                                   fvit_stream_t stream) {
+    if (drop_mask && spad < S) { set_error("bwd_window_attention: the attn_drop mask is [nwin * heads][S][spad], spad >= S"); return FVIT_EINVAL; }
     if (!qkv || !dO || !dqkv || nwin <= 0 || S < 1 || S > 64 || heads <= 0 || (D != 32 && D != 64 && D != 96) || ld < 3 * heads * D || ldo < heads * D || (bias && spad < S)) {
         set_error("bwd_window_attention: unsupported arguments nwin=%d S=%d heads=%d D=%d (need S <= 64, padded head_dim 32 / 64 / 96)", nwin, S, heads, D);
         return FVIT_EINVAL;
     }
     const dim3 grid(nwin * heads);
-#define FVIT_ATTN_BWD(T_, D_) hipLaunchKernelGGL((attn_bwd_kernel<T_, D_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)qkv, ld, (const T_*)dO, ldo, bias, spad, scale, (T_*)dqkv, dbias_part, S, heads)
+#define FVIT_ATTN_BWD(T_, D_) hipLaunchKernelGGL((attn_bwd_kernel<T_, D_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)qkv, ld, (const T_*)dO, ldo, bias, spad, scale, (T_*)dqkv, dbias_part, S, heads, (const T_*)drop_mask)
 #define FVIT_ATTN_BWD_D(T_) do { if (D == 32) FVIT_ATTN_BWD(T_, 32); else if (D == 64) FVIT_ATTN_BWD(T_, 64); else FVIT_ATTN_BWD(T_, 96); } while (0)
     if (dtype == FVIT_F16) FVIT_ATTN_BWD_D(_Float16);
     else if (dtype == FVIT_BF16) FVIT_ATTN_BWD_D(__bf16);

@@ -307,6 +307,8 @@ struct AttnCall {
     // two-term activations (weight_terms 3): qkv rows hold [q|k|v] hi at column 0 and lo at column q_lo_off; scores = qh.kh + qh.kl + ql.kh,
     // P and V as two terms too (P in registers), the output written as hi at column 0 and lo at column o_lo_off.  0 = single terms.
     int q_lo_off = 0, o_lo_off = 0;
+    // train mode (r05): Dropout on the softmax probabilities (WindowAttention.attn_drop, FV:564): op16 [nwin * heads][S][Spad], 0 or 1 / keep; null = none
+    const void* drop_mask = nullptr;
 };
 bool attention_dense(int S, int dpad);                               // in-register kernel + dense bias table, else the long kernel
 int launch_attention(const AttnCall& c, hipStream_t stream);        // dispatches on attention_dense(S, dpad)

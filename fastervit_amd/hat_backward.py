@@ -117,24 +117,30 @@ class _RS:
     """What scales a sub-block's residual update in TRAIN mode: ``rows`` fp32 [M] = DropPath (one factor per window / image, repeated per row), ``out`` fp32
     [M][C] = the Dropout mask of the sub-block's OUTPUT (0 or 1 / keep: ``Mlp.drop`` after fc2, FV:406; ``WindowAttention.proj_drop``, FV:567), ``hid``
     operand-dtype [M][hidden] = the Dropout mask of GELU(fc1) (``Mlp.drop`` after the activation, FV:404).  y = x + rows * out * gamma * f(x): the output mask is
-    an elementwise form of the DropPath factor, so forward and backward treat the two alike; ``hid`` multiplies the hidden activation (and dh in the backward)."""
-    __slots__ = ("rows", "out", "hid")
+    an elementwise form of the DropPath factor, so forward and backward treat the two alike; ``hid`` multiplies the hidden activation (and dh in the backward);
+    ``attn`` operand-dtype [windows * heads][S][Spad] = the Dropout mask of the softmax probabilities (``WindowAttention.attn_drop``, FV:564), applied inside the
+    attention kernels (fvit_window_attention_drop / fvit_bwd_window_attention_drop)."""
+    __slots__ = ("rows", "out", "hid", "attn")
 
-    def __init__(self, rows=None, out=None, hid=None):
-        self.rows, self.out, self.hid = rows, out, hid
+    def __init__(self, rows=None, out=None, hid=None, attn=None):
+        self.rows, self.out, self.hid, self.attn = rows, out, hid, attn
 
 
-def _rows(scale, group: int, out=None, hid=None):
+def _rows(scale, group: int, out=None, hid=None, attn=None):
     """Per-group DropPath factors (one per window / per image) -> one per row; with Dropout masks an ``_RS``."""
     rows = None if scale is None else scale.repeat_interleave(group)
-    if out is None and hid is None:
+    if out is None and hid is None and attn is None:
         return rows
-    return _RS(rows, out, hid)
+    return _RS(rows, out, hid, attn)
 
 
 def _rs(mk: Optional[dict], key: str, group: int):
     mk = mk or {}
-    return _rows(mk.get(key), group, mk.get(key + "_out"), mk.get(key + "_hid"))
+    return _rows(mk.get(key), group, mk.get(key + "_out"), mk.get(key + "_hid"), mk.get(key + "_p"))
+
+
+def _attn_mask(rs):
+    return rs.attn if isinstance(rs, _RS) else None
 
 
 def _out_scale(rs, M: int) -> Optional[torch.Tensor]:
@@ -322,7 +328,8 @@ def attn_block_backward(x: torch.Tensor, dy: torch.Tensor, ln_w: torch.Tensor, l
         ck(lib.fvit_gather_layernorm(code, x.data_ptr(), M, None, 0, None, None, None, None, xn.data_ptr(), Ck, ln_w.data_ptr(), ln_b.data_ptr(),
                                      C.c_float(eps), M, M, C_, st), "layernorm")
         ck(lib.fvit_gemm_bias_act(code, xn.data_ptr(), Ck, Wq.data_ptr(), Ck, bq.data_ptr(), qkv.data_ptr(), Kq, M, C3p, Ck, 0, st), "qkv")
-        ck(lib.fvit_window_attention(code, qkv.data_ptr(), Kq, o.data_ptr(), Kao, p(btab), nwin, S, heads, dp, C.c_float(scale), st), "attention")
+        pmask = _attn_mask(row_scale)
+        ck(lib.fvit_window_attention_drop(code, qkv.data_ptr(), Kq, o.data_ptr(), Kao, p(btab), nwin, S, heads, dp, C.c_float(scale), p(pmask), st), "attention")
         ck(lib.fvit_gemm_bias_act(code, o.data_ptr(), Kao, Wp.data_ptr(), Kao, bp.data_ptr(), z.data_ptr(), C_, M, C_, Kao, 0, st), "proj")
         # ---- gamma, proj bias, dz = gamma * dy ----
         ck(lib.fvit_bwd_scale_cols(code, dyi.data_ptr(), z.data_ptr(), C_, p(g), dz.data_ptr(), Ck, part.data_ptr(), M, C_, st), "scale_cols")
@@ -335,8 +342,8 @@ def attn_block_backward(x: torch.Tensor, dy: torch.Tensor, ln_w: torch.Tensor, l
         ck(lib.fvit_bwd_transpose16(code, o.data_ptr(), Kao, oT.data_ptr(), Mk, M, Kao, st), "O^T")
         ck(lib.fvit_gemm_residual(code, dzT.data_ptr(), Mk, oT.data_ptr(), Mk, None, None, gp_w.data_ptr(), Kao, C_, Kao, Mk, st), "dWproj")
         # ---- attention core ----
-        ck(lib.fvit_bwd_window_attention(code, qkv.data_ptr(), Kq, do.data_ptr(), Kao, p(btab), spad, C.c_float(scale), dqkv.data_ptr(), p(dbias_part),
-                                         nwin, S, heads, dp, st), "attention_bwd")
+        ck(lib.fvit_bwd_window_attention_drop(code, qkv.data_ptr(), Kq, do.data_ptr(), Kao, p(btab), spad, C.c_float(scale), dqkv.data_ptr(), p(dbias_part),
+                                              nwin, S, heads, dp, p(pmask), st), "attention_bwd")
         if grads.bias is not None:
             ck(lib.fvit_bwd_colsum_finish(dbias_part.data_ptr(), nwin, heads * S * S, grads.bias.data_ptr(), heads * S * S, 1, st), "dbias")
         # ---- qkv: bias, dWqkv += dqkv^T xn, dxn = dqkv Wqkv ----
@@ -397,7 +404,9 @@ def attn_block_forward(x: torch.Tensor, ln_w, ln_b, qkv_w, qkv_b, proj_w, proj_b
         ck(lib.fvit_gather_layernorm(code, x.data_ptr(), M, None, 0, None, None, None, None, xn.data_ptr(), Ck, lw.data_ptr(), lb.data_ptr(),
                                      C.c_float(eps), M, M, C_, st), "layernorm")
         ck(lib.fvit_gemm_bias_act(code, xn.data_ptr(), Ck, Wq.data_ptr(), Ck, bq.data_ptr(), qkv.data_ptr(), Kq, M, C3p, Ck, 0, st), "qkv")
-        ck(lib.fvit_window_attention(code, qkv.data_ptr(), Kq, o.data_ptr(), Kao, btab.data_ptr(), nwin, S, heads, dp, C.c_float(scale), st), "attention")
+        pm = _attn_mask(row_scale)
+        ck(lib.fvit_window_attention_drop(code, qkv.data_ptr(), Kq, o.data_ptr(), Kao, btab.data_ptr(), nwin, S, heads, dp, C.c_float(scale),
+                                          None if pm is None else pm.data_ptr(), st), "attention")
         ck(lib.fvit_gemm_residual(code, o.data_ptr(), Kao, Wp.data_ptr(), Kao, bp.data_ptr(), None if g is None else g.data_ptr(), y.data_ptr(), C_,
                                   M, C_, Kao, st), "proj")
     return _lerp_rows(x, y, row_scale)
@@ -627,7 +636,8 @@ def drop_path_masks(layer, batch: int, windows_per_image: int, device, generator
         the window branch (x is (B nW, S, C)), per IMAGE for the carrier branch): entries ``attn`` / ``mlp`` / ``hat_attn`` / ``hat_mlp``, None where p = 0;
       * Dropout inside the blocks (r05; ``drop_rate`` of the entrypoints -> ``Mlp.drop`` after GELU and after fc2, FV:404-406, and ``WindowAttention.proj_drop``,
         FV:567): elementwise masks ``<key>_out`` fp32 [rows][C] and ``mlp_hid`` / ``hat_mlp_hid`` operand-dtype [rows][hidden], values 0 or 1 / keep, only where p > 0
-        (``attn_drop`` > 0 -- Dropout on the softmax probabilities inside the attention kernel -- is not implemented: ``backward_unsupported_reason``)."""
+        and ``attn_p`` / ``hat_attn_p`` operand-dtype [windows * heads][S][Spad] for ``WindowAttention.attn_drop`` (FV:564: Dropout on the softmax probabilities,
+        applied inside the attention kernels)."""
     out = []
     for blk in layer.blocks:
         def draw(n, mod):
@@ -647,13 +657,26 @@ def drop_path_masks(layer, batch: int, windows_per_image: int, device, generator
         C_, hid = blk.attn.qkv.in_features, blk.mlp.fc1.out_features
         ncw = blk.cr_window ** 2 if blk.do_sr_hat else 0
         rows = batch * windows_per_image * (blk.window_size ** 2 + ncw)
+        lib = _lib.lib()
+        S_ = blk.window_size ** 2 + ncw
+        heads = blk.attn.num_heads
+
+        def pmask(items, S, mod):   # [items][S][Spad]: the attention kernels index the key axis at the padded stride
+            p_ = float(getattr(mod, "p", 0.0) or 0.0)
+            if p_ <= 0.0:
+                return None
+            keep = 1.0 - p_
+            return (torch.empty(items, S, lib.fvit_attention_spad(S), dtype=torch.float32, device=device).bernoulli_(keep, generator=generator) / keep).to(operand_dtype)
+
         m = dict(attn=draw(batch * windows_per_image, blk.drop_path), mlp=draw(batch * windows_per_image, blk.drop_path),
-                 attn_out=elem(rows, C_, blk.attn.proj_drop), mlp_out=elem(rows, C_, blk.mlp.drop), mlp_hid=elem(rows, hid, blk.mlp.drop, operand_dtype))
+                 attn_out=elem(rows, C_, blk.attn.proj_drop), mlp_out=elem(rows, C_, blk.mlp.drop), mlp_hid=elem(rows, hid, blk.mlp.drop, operand_dtype),
+                 attn_p=pmask(batch * windows_per_image * heads, S_, blk.attn.attn_drop))
         if blk.do_sr_hat:
             crow = batch * windows_per_image * ncw
             m.update(hat_attn=draw(batch, blk.hat_drop_path), hat_mlp=draw(batch, blk.hat_drop_path),
                      hat_attn_out=elem(crow, C_, blk.hat_attn.proj_drop), hat_mlp_out=elem(crow, C_, blk.hat_mlp.drop),
-                     hat_mlp_hid=elem(crow, hid, blk.hat_mlp.drop, operand_dtype))
+                     hat_mlp_hid=elem(crow, hid, blk.hat_mlp.drop, operand_dtype),
+                     hat_attn_p=pmask(batch * heads, windows_per_image * ncw, blk.hat_attn.attn_drop))
         out.append(m)
     return out
 
@@ -918,9 +941,6 @@ def backward_unsupported_reason(layer, H: Optional[int] = None, W: Optional[int]
             return f"{ncw * sr[0] * sr[1]} carrier tokens per image (at most 64)"
         if H is not None and (-(-H // ws), -(-W // ws)) != sr:
             return f"map {H}x{W} does not pad into the stage's {sr[0]}x{sr[1]} windows of {ws}"
-    if layer.training and any(float(getattr(b.attn.attn_drop, "p", 0.0)) > 0 or (hier and float(getattr(b.hat_attn.attn_drop, "p", 0.0)) > 0) for b in blocks):
-        return ("attn_drop > 0 in train mode: Dropout on the softmax probabilities inside the attention kernel is not implemented (drop_rate -- Mlp.drop and "
-                "proj_drop -- and stochastic depth are)")
     return None
 
 

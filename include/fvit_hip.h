@@ -266,6 +266,10 @@ int fvit_gather_layernorm_terms(int32_t operand_dtype, const float* srcA, int32_
 int fvit_window_attention(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo,
                           const float* bias, int32_t nwin, int32_t S, int32_t heads, int32_t dpad,
                           float scale, fvit_stream_t stream);
+/* fvit_window_attention with Dropout on the probabilities (TRAIN mode, r05; WindowAttention.attn_drop, FV:563-564: softmax, then Dropout, then . v):
+ * drop_mask op16 [nwin * heads][S][spad] (spad = fvit_attention_spad(S)), entries 0 or 1 / keep, applied after the softmax normalisation; NULL = none. */
+int fvit_window_attention_drop(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo, const float* bias, int32_t nwin, int32_t S,
+                               int32_t heads, int32_t dpad, float scale, const void* drop_mask, fvit_stream_t stream);
 /* Same contract for windows of more than FVIT_MAX_DENSE_SEQ tokens (any S >= 1 is accepted): online softmax over key tiles,
  * bias from the compact table rel_table f32 [heads][(2*rel_w-1)^2] (NULL = no bias) with rel_ng + rel_w^2 == S, see FvitAttnWeights. */
 int fvit_window_attention_long(int32_t operand_dtype, const void* qkv, int32_t ldq, void* out, int32_t ldo,
@@ -499,6 +503,10 @@ int fvit_bwd_colsum16(int32_t operand_dtype, const void* in, int32_t ld, float* 
  * qkv layout, 32 / 64 / 96 (pad channels are zero and receive zero gradients). */
 int fvit_bwd_window_attention(int32_t operand_dtype, const void* qkv, int32_t ld, const void* dO, int32_t ldo, const float* bias, int32_t spad,
                               float scale, void* dqkv, float* dbias_part, int32_t nwin, int32_t S, int32_t heads, int32_t D, fvit_stream_t stream);
+/* ... with the attn_drop mask of the forward (fvit_window_attention_drop): dP = (dO V^T) . mask, dV = (P . mask)^T dO. */
+int fvit_bwd_window_attention_drop(int32_t operand_dtype, const void* qkv, int32_t ld, const void* dO, int32_t ldo, const float* bias, int32_t spad,
+                                   float scale, void* dqkv, float* dbias_part, int32_t nwin, int32_t S, int32_t heads, int32_t D, const void* drop_mask,
+                                   fvit_stream_t stream);
 /* out[i] (+)= sum over b < blocks of part[b * stride + i], i < n, in block order. */
 int fvit_bwd_colsum_finish(const float* part, int32_t blocks, int32_t stride, float* out, int32_t n, int32_t accumulate, fvit_stream_t stream);
 

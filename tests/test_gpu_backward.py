@@ -728,12 +728,16 @@ def test_dropout_masks_in_the_sub_blocks_vs_autograd():
     bias = (torch.rand(heads, S, S, generator=g) * 4).cuda()
     rows2 = (torch.bernoulli(torch.full((nwin,), 0.7), generator=g) / 0.7).cuda().repeat_interleave(S)
     m2 = (torch.bernoulli(torch.full((M2, C), keep), generator=g) / keep).cuda()
-    rs2 = hat_backward._RS(rows2, m2, None)
+    spad = _lib.lib().fvit_attention_spad(S)
+    mp = torch.zeros(nwin * heads, S, spad)
+    mp[:, :, :S] = torch.bernoulli(torch.full((nwin * heads, S, S), keep), generator=g) / keep      # attn_drop: Dropout on the softmax probabilities
+    mp = mp.to(dt).cuda()
+    rs2 = hat_backward._RS(rows2, m2, None, mp)
     leaves = [t.clone().requires_grad_(True) for t in (x2, lnw, lnb, wq, bq, wp, bp, gamma)]
     xr, lw, lb, Wq, Bq, Wp, Bp, G = leaves
     d = C // heads
     qkv = F.linear(F.layer_norm(xr, (C,), lw, lb, 1e-5), Wq, Bq).view(nwin, S, 3, heads, d).permute(2, 0, 3, 1, 4)
-    att = ((qkv[0] @ qkv[1].transpose(-1, -2)) * d ** -0.5 + bias).softmax(-1)
+    att = ((qkv[0] @ qkv[1].transpose(-1, -2)) * d ** -0.5 + bias).softmax(-1) * mp[:, :, :S].float().view(nwin, heads, S, S)
     o = (att @ qkv[2]).transpose(1, 2).reshape(M2, C)
     out2 = xr + rows2.view(M2, 1) * (G * (F.linear(o, Wp, Bp) * m2))
     out2.backward(dy2)
@@ -748,12 +752,12 @@ def test_dropout_masks_in_the_sub_blocks_vs_autograd():
         assert torch.isfinite(a).all() and err < 1.5 * tol * scale, f"attn {name}: {err:.3e} vs {scale:.3e}"
 
 
-def test_training_with_drop_rate_runs_and_attn_drop_is_refused():
-    """``drop_rate`` > 0 (Mlp.drop + proj_drop inside the HAT blocks) trains end to end: finite gradients for every parameter, different draws step to step, the
-    loss falls on a fixed batch; ``attn_drop_rate`` > 0 raises at forward time with the reason (not built: Dropout on P inside the attention kernel)."""
+def test_training_with_drop_rate_and_attn_drop_rate_runs():
+    """``drop_rate`` > 0 (Mlp.drop + proj_drop) and ``attn_drop_rate`` > 0 (Dropout on the softmax probabilities, inside the attention kernels) train end to
+    end: finite gradients for every parameter, different draws call to call, the loss falls on a fixed batch."""
     import fastervit_amd
     torch.manual_seed(0)
-    model = fastervit_amd.create_model("faster_vit_0_224", drop_path_rate=0.1, drop_rate=0.1, num_classes=10).cuda().train()
+    model = fastervit_amd.create_model("faster_vit_0_224", drop_path_rate=0.1, drop_rate=0.1, attn_drop_rate=0.1, num_classes=10).cuda().train()
     opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0.0)
     g = torch.Generator(device="cpu").manual_seed(1)
     x = torch.randn(8, 3, 224, 224, generator=g).cuda()
@@ -769,8 +773,9 @@ def test_training_with_drop_rate_runs_and_attn_drop_is_refused():
         assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
         opt.step()
         losses.append(loss.item())
-    print("training losses with drop_rate 0.1:", [round(v, 4) for v in losses])
+    print("training losses with drop_rate 0.1, attn_drop_rate 0.1:", [round(v, 4) for v in losses])
     assert losses[-1] < 0.85 * losses[0], losses
-    bad = fastervit_amd.create_model("faster_vit_0_224", attn_drop_rate=0.1, num_classes=10).cuda().train()
-    with pytest.raises(RuntimeError, match="attn_drop"):
-        bad(x)
+    model.eval()
+    with torch.no_grad():
+        a, b = model(x), model(x)
+    assert torch.equal(a, b)   # eval mode: no Dropout
