@@ -778,4 +778,4 @@ def test_training_with_drop_rate_and_attn_drop_rate_runs():
     model.eval()
     with torch.no_grad():
         a, b = model(x), model(x)
-    assert torch.equal(a, b)   # eval mode: no Dropout
+    assert (a - b).abs().max().item() < 1e-3 * a.abs().max().item()   # eval mode: no Dropout (MIOpen's fp32 convs are not bitwise repeatable call to call)
