@@ -581,7 +581,7 @@ def compact_line(out, detail_path=None):
     if cb and cb.get("batch_64"):
         c["cpu_baseline"]["batch_64_images_per_s"] = cb["batch_64"]["value"]
     c["parity"] = _pick(out.get("parity"), _PAR_KEYS)
-    for m in OPERAND_MODES + tuple(mm + "_down2" for mm in ALL_OPERAND_MODES):
+    for m in OPERAND_MODES + tuple(mm + "_down2" for mm in ALL_OPERAND_MODES) + ("bf16x3_precise",):
         if "parity_" + m in out:
             c["parity_" + m] = _pick(out["parity_" + m], _PAR_KEYS)
     for k in ("hat_ms_per_step", "kernel_ms_per_step_serialized", "launches_per_step"):
@@ -611,7 +611,7 @@ def compact_line(out, detail_path=None):
     c["detail"] = detail_path
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > LINE_BUDGET:   # never let prose grow the line past what the driver's stdout tail holds
-        for k in ("train_step", "secondary", "step_ms", "parity_f16x2", "parity_bf16", "hat_ms_per_step", "kernel_ms_per_step_serialized", "launches_per_step"):
+        for k in ("train_step", "secondary", "step_ms", "parity_bf16x3_precise", "parity_f16x2", "parity_bf16", "hat_ms_per_step", "kernel_ms_per_step_serialized", "launches_per_step"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) <= LINE_BUDGET:
@@ -798,6 +798,26 @@ def main():
             cfg.plan.down_weight_terms, cfg.plan.sig = 1, None
         if cfg.runner is not None:
             cfg.runner.recompile()
+        if cfg.runner is not None and cfg.plan is not None and not args.no_modes and headline:
+            # north_star's "bf16", literally and with margin (r05): the PRECISE conv plan on bf16 planes + HAT operands bf16x3 -- bf16 MFMA operands everywhere, every
+            # stream and weight as two bf16 terms -- in the timed launch structure (its own runner: the plan's plane dtype is fixed at compile time)
+            try:
+                cfg.model.set_hat_operand_dtype("bf16x3")
+                jf = args.join_from if (args.join_from > 0 and cfg.streams > 1) else None
+                rb = cfg.model.compile_inference(cfg.x, dtype=torch.bfloat16, streams=cfg.streams, graph=not args.no_graph, join_from=jf, precise=True)
+                nrep = max(5, args.steps // 4)
+                el = dp.timed_steps((lambda: rb.graph.replay()) if rb.graph is not None else (lambda: rb(cfg.x)), nrep, 2, torch.cuda.synchronize, None, dev)
+                torch.cuda.synchronize()
+                y = rb.static_y.float().cpu()
+                err = (y[idx] - ref_all).abs().max().item()
+                out["parity_bf16x3_precise"] = {"logits_max_abs_err": float(f"{err:.3e}"), "images": len(idx), "meets_1e-3": bool(err < 1e-3),
+                                                "images_per_s": round(args.batch * nrep / el, 1),
+                                                "vs": "CPU oracle fp32, the images of 'parity'; precise conv plan on bf16 planes + HAT operands bf16x3 (bf16 everywhere)"}
+                del rb
+            except Exception as e:
+                out["parity_bf16x3_precise"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            cfg.model.set_hat_operand_dtype(args.operand)
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, arch, args.cpu_seconds)
     out["cpu_baseline"], out["parity"] = cpu, (parity if parity is not None else rank_parity)
