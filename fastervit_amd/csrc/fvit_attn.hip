@@ -104,6 +104,26 @@ __global__ __launch_bounds__(TT ? 128 : 256) void attn_kernel(AttnParams p) {
         }
     }
 
+    // TT: the K lo fragments too, when they fit (r05: SB * KD <= 16 fragments = 64 registers; 7 x 7 windows + 4 carrier tokens at head_dim <= 64 are 4 x 2): they used
+    // to be re-read from L2 inside the query loop for every (query block, key block, k step) -- the kernel ran at wait 0.75, MFMA busy 0.035
+    // (profiles/r05_sq_counters_by_kernel_faster_vit_4_224_precise.json).  Same arithmetic, same order: bitwise the same result.
+    constexpr bool KEEP_KL = TT && SB * KD <= 16;
+    v8 klf[KEEP_KL ? SB : 1][KEEP_KL ? KD : 1];
+    if constexpr (KEEP_KL) {
+#pragma unroll
+        for (int jb = 0; jb < SB; ++jb) {
+            const int key = jb * 16 + s;
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) {
+                v8 val;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
+                if (key < S) val = *(const v8*)(qkv + p.q_lo_off + (size_t)key * p.ldq + HD + kd * 32 + g * 8);
+                klf[jb][kd] = val;
+            }
+        }
+    }
+
     // V^T rows for A-row slot s of output block db: dim = (s>>2)*(DP/4) + db*4 + (s&3)
     const T* vrow[DB];
 #pragma unroll
@@ -148,11 +168,15 @@ __global__ __launch_bounds__(TT ? 128 : 256) void attn_kernel(AttnParams p) {
 #pragma unroll
             for (int kd = 0; kd < KD; ++kd) {
                 if constexpr (TT) {   // the small products first: qh.kl + ql.kh, then qh.kh
-                    const int key = jb * 16 + s;
                     v8 kl;
+                    if constexpr (KEEP_KL) {
+                        kl = klf[jb][kd];
+                    } else {
+                        const int key = jb * 16 + s;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) kl[j] = (T)0.f;
-                    if (key < S) kl = *(const v8*)(qkv + p.q_lo_off + (size_t)key * p.ldq + HD + kd * 32 + g * 8);
+                        for (int j = 0; j < 8; ++j) kl[j] = (T)0.f;
+                        if (key < S) kl = *(const v8*)(qkv + p.q_lo_off + (size_t)key * p.ldq + HD + kd * 32 + g * 8);
+                    }
                     a = Op16<T>::mfma(kl, qf[kd], a);
                     a = Op16<T>::mfma(kf[jb][kd], ql[kd], a);
                 }
