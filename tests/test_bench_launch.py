@@ -102,3 +102,23 @@ def test_one_slow_launch_does_not_flip_the_dominant_kernel():
     e = bench.roofline_entry(dict(dom, avg_launch_us=100.0), "f16", fam_ms)
     if "avg_launch_us_rocprof" in e:
         assert "timer_mismatch" in e and e["event_vs_rocprof"] > 0.25
+
+
+def test_r05_record_compacts_with_the_new_entries():
+    """The committed r05 full record through the live compaction: the secondary entries carry the TIMED precise plan (`parity` absolute, meets_1e-3) with the
+    16-bit plan beside it (`fast`), the bf16-everywhere leg and the training-step entry are in the line, and it still fits the driver's tail."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_final_detail.json")))
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    assert len(line) < bench.LINE_BUDGET and "\n" not in line
+    c = json.loads(line)
+    assert c["config"]["streams"] == 2 and c["config"]["join_from"] == 3
+    assert c["roofline"]["kernel"].startswith("winmlp_kernel<256>") and c["roofline"]["outlier_launches_dropped"] == 0 and "timer_mismatch" not in c["roofline"]
+    assert c["parity"]["logits_max_abs_err"] < 1e-3
+    assert c["parity_bf16x3_precise"]["meets_1e-3"] and c["parity_bf16x3_precise"]["logits_max_abs_err"] < 7.5e-4
+    assert len(c["secondary"]) == 2
+    for s in c["secondary"]:
+        assert s["dtype"] == "f16x3" and s["parity"]["meets_1e-3"] and s["parity"]["logits_max_abs_err"] < 7.5e-4   # absolute, >= 25 % margin
+        assert s["fast"]["value"] > s["value"] and not s["fast"]["meets_1e-3"]
+    assert c["train_step"]["finite"] and c["train_step"]["value"] > 0
+    assert json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_final.json")).read().strip())["value"] == c["value"]
