@@ -13,6 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 DIAG = os.environ.get("FVIT_DIAG", "0") == "1"   # diagnosis build (scripts/timeline_*.py, scripts/poison_check.py, the poison test's subprocess)
 LIB_PATH = os.path.join(CSRC_DIR, "libfvit_hip_diag.so" if DIAG else "libfvit_hip.so")
+# A/B measurements only (scripts/r06_calls): another build of the same ABI, e.g. the previous round's kernels, selected per process
+if os.environ.get("FVIT_LIB_PATH"):
+    LIB_PATH = os.path.abspath(os.environ["FVIT_LIB_PATH"])
 
 FVIT_ABI_VERSION = 7
 FVIT_F32, FVIT_F16, FVIT_BF16 = 0, 1, 2

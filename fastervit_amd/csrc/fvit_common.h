@@ -131,9 +131,123 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return hx * (z * q) + hx;
 }
 
+// gelu_fast over N values at once, every Horner step issued for all N values before the next step (r06).  The per-value form above compiles to
+// ONE dependent chain of 15 VALU instructions per value and hipcc emits the values one after the other: the fused MLP kernels ran 32 such chains
+// back to back per super-chunk (r05 ISA: 224 v_fmaak + 32 v_fmamk in strict dependence, ~3.5 issue cycles each instead of 2).  Source order alone
+// does not survive (the DAG scheduler re-serialises the chains into the register-minimal order, and __builtin_amdgcn_sched_barrier has no data
+// edge to them: r06 ISA check): an empty asm that takes all N partial results as read-write operands pins every step.  Same operations in the
+// same order per value => bitwise the same results as gelu_fast.
+template <int N>
+__device__ __forceinline__ void pin_values(float (&q)[N]) {
+    static_assert(N == 4 || N == 8, "pin_values: 4 or 8 values");
+    if constexpr (N == 4) asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    else asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]));
+}
+template <int N>
+__device__ __forceinline__ void gelu_fast_n(float (&x)[N]) {
+    float z[N], u[N], q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = __builtin_amdgcn_fmed3f(x[i] * 0.70710678118654752f, -3.0f, 3.0f);
+#pragma unroll
+    for (int i = 0; i < N; ++i) u[i] = z[i] * z[i];
+    pin_values(u);
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = 4.075095461e-08f * u[i] - 1.945139275e-06f;
+#define FVIT_GELU_STEP(c) \
+    pin_values(q);        \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) q[i] = q[i] * u[i] + (c);
+    FVIT_GELU_STEP(4.106515917e-05f)
+    FVIT_GELU_STEP(-5.110726343e-04f)
+    FVIT_GELU_STEP(4.235583358e-03f)
+    FVIT_GELU_STEP(-2.510324307e-02f)
+    FVIT_GELU_STEP(1.110798195e-01f)
+    FVIT_GELU_STEP(-3.753151596e-01f)
+    FVIT_GELU_STEP(1.128268480e+00f)
+#undef FVIT_GELU_STEP
+    pin_values(q);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float hx = 0.5f * x[i];
+        x[i] = hx * (z[i] * q[i]) + hx;
+    }
+}
+
+// M values (a multiple of 4) in groups of 8 (+ one group of 4)
+template <int M>
+__device__ __forceinline__ void gelu_fast_each(float (&x)[M]) {
+    static_assert(M % 4 == 0, "gelu_fast_each: a multiple of 4 values");
+#pragma unroll
+    for (int j = 0; j + 8 <= M; j += 8) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = x[j + i];
+        gelu_fast_n<8>(t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[j + i] = t[i];
+    }
+    if constexpr (M % 8 == 4) {
+        float t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = x[M - 4 + i];
+        gelu_fast_n<4>(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[M - 4 + i] = t[i];
+    }
+}
+
 // the same function through fast_erf (|erf error| <= 1.5e-7): the two-term-activation mode (weight_terms 3) carries ~22 significant
 // bits through every Linear layer, the polynomial above would be its error floor
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+// gelu_erf over N values in lockstep (the two-term-activation epilogues): the same operations per value, the steps pinned like gelu_fast_n
+template <int N>
+__device__ __forceinline__ void gelu_erf_n(float (&x)[N]) {
+    float ax[N], t[N], y[N], e[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) ax[i] = fabsf(x[i] * 0.70710678118654752f);
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = __frcp_rn(1.0f + 0.3275911f * ax[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __expf(-ax[i] * ax[i]);
+    pin_values(t);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = 1.061405429f * t[i] - 1.453152027f;
+    pin_values(y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = y[i] * t[i] + 1.421413741f;
+    pin_values(y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = y[i] * t[i] - 0.284496736f;
+    pin_values(y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = y[i] * t[i] + 0.254829592f;
+    pin_values(y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float r = copysignf(1.0f - y[i] * t[i] * e[i], x[i] * 0.70710678118654752f);
+        x[i] = 0.5f * x[i] * (1.0f + r);
+    }
+}
+template <int M>
+__device__ __forceinline__ void gelu_erf_each(float (&x)[M]) {
+    static_assert(M % 4 == 0, "gelu_erf_each: a multiple of 4 values");
+#pragma unroll
+    for (int j = 0; j + 8 <= M; j += 8) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = x[j + i];
+        gelu_erf_n<8>(t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[j + i] = t[i];
+    }
+    if constexpr (M % 8 == 4) {
+        float t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = x[M - 4 + i];
+        gelu_erf_n<4>(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[M - 4 + i] = t[i];
+    }
+}
 
 __host__ __device__ constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

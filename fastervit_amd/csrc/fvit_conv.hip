@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
                         for (int r = 0; r < 4; ++r) {
                             float v = acc[ni][mi][r] + bias[ni * 4 + r];
                             if (ACT == 1) v = fmaxf(v, 0.f);
-                            else if (ACT == 2) v = gelu_erf(v);
                             y[ni * 4 + r] = v;
                         }
+                    if constexpr (ACT == 2) gelu_erf_each<NC>(y);   // interleaved chains (fvit_common.h), bitwise gelu_erf per value
                     if (R) {
                         const vout rv = *(const vout*)(R + (size_t)m * p.Cout + nb);
 #pragma unroll
@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
                 vout rv;
                 if (RES) rv = rvs[mi];
                 vout ov;
+                float yv[NI * 4];
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const f4 a = acc[ni][mi];
@@ -292,11 +293,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
                     for (int r = 0; r < 4; ++r) {
                         float y = a[r] + bias[ni * 4 + r];
                         if (ACT == 1) y = fmaxf(y, 0.f);
-                        else if (ACT == 2) y = gelu_fast(y);
-                        if (RES) y += (float)rv[ni * 4 + r];
-                        ov[ni * 4 + r] = (T)y;
+                        yv[ni * 4 + r] = y;
                     }
                 }
+                if constexpr (ACT == 2) gelu_fast_each<NI * 4>(yv);   // interleaved Horner chains, bitwise gelu_fast
+#pragma unroll
+                for (int j = 0; j < NI * 4; ++j) ov[j] = (T)(RES ? yv[j] + (float)rv[j] : yv[j]);
                 *(vout*)(O + (size_t)m * p.Cout + nb) = ov;
             }
         }
@@ -597,18 +599,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_halo_kernel(HaloParams p) 
                     v8 rv;
                     if (RES) rv = *(const v8*)(tb + roff + mi * (HALO_TW * 128));
                     v8 ov;
+                    float yv[8];
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
                         const f4 a = acc[ni][mi];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float yv = a[r] + bias[ni * 4 + r];
-                            if (ACT == 1) yv = fmaxf(yv, 0.f);
-                            else if (ACT == 2) yv = gelu_fast(yv);
-                            if (RES) yv += (float)rv[ni * 4 + r];
-                            ov[ni * 4 + r] = (T)yv;
+                            float y = a[r] + bias[ni * 4 + r];
+                            if (ACT == 1) y = fmaxf(y, 0.f);
+                            yv[ni * 4 + r] = y;
                         }
                     }
+                    if constexpr (ACT == 2) {   // interleaved Horner chains, bitwise gelu_fast; groups of 4: eight chains at once spill here (249 registers)
+                        float y0[4] = {yv[0], yv[1], yv[2], yv[3]}, y1[4] = {yv[4], yv[5], yv[6], yv[7]};
+                        gelu_fast_n<4>(y0);
+                        gelu_fast_n<4>(y1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { yv[j] = y0[j]; yv[4 + j] = y1[j]; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ov[j] = (T)(RES ? yv[j] + (float)rv[j] : yv[j]);
                     pk[mi] = ov;
                 }
             });
@@ -829,18 +839,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c128_band_kernel(BandParams p)
 #pragma unroll
             for (int i = 0; i < HB; ++i) {
                 v8 ov;
+                float yv[8];
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const f4 a = acc[ni][h * HB + i];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float yv = a[r] + bias[ni * 4 + r];
-                        if (ACT == 1) yv = fmaxf(yv, 0.f);
-                        else if (ACT == 2) yv = gelu_fast(yv);
-                        if (RES) yv += (float)rv[i][ni * 4 + r];
-                        ov[ni * 4 + r] = (T)yv;
+                        float y = a[r] + bias[ni * 4 + r];
+                        if (ACT == 1) y = fmaxf(y, 0.f);
+                        yv[ni * 4 + r] = y;
                     }
                 }
+                if constexpr (ACT == 2) gelu_fast_n<8>(yv);   // interleaved Horner chains, bitwise gelu_fast
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ov[j] = (T)(RES ? yv[j] + (float)rv[i][j] : yv[j]);
                 if (off[i] >= 0) *(v8*)(O + off[i]) = ov;
             }
             if (h == 0) { FVIT_BD_STAMP(4) }

@@ -347,12 +347,16 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
         }
         const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
         const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
-        v8 pf;
+        float hv[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            pf[r] = sat16<T>(gelu_fast(a1[0][r] + bA[r]));
-            pf[4 + r] = sat16<T>(gelu_fast(a1[1][r] + bB[r]));
+            hv[r] = a1[0][r] + bA[r];
+            hv[4 + r] = a1[1][r] + bB[r];
         }
+        gelu_fast_n<8>(hv);   // eight Horner chains in lockstep, bitwise gelu_fast (fvit_common.h)
+        v8 pf;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pf[r] = sat16<T>(hv[r]);
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -402,9 +406,15 @@ __global__ __launch_bounds__(256, MINB) void ctblk_kernel(CtBlkParams p) {
 // does the first one: the gather is 16 KiB per wave out of L2).  Every wave streams 192 KiB of weights instead of 384 (the same arrays, other
 // fragment addresses), eight rings of three 8-fragment steps are in flight per CU instead of four.
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int WT, int DEPTH, bool TS = false>
+// NIMG (r06): images per workgroup.  One image is ONE 16-row MFMA block: every weight fragment of the 1.5 MB stream feeds one MFMA, and a
+// launch of B workgroups pulls B x 1.5 MB through L2 for 6 % of a block's FLOPs (r05: 0.04 of the MFMA peak, 17.4 MB moved for 5.8 MB,
+// 128 CUs held for 32 us per shard launch).  With NIMG = 2 a fragment feeds two MFMAs (one per image) and the launch needs half the
+// workgroups for about the same duration (the duration is the weight stream through one CU): half the CU x time, which is what the step
+// pays while two stream shards share the chip.  Per-image arithmetic is unchanged (same operations in the same order): bitwise the NIMG = 1 result.
+template <typename T, int WT, int DEPTH, bool TS = false, int NIMG = 1>
 __global__ __launch_bounds__(512, 1) void ctblk8_kernel(CtBlkParams p) {
     typedef typename Op16<T>::v8 v8;
+    static_assert(!TS || NIMG == 1, "timeline instance: one image per workgroup");
     // stamps: 0 entry, 1 rows + constants landed (constants in LDS), first ring steps requested, 3 barrier passed, 2 LayerNorm 1 done, 4 attention done, 5 barrier,
     // 6 proj + residual done, 7 barrier, 8 LayerNorm 2 done, 9 fc1 + GELU done, 10 barrier, 11 fc2 done, 12 end (stores drained)
 #define FVIT_CT8_STAMP(k, dep) if constexpr (TS) { asm volatile("s_nop 0" ::"v"(dep) : "memory"); if ((threadIdx.x & 63) == 0) p.ts[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); }
@@ -413,12 +423,18 @@ __global__ __launch_bounds__(512, 1) void ctblk8_kernel(CtBlkParams p) {
     constexpr int S_QKV = 6 * WT, S_PROJ = 2 * WT, S_FC1 = 8 * WT, S_FC2 = 8 * WT;
     constexpr int T_PROJ = S_QKV, T_FC1 = T_PROJ + S_PROJ, T_FC2 = T_FC1 + S_FC1, NSTEP = T_FC2 + S_FC2;
     constexpr size_t QKV_IMG = (size_t)3 * C * C * 2, PROJ_IMG = (size_t)C * C * 2, FC_IMG = (size_t)C * HID * 2;
-    constexpr int OFF_OT = 0, OFF_H = OFF_OT + 8 * 1024, OFF_CT = OFF_H + 32 * 1024, OFF_B1 = OFF_CT + CB * 1024;
-    constexpr int OFF_BQ = OFF_B1 + HID * 4, OFF_BZ = OFF_BQ + 8 * 96 * 4, OFF_VEC = OFF_BZ + 8 * 256 * 4;
+    // per image: O^T (8 KiB), H^T (32 KiB), ct1 rows (16 KiB); then the constants shared by the images
+    constexpr int OT_B = 8 * 1024, H_B = 32 * 1024, CT_B = CB * 1024;
+    // the constants and the regions every phase touches first, H^T (written and read in ONE phase each) last: DS instructions carry a 16-bit
+    // offset, and with the H^T regions in front every access beyond 64 KiB got its own address register (r06 ISA check: 135 spilled registers
+    // at NIMG = 2).  O^T and H^T go through their own base pointers (smO, smH below).
+    constexpr int OFF_B1 = 0, OFF_BQ = OFF_B1 + HID * 4, OFF_BZ = OFF_BQ + 8 * 96 * 4, OFF_VEC = OFF_BZ + 8 * 256 * 4;
+    constexpr int OFF_CT = OFF_VEC + 8 * C * 4, OFF_OT = OFF_CT + NIMG * CT_B, OFF_H = OFF_OT + NIMG * OT_B, LDS_BYTES = OFF_H + NIMG * H_B;
+    static_assert(OFF_OT <= 65536 && NIMG * OT_B <= 65536 && NIMG * H_B <= 65536, "three bases (constants + ct1 rows, O^T, H^T), 16-bit offsets from each");
     // the eight per-channel vectors of the branch (ln1 w / b, proj bias, gamma1, ln2 w / b, fc2 bias, gamma2; a missing gamma is stored as ones):
     // read from global inside the phases they would queue behind the ring's prefetches in the in-order vmcnt counter and drain it
     // (timeline of the first version: proj + residual 2.9 us for 16 MFMAs, LayerNorm 2 2.5 us)
-    __shared__ __attribute__((aligned(16))) char smem[OFF_VEC + 8 * C * 4];
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     float* b1s = (float*)(smem + OFF_B1);
     float* bqs = (float*)(smem + OFF_BQ);
     float* bzs = (float*)(smem + OFF_BZ);
@@ -429,21 +445,39 @@ __global__ __launch_bounds__(512, 1) void ctblk8_kernel(CtBlkParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, s = lane & 15;
     const int lane16 = lane * 16;
-    const int img = blockIdx.x;
+    char* smH = smem + OFF_H + lane16;          // bases of the H^T / O^T regions (fragment j of image im: + im * H_B + j * 1024), opaque to the compiler so
+    char* smO = smem + OFF_OT + lane16;         // that each is kept as ONE register + immediate offsets instead of smem + a 17-bit constant per access
+    asm volatile("" : "+v"(smH), "+v"(smO));
+    const int img0 = blockIdx.x * NIMG;
     const int tok = s < p.G ? s : p.G - 1;
     const bool row_ok = s < p.G;
 
-    // ---- the rows first (the longest round trip: they come from the memory side), every wave for itself: lane (g, s) holds token s,
-    //      channels (cb>>2)*64 + 16g + (cb&3)*4 .. +3 in v[cb] ----
-    const float* src = p.X + ((size_t)img * p.rowsA + p.src_idx[tok]) * C + g * 16;
+    // ---- the rows first (the longest round trip: they come from the memory side).  r06: wave w gathers only ITS two channel fragments (2w, 2w + 1:
+    //      lane (g, s) = token s, channels (cb>>2)*64 + 16g + (cb&3)*4 .. +3) of every image and parks them in the ct1 region of LDS, from where
+    //      every wave reads the full rows for its LayerNorm after the constants barrier (the second LayerNorm reads the same region the same way).
+    //      r03 had every wave gather all 16 fragments for itself: 64 registers per image next to the ring's first steps, 8 x the gather traffic.
+    //      An image beyond the batch (odd batch, NIMG = 2) recomputes the last one and is not stored ----
     const bool has_add = p.add != nullptr;
-    const float* addp = has_add ? p.add + (size_t)tok * C + g * 16 : src;
-    f4 v[CB];
+    f4 rowq[NIMG][2];
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) v[cb] = *(const f4*)(src + (cb >> 2) * 64 + (cb & 3) * 4);
+    for (int im = 0; im < NIMG; ++im) {
+        const int img = min(img0 + im, p.B - 1);
+        const float* src = p.X + ((size_t)img * p.rowsA + p.src_idx[tok]) * C + g * 16;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cb = 2 * wave + q;
+            rowq[im][q] = *(const f4*)(src + (cb >> 2) * 64 + (cb & 3) * 4);
+        }
+    }
     if (has_add) {   // hat_pos_embed rows (L2): requested here too -- after the barrier they would queue behind the first ring steps
+        const float* addp = p.add + (size_t)tok * C + g * 16;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) v[cb] += *(const f4*)(addp + (cb >> 2) * 64 + (cb & 3) * 4);
+        for (int q = 0; q < 2; ++q) {
+            const int cb = 2 * wave + q;
+            const f4 a = *(const f4*)(addp + (cb >> 2) * 64 + (cb & 3) * 4);
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) rowq[im][q] += a;
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -509,231 +543,279 @@ __global__ __launch_bounds__(512, 1) void ctblk8_kernel(CtBlkParams p) {
         for (int i = 0; i < 4; ++i) bzs[tid + 512 * i] = c3[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) vecs[(2 * i + (tid >> 8)) * C + (tid & 255)] = c4[i];
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *(f4*)(smem + OFF_CT + im * CT_B + (2 * wave + q) * 1024 + lane16) = rowq[im][q];
         FVIT_CT8_STAMP(1, c3[3])
     }
-    __syncthreads();   // constants visible (plain loads in flight survive the barrier)
-    FVIT_CT8_STAMP(3, v[0])
+    __syncthreads();   // constants and gathered rows visible (plain loads in flight survive the barrier)
+    FVIT_CT8_STAMP(3, rowq[0][0])
 
-    auto layernorm = [&](const f4 (&v)[CB], const float* lw, const float* lb, v8 (&xf)[KK]) {
+    // LayerNorm of the 16 rows parked in LDS (fragment cb at rows + cb * 1024, lane-linear) in three streaming passes -- sum, squared deviations,
+    // normalise -- four fragments at a time: the r03 form held all 64 values of a lane in registers next to the ring's steps in flight and the
+    // other image's fragments (250 registers at NIMG = 2).  48 ds_read_b128 per image instead of 16; same operations in the same order.
+    auto layernorm = [&](const char* rows, const float* lw, const float* lb, v8 (&xf)[KK]) {
         float sum = 0.f;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) sum += (v[cb][0] + v[cb][1]) + (v[cb][2] + v[cb][3]);
+        for (int cb = 0; cb < CB; ++cb) {
+            if ((cb & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            const f4 t = *(const f4*)(rows + cb * 1024);
+            sum += (t[0] + t[1]) + (t[2] + t[3]);
+        }
         sum = sum_xor32(sum_xor16(sum));
         const float mean = sum / (float)C;
+        asm volatile("" ::: "memory");   // the next pass RE-READS the rows: without the clobber the three passes' loads are merged and the 64 values stay in registers
         float sq = 0.f;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            const f4 d = v[cb] - mean;
+            if ((cb & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            const f4 d = *(const f4*)(rows + cb * 1024) - mean;
             sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         }
         sq = sum_xor32(sum_xor16(sq));
         const float rstd = rsqrtf(sq / (float)C + p.eps);
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
+            if ((kk & 1) == 0) __builtin_amdgcn_sched_barrier(0);
             v8 o;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int cb = 2 * kk + h2;
                 const int co = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
+                const f4 t = *(const f4*)(rows + cb * 1024);
                 const f4 w = *(const f4*)(lw + co);
                 const f4 b = *(const f4*)(lb + co);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = sat16<T>((v[cb][r] - mean) * rstd * w[r] + b[r]);
+                for (int r = 0; r < 4; ++r) o[h2 * 4 + r] = sat16<T>((t[r] - mean) * rstd * w[r] + b[r]);
             }
             xf[kk] = o;
         }
+        __builtin_amdgcn_sched_barrier(0);
     };
 
-    v8 xf[KK];
-    f4 ct0[2];   // this wave's two channel fragments (2w, 2w + 1) of the gathered rows, for the first residual
-    {
+    v8 xf[NIMG][KK];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {   // cb = 2 * wave + q without dynamic register indexing
-            f4 t = v[q];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) t = wave == w ? v[2 * w + q] : t;
-            ct0[q] = t;
-        }
-        layernorm(v, vecs + 0 * C, vecs + 1 * C, xf);
-    }
-    FVIT_CT8_STAMP(2, xf[KK - 1])
+    for (int im = 0; im < NIMG; ++im) layernorm(smem + OFF_CT + im * CT_B + lane16, vecs + 0 * C, vecs + 1 * C, xf[im]);
+    FVIT_CT8_STAMP(2, xf[NIMG - 1][KK - 1])
 
     // ---- attention of head = wave ----
     {
         const int h = wave;
         const float* bq = bqs + h * 96;
-        v8 qf, kf, vf[2];
+        v8 qf[NIMG], kf[NIMG], vf[NIMG][2];
 #pragma unroll
         for (int ub = 0; ub < 6; ++ub) {
-            f4 a = (f4){0.f, 0.f, 0.f, 0.f}, ao = (f4){0.f, 0.f, 0.f, 0.f};
+            f4 a[NIMG], ao[NIMG];
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) { a[im] = (f4){0.f, 0.f, 0.f, 0.f}; ao[im] = (f4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int term = 0; term < WT; ++term) {
                 const int t = ub * WT + term;
 #pragma unroll
                 for (int kk = 0; kk < KK; kk += 2) {
-                    a = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a) : Op16<T>::mfma(xf[kk], ring[t % DEPTH][kk], a);
-                    ao = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[kk + 1], ao) : Op16<T>::mfma(xf[kk + 1], ring[t % DEPTH][kk + 1], ao);
+#pragma unroll
+                    for (int im = 0; im < NIMG; ++im) {
+                        a[im] = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk], xf[im][kk], a[im]) : Op16<T>::mfma(xf[im][kk], ring[t % DEPTH][kk], a[im]);
+                        ao[im] = ub < 4 ? Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[im][kk + 1], ao[im]) : Op16<T>::mfma(xf[im][kk + 1], ring[t % DEPTH][kk + 1], ao[im]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 FVIT_CT8_LOAD(t + DEPTH)
             }
-            a += ao;
-            if (ub < 4) {
-                const f4 bb = *(const f4*)(bq + (ub >> 1) * 32 + (ub & 1) * 16 + g * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (ub < 2) qf[(ub & 1) * 4 + r] = sat16<T>(a[r] + bb[r]);
-                    else kf[(ub & 1) * 4 + r] = sat16<T>(a[r] + bb[r]);
-                }
-            } else {
-                const float bv = bq[64 + (ub - 4) * 16 + s];
+            for (int im = 0; im < NIMG; ++im) {
+                const f4 aa = a[im] + ao[im];
+                if (ub < 4) {
+                    const f4 bb = *(const f4*)(bq + (ub >> 1) * 32 + (ub & 1) * 16 + g * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    vf[ub - 4][r] = sat16<T>(a[r] + bv);
-                    vf[ub - 4][4 + r] = (T)0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        if (ub < 2) qf[im][(ub & 1) * 4 + r] = sat16<T>(aa[r] + bb[r]);
+                        else kf[im][(ub & 1) * 4 + r] = sat16<T>(aa[r] + bb[r]);
+                    }
+                } else {
+                    const float bv = bq[64 + (ub - 4) * 16 + s];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        vf[im][ub - 4][r] = sat16<T>(aa[r] + bv);
+                        vf[im][ub - 4][4 + r] = (T)0.f;
+                    }
                 }
             }
         }
-        f4 sc = Op16<T>::mfma(kf, qf, (f4){0.f, 0.f, 0.f, 0.f});
         const f4 bz = *(const f4*)(bzs + (h * 16 + tok) * 16 + g * 4);
-        float mx = -3.0e38f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sc[r] = sc[r] * p.scale + bz[r];
-            mx = fmaxf(mx, sc[r]);
+        for (int im = 0; im < NIMG; ++im) {
+            f4 sc = Op16<T>::mfma(kf[im], qf[im], (f4){0.f, 0.f, 0.f, 0.f});
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[r] = sc[r] * p.scale + bz[r];
+                mx = fmaxf(mx, sc[r]);
+            }
+            mx = max_xor32(max_xor16(mx));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[r] = __expf(sc[r] - mx);
+                sum += sc[r];
+            }
+            sum = sum_xor32(sum_xor16(sum));
+            const float inv = 1.0f / sum;
+            v8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (T)sc[r];
+                pf[4 + r] = (T)0.f;
+            }
+            v8 of;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const f4 o = Op16<T>::mfma(vf[im][db], pf, (f4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int r = 0; r < 4; ++r) of[db * 4 + r] = sat16<T>(o[r] * inv);
+            }
+            *(v8*)(smO + im * OT_B + h * 1024) = of;
+            if (im == NIMG - 1) { FVIT_CT8_STAMP(4, of) }
         }
-        mx = max_xor32(max_xor16(mx));
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sc[r] = __expf(sc[r] - mx);
-            sum += sc[r];
-        }
-        sum = sum_xor32(sum_xor16(sum));
-        const float inv = 1.0f / sum;
-        v8 pf;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pf[r] = (T)sc[r];
-            pf[4 + r] = (T)0.f;
-        }
-        v8 of;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            const f4 o = Op16<T>::mfma(vf[db], pf, (f4){0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-            for (int r = 0; r < 4; ++r) of[db * 4 + r] = sat16<T>(o[r] * inv);
-        }
-        *(v8*)(smem + OFF_OT + h * 1024 + lane16) = of;
-        FVIT_CT8_STAMP(4, of)
     }
     __syncthreads();   // O^T of all heads visible
-    FVIT_CT8_STAMP(5, xf[0])
+    FVIT_CT8_STAMP(5, xf[0][0])
 
     // ---- proj over all heads for channel fragments 2w, 2w + 1; ct1 = ct0 + gamma1 * (out + bproj) -> LDS (fp32, lane-linear per fragment) ----
     {
-        f4 oacc[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+        f4 oacc[NIMG][2];
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) { oacc[im][0] = (f4){0.f, 0.f, 0.f, 0.f}; oacc[im][1] = (f4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            v8 ob[4];
+            v8 ob[NIMG][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ob[i] = *(const v8*)(smem + OFF_OT + (4 * half + i) * 1024 + lane16);
+            for (int im = 0; im < NIMG; ++im)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ob[im][i] = *(const v8*)(smO + im * OT_B + (4 * half + i) * 1024);
 #pragma unroll
             for (int term = 0; term < WT; ++term) {
                 const int t = T_PROJ + half * WT + term;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) oacc[i & 1] = Op16<T>::mfma(ring[t % DEPTH][i], ob[i >> 1], oacc[i & 1]);
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int im = 0; im < NIMG; ++im) oacc[im][i & 1] = Op16<T>::mfma(ring[t % DEPTH][i], ob[im][i >> 1], oacc[im][i & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 FVIT_CT8_LOAD(t + DEPTH)
             }
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int cb = 2 * wave + q;
-            const int co = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
-            const f4 bv = *(const f4*)(vecs + 2 * C + co);
-            const f4 gl = *(const f4*)(vecs + 3 * C + co);
-            f4 o = ct0[q];
+        for (int im = 0; im < NIMG; ++im)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] += gl[r] * (oacc[q][r] + bv[r]);
-            *(f4*)(smem + OFF_CT + cb * 1024 + lane16) = o;
-        }
-        FVIT_CT8_STAMP(6, oacc[1])
+            for (int q = 0; q < 2; ++q) {
+                const int cb = 2 * wave + q;
+                const int co = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
+                const f4 bv = *(const f4*)(vecs + 2 * C + co);
+                const f4 gl = *(const f4*)(vecs + 3 * C + co);
+                // the gathered rows ct0 of this fragment are still where this wave parked them: every wave finished reading them for its LayerNorm
+                // before the O^T barrier, and only this wave writes fragment cb
+                f4 o = *(const f4*)(smem + OFF_CT + im * CT_B + cb * 1024 + lane16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += gl[r] * (oacc[im][q][r] + bv[r]);
+                *(f4*)(smem + OFF_CT + im * CT_B + cb * 1024 + lane16) = o;
+            }
+        FVIT_CT8_STAMP(6, oacc[NIMG - 1][1])
     }
     __syncthreads();   // ct1 of all channel fragments visible
-    FVIT_CT8_STAMP(7, xf[0])
+    FVIT_CT8_STAMP(7, xf[0][0])
 
     // ---- second LayerNorm (every wave for itself), fc1 + GELU of hidden chunks 4w .. 4w + 3 -> LDS ----
-    {
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) v[cb] = *(const f4*)(smem + OFF_CT + cb * 1024 + lane16);
-        layernorm(v, vecs + 4 * C, vecs + 5 * C, xf);
-    }
-    FVIT_CT8_STAMP(8, xf[KK - 1])
+    for (int im = 0; im < NIMG; ++im) layernorm(smem + OFF_CT + im * CT_B + lane16, vecs + 4 * C, vecs + 5 * C, xf[im]);
+    FVIT_CT8_STAMP(8, xf[NIMG - 1][KK - 1])
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int j = 4 * wave + c;
-        f4 a1[2];
+        f4 a1[NIMG][2];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
-            f4 a = (f4){0.f, 0.f, 0.f, 0.f}, ao = (f4){0.f, 0.f, 0.f, 0.f};
+            f4 a[NIMG], ao[NIMG];
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) { a[im] = (f4){0.f, 0.f, 0.f, 0.f}; ao[im] = (f4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int term = 0; term < WT; ++term) {
                 const int t = T_FC1 + (2 * c + hb) * WT + term;
 #pragma unroll
                 for (int kk = 0; kk < KK; kk += 2) {
-                    a = Op16<T>::mfma(ring[t % DEPTH][kk], xf[kk], a);
-                    ao = Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[kk + 1], ao);
+#pragma unroll
+                    for (int im = 0; im < NIMG; ++im) {
+                        a[im] = Op16<T>::mfma(ring[t % DEPTH][kk], xf[im][kk], a[im]);
+                        ao[im] = Op16<T>::mfma(ring[t % DEPTH][kk + 1], xf[im][kk + 1], ao[im]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 FVIT_CT8_LOAD(t + DEPTH)
             }
-            a1[hb] = a + ao;
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) a1[im][hb] = a[im] + ao[im];
         }
         const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
         const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
-        v8 pf;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pf[r] = sat16<T>(gelu_fast(a1[0][r] + bA[r]));
-            pf[4 + r] = sat16<T>(gelu_fast(a1[1][r] + bB[r]));
+        for (int im = 0; im < NIMG; ++im) {
+            float hv[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                hv[r] = a1[im][0][r] + bA[r];
+                hv[4 + r] = a1[im][1][r] + bB[r];
+            }
+            gelu_fast_n<8>(hv);   // eight Horner chains in lockstep, bitwise gelu_fast (fvit_common.h)
+            v8 pf;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pf[r] = sat16<T>(hv[r]);
+            *(v8*)(smH + im * H_B + j * 1024) = pf;
+            if (c == 3 && im == NIMG - 1) { FVIT_CT8_STAMP(9, pf) }
         }
-        *(v8*)(smem + OFF_H + j * 1024 + lane16) = pf;
-        if (c == 3) { FVIT_CT8_STAMP(9, pf) }
     }
     __syncthreads();   // H^T of all 32 chunks visible
-    FVIT_CT8_STAMP(10, xf[0])
+    FVIT_CT8_STAMP(10, xf[0][0])
 
     // ---- fc2 over all chunks for channel fragments 2w, 2w + 1; ct2 = ct1 + gamma2 * (out + b2) -> R ----
     {
-        f4 acc2[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+        f4 acc2[NIMG][2];
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) { acc2[im][0] = (f4){0.f, 0.f, 0.f, 0.f}; acc2[im][1] = (f4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            v8 hb4[4];
+            v8 hb4[NIMG][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hb4[i] = *(const v8*)(smem + OFF_H + (4 * q + i) * 1024 + lane16);
+            for (int im = 0; im < NIMG; ++im)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hb4[im][i] = *(const v8*)(smH + im * H_B + (4 * q + i) * 1024);
 #pragma unroll
             for (int term = 0; term < WT; ++term) {
                 const int t = T_FC2 + q * WT + term;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc2[i & 1] = Op16<T>::mfma(ring[t % DEPTH][i], hb4[i >> 1], acc2[i & 1]);
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int im = 0; im < NIMG; ++im) acc2[im][i & 1] = Op16<T>::mfma(ring[t % DEPTH][i], hb4[im][i >> 1], acc2[im][i & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 FVIT_CT8_LOAD(t + DEPTH)
             }
         }
-        FVIT_CT8_STAMP(11, acc2[1])
-        if (row_ok) {
-            float* pr = p.R + ((size_t)img * p.G + s) * C;
+        FVIT_CT8_STAMP(11, acc2[NIMG - 1][1])
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int cb = 2 * wave + q;
-                const int co = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
-                const f4 bv = *(const f4*)(vecs + 6 * C + co);
-                const f4 gl = *(const f4*)(vecs + 7 * C + co);
-                f4 o = *(const f4*)(smem + OFF_CT + cb * 1024 + lane16);
+        for (int im = 0; im < NIMG; ++im) {
+            if (row_ok && img0 + im < p.B) {
+                float* pr = p.R + ((size_t)(img0 + im) * p.G + s) * C;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += gl[r] * (acc2[q][r] + bv[r]);
-                *(f4*)(pr + co) = o;
+                for (int q = 0; q < 2; ++q) {
+                    const int cb = 2 * wave + q;
+                    const int co = (cb >> 2) * 64 + g * 16 + (cb & 3) * 4;
+                    const f4 bv = *(const f4*)(vecs + 6 * C + co);
+                    const f4 gl = *(const f4*)(vecs + 7 * C + co);
+                    f4 o = *(const f4*)(smem + OFF_CT + im * CT_B + cb * 1024 + lane16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += gl[r] * (acc2[im][q][r] + bv[r]);
+                    *(f4*)(pr + co) = o;
+                }
             }
         }
     }
@@ -775,7 +857,23 @@ int launch_ctblk(const CtBlkCall& c, hipStream_t stream) {
     const int variant = tune_get("ct_variant", 3);
     if (c.terms != 1 && c.terms != 2) { set_error("ct_block: weight terms %d (1 or 2)", c.terms); return FVIT_EINVAL; }
     if (variant == 3) {   // the 8-wave form: waves split output channels, no fp32 partial exchange
-        const int depth = tune_get("ct8_depth", 3);   // ring steps of 8 fragments in flight per wave (2 / 3 / 4)
+        // r06: two images per workgroup (fvit_tune "ct_nimg", default 2; 1 = the r03 form): every weight fragment feeds two MFMAs, half the workgroups
+        const int nimg = c.batch >= 2 ? tune_get("ct_nimg", 2) : 1;
+        const int depth = tune_get("ct8_depth", nimg == 2 ? 2 : 3);   // ring steps of 8 fragments in flight per wave (2 / 3 / 4; two images: 2 / 3)
+        if (nimg == 2) {
+            const int grid2 = (c.batch + 1) / 2;
+            prof_note("ctblk8_kernel<256,G16,2img>", grid2);
+#define FVIT_CT8X2(T_, WT_) do { \
+            if (depth == 2) hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 2, false, 2>), dim3(grid2), dim3(512), 0, stream, p); \
+            else hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 3, false, 2>), dim3(grid2), dim3(512), 0, stream, p); } while (0)
+            if (c.dtype == FVIT_F16) {
+                if (c.terms == 2) FVIT_CT8X2(_Float16, 2); else FVIT_CT8X2(_Float16, 1);
+            } else if (c.dtype == FVIT_BF16) {
+                if (c.terms == 2) FVIT_CT8X2(__bf16, 2); else FVIT_CT8X2(__bf16, 1);
+#undef FVIT_CT8X2
+            } else { set_error("ct_block: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
+            return check_launch("ctblk8_kernel");
+        }
 #define FVIT_CT8(T_, WT_) do { \
             if (depth == 2) hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 2>), dim3(c.batch), dim3(512), 0, stream, p); \
             else if (depth == 4) hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 4>), dim3(c.batch), dim3(512), 0, stream, p); \

@@ -346,11 +346,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
                     for (int ni = 0; ni < 4; ++ni) {
                         const f4 a = acc[cg * 4 + ni][mi];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = a[r] + bias[ni * 4 + r];
-                            if (EPI == 1) v = LO ? gelu_erf(v) : gelu_fast(v);
-                            y[ni * 4 + r] = v;
-                        }
+                        for (int r = 0; r < 4; ++r) y[ni * 4 + r] = a[r] + bias[ni * 4 + r];
+                    }
+                    if constexpr (EPI == 1) {   // 16 values as two groups of 8 interleaved chains (fvit_common.h), bitwise the per-value functions
+                        if constexpr (LO) gelu_erf_each<16>(y); else gelu_fast_each<16>(y);
                     }
                     v8 o0, o1;
 #pragma unroll
@@ -565,11 +564,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
                     for (int ni = 0; ni < 4; ++ni) {
                         const f4 a = acc[ni][mi];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = a[r] + bias[ni * 4 + r];
-                            if (EPI == 1) v = LO ? gelu_erf(v) : gelu_fast(v);
-                            y[ni * 4 + r] = v;
-                        }
+                        for (int r = 0; r < 4; ++r) y[ni * 4 + r] = a[r] + bias[ni * 4 + r];
+                    }
+                    if constexpr (EPI == 1) {   // 16 values as two groups of 8 interleaved chains (fvit_common.h), bitwise the per-value functions
+                        if constexpr (LO) gelu_erf_each<16>(y); else gelu_fast_each<16>(y);
                     }
                     v8 o0, o1;
 #pragma unroll

@@ -289,11 +289,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
 #pragma unroll
                 for (int ks = 1; ks < KSPLIT; ++ks) { h0 += acc1[0][rb][ks]; h1 += acc1[1][rb][ks]; }
                 if (TRACE && dq) dq[(size_t)(4 + 5 * it + 1) * 64] = fold4(fold4(0u, h0), h1);
+                float hv[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pf[rb][r] = sat16<T>(gelu_fast(h0[r] + bA[r]));
-                    pf[rb][4 + r] = sat16<T>(gelu_fast(h1[r] + bB[r]));
+                    hv[r] = h0[r] + bA[r];
+                    hv[4 + r] = h1[r] + bB[r];
                 }
+                gelu_fast_n<8>(hv);   // eight Horner chains in lockstep, bitwise gelu_fast (fvit_common.h)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) pf[rb][r] = sat16<T>(hv[r]);
             }
             if (TRACE && dq) dq[(size_t)(4 + 5 * it + 2) * 64] = fold8(0u, pf[0]);
             unsigned hw2 = 0;
@@ -358,12 +362,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void mlp_fused_kernel(MlpParams p) {
             v8 pf[RB];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
+                float hv[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float u0 = acc1[0][rb][r] + bA[r], u1 = acc1[1][rb][r] + bB[r];
-                    pf[rb][r] = sat16<T>(gelu_fast(u0));
-                    pf[rb][4 + r] = sat16<T>(gelu_fast(u1));
+                    hv[r] = acc1[0][rb][r] + bA[r];
+                    hv[4 + r] = acc1[1][rb][r] + bB[r];
                 }
+                gelu_fast_n<8>(hv);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) pf[rb][r] = sat16<T>(hv[r]);
             }
             // ---- GEMM2: OUT^T[channel][row] += W2[channel][chunk units] . H^T ----
 #pragma unroll

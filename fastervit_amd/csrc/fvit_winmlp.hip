@@ -239,12 +239,16 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
         char* hw = smem + OFF_H + (hbuf * NW + wave) * NRB * 1024 + lane16;
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
-            v8 pf;
+            float hv[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pf[r] = sat16<T>(gelu_fast(acc1[0][rb][r] + bA[r]));
-                pf[4 + r] = sat16<T>(gelu_fast(acc1[1][rb][r] + bB[r]));
+                hv[r] = acc1[0][rb][r] + bA[r];
+                hv[4 + r] = acc1[1][rb][r] + bB[r];
             }
+            gelu_fast_n<8>(hv);   // eight independent Horner chains in lockstep (fvit_common.h), bitwise gelu_fast
+            v8 pf;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pf[r] = sat16<T>(hv[r]);
             *(v8*)(hw + rb * 1024) = pf;
         }
         __syncthreads();   // H of this super-chunk visible (HBUF = 2: the other buffer's last readers are past their fc2 of super-chunk sc - 1)

@@ -702,16 +702,21 @@ def test_ct_block_fused(opname, dt, code, batch, G, use_add, use_gamma):
     out = torch.full((batch * G + 3, C), float("nan"), device="cuda")
     scale = d ** -0.5
     p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-    for variant in (0, 1, 2, 3):   # 3: the 8-wave form (waves split output channels)
+    outs8 = {}
+    for variant, nimg in ((0, 1), (1, 1), (2, 1), (3, 1), (3, 2)):   # 3: the 8-wave form (waves split output channels); r06: one or two images per workgroup
         _lib.tune("ct_variant", variant)
+        _lib.tune("ct_nimg", nimg)
         out.fill_(float("nan"))
         rc = lib.fvit_ct_block_fused(code, X.data_ptr(), rowsA, src_idx.data_ptr(), p(add), out.data_ptr(), batch, G, heads, C, hid,
                                      ln1w.data_ptr(), ln1b.data_ptr(), wqf.data_ptr(), bqh.data_ptr(), wpf.data_ptr(), bproj.data_ptr(), p(g1),
                                      bp.data_ptr(), ctypes.c_float(scale), ln2w.data_ptr(), ln2b.data_ptr(), w1f.data_ptr(), b1.data_ptr(),
                                      w2f.data_ptr(), b2.data_ptr(), p(g2), ctypes.c_float(1e-5), _stream())
-        _lib.tune("ct_variant", 3)   # the default
+        _lib.tune("ct_variant", 3)   # the defaults
+        _lib.tune("ct_nimg", 2)
         _lib.check(rc, "ct_block_fused")
         torch.cuda.synchronize()
+        if variant == 3:
+            outs8[nimg] = out[:batch * G].clone()
         ct = X.view(batch, rowsA, C)[:, src_idx.long()]
         if use_add:
             ct = ct + add[None]
@@ -729,7 +734,9 @@ def test_ct_block_fused(opname, dt, code, batch, G, use_add, use_gamma):
         got = out[:batch * G]
         assert torch.isfinite(got).all() and torch.isnan(out[batch * G:]).all()
         tol = (4e-3 if dt == torch.float16 else 3e-2) * ref.abs().max().item()
-        assert (got - ref).abs().max().item() < tol, f"variant {variant}: {(got - ref).abs().max().item()} vs {tol}"
+        assert (got - ref).abs().max().item() < tol, f"variant {variant} x {nimg}: {(got - ref).abs().max().item()} vs {tol}"
+    # two images per workgroup share every weight fragment; per image the operations and their order are those of the one-image form
+    assert torch.equal(outs8[1], outs8[2])
 
 
 @pytest.mark.parametrize("opname,dt,code", OPS)
