@@ -263,7 +263,7 @@ struct NextPe {   // position-embedding rows of the NEXT block, applied in this 
 static bool win_mlp_ok(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t rows) {
     if (d.weight_terms > 2 || !winmlp_supported(d.C, d.hidden) || !w.w_fc1_frag || !w.w_fc2_frag) return false;
     if (d.C == 512) return tune_get("win_mlp", 1) != 0;
-    return rows >= tune_get("mlp_fused_min_rows", 16384) && tune_get("win_mlp256", 2) != 0;   // C = 256: 2 = 4-wave 64-row workgroups, two per CU (default); 1 = 8-wave 128-row
+    return rows >= tune_get("mlp_fused_min_rows", 16384) && tune_get("win_mlp256", 2) != 0;   // C = 256: 4-wave 64-row workgroups, two per CU (0: fvit_mlp_fused's kernel)
 }
 
 static bool mlp_takes_fused_kernel(const FvitStageDesc& d, const FvitMlpWeights& w, int64_t rows) {
@@ -503,28 +503,10 @@ int fvit_hat_stage_forward(const FvitStageDesc* desc, const FvitBlockWeights* bl
     PartitionCall pc = {*in, d.batch, d.C, d.Hp, d.Wp, d.ws, X, L.S, L.ncw, d.hier ? ct_init : nullptr, L.ncw};
     FVIT_TRY(launch_partition(pc, st));
     dbg_rowhash("partition", X, L.Mx, d.C * 4, st);
-    // a non-hierarchical C = 512 stage whose blocks all take the per-window kernels: ONE launch of persistent per-window workgroups (fvit_stage3.hip)
-    bool one_launch = !d.hier && d.weight_terms == 1 && d.depth >= 1 && tune_get("win_stage3", 0) && win_stage3_supported(d.C, d.heads, d.hidden, L.S, d.depth) &&
-                      d.dpad == 32;
-    for (int i = 0; one_launch && i < d.depth; ++i) one_launch = win_fused_ok(d, blocks[i].attn, L.S) && win_mlp_ok(d, blocks[i].mlp, L.Mx);
-    if (one_launch) {
-        AttnBlkCall ab[8];
-        MlpFusedCall mc[8];
-        const int rpi = L.nW * L.S;
-        const float scale = (d.qk_scale > 0.f ? d.qk_scale : 1.0f / sqrtf((float)(d.C / d.heads)));
-        for (int i = 0; i < d.depth; ++i) {
-            const FvitBlockWeights& w = blocks[i];
-            ab[i] = AttnBlkCall{d.operand_dtype, X, rpi, nullptr, 0, nullptr, tables->ln1_add, w.pe_x, w.attn.ln_w, w.attn.ln_b, 1e-5f, rpi,
-                                w.attn.w_qkv_frag, w.attn.b_qkv_heads, w.attn.w_proj_frag, w.attn.b_proj, w.attn.gamma, w.attn.bias, X,
-                                d.batch * L.nW, L.S, d.heads, d.C, scale};
-            mc[i] = MlpFusedCall{d.operand_dtype, X, (int)L.Mx, d.C, d.hidden, w.mlp.ln_w, w.mlp.ln_b, 1e-5f, w.mlp.w_fc1_frag, w.mlp.b_fc1, w.mlp.w_fc2_frag,
-                                 w.mlp.b_fc2, w.mlp.gamma, 1};
-        }
-        FVIT_TRY(launch_win_stage3(ab, mc, d.depth, st));
-        dbg_rowhash("win.stage3", X, L.Mx, d.C * 4, st);
-    }
+    // (r03-r05 carried an opt-in ONE-launch form of a non-hierarchical C = 512 stage -- persistent per-window workgroups running the two kernel bodies alternately,
+    // fvit_stage3.hip: measured -3 % in the joined launch structure, removed in r06: git history, profiles/HISTORY.md)
     bool pre = false;   // does X already include block i's position embedding?
-    for (int i = 0; !one_launch && i < d.depth; ++i) {
+    for (int i = 0; i < d.depth; ++i) {
         NextPe np;
         const bool chain = i + 1 < d.depth && pe_preadd_chain(d, L, blocks[i]) && pe_preadd_chain(d, L, blocks[i + 1]) && blocks[i + 1].pe_x;
         if (chain) { np.add = blocks[i + 1].pe_x; np.add_idx = tables->ln1_add; np.rows_per_image = L.nW * L.S; }

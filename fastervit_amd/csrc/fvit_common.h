@@ -140,8 +140,9 @@ __device__ __forceinline__ float gelu_fast(float x) {
 template <int N>
 __device__ __forceinline__ void pin_values(float (&q)[N]) {
     static_assert(N == 4 || N == 8, "pin_values: 4 or 8 values");
-    if constexpr (N == 4) asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
-    else asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]));
+    // (not volatile: the data dependence alone orders the steps, and the statement stays free to move between independent instructions, e.g. MFMAs)
+    if constexpr (N == 4) asm("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    else asm("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]));
 }
 template <int N>
 __device__ __forceinline__ void gelu_fast_n(float (&x)[N]) {
@@ -400,11 +401,6 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream);
 // same contract for C = 512 / 16 heads, one 49..64-token window per workgroup, waves split heads / output channels (fvit_winblk.hip)
 bool winblk_supported(int C, int heads, int S);
 int launch_winblk(const AttnBlkCall& c, hipStream_t stream);
-// a whole non-hierarchical C = 512 stage (depth x [winblk, winmlp]) as one launch of persistent per-window workgroups (fvit_stage3.hip);
-// attn[b].x_out == mlp[b].x == the stage's row buffer, attn[b].nwin * S == mlp[b].M
-bool win_stage3_supported(int C, int heads, int hidden, int S, int depth);
-int launch_win_stage3(const AttnBlkCall* attn, const MlpFusedCall* mlp, int depth, hipStream_t stream);
-
 struct AttnCall {
     int dtype;
     const void* qkv;  // op16 [rows][ldq], columns [q|k|v][head][dpad]

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     const int ldw = p.wterms * 9 * p.Cin;
 
     // ---- per-lane gather state for the rows this lane stages (fixed for the whole K loop) ----
-    const T* rowbase[XP];   // &in[b][yo*s-1][xo*s-1][0] (may point outside the image; only used when the tap is valid)
+    int64_t rowoff[XP];     // element offset of in[b][yo*s-1][xo*s-1][0] from the plane's base (may lie outside the image; only used when the tap is valid)
     int rowmask[XP];        // bit ky*3+kx set <=> tap inside the image
     int rowchunk[XP];       // swizzled 16-byte chunk this lane copies
 #pragma unroll
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
         const int r = (wave * XP + i) * 8 + (lane >> 3);
         const int m = m0 + r;
         int mask = 0;
-        const T* base = Z;
+        int64_t base = 0;
         if (m < p.M) {
             const int hw = p.Ho * p.Wo;
             const int bb = m / hw, rem = m - bb * hw;
@@ -117,28 +117,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
                     if (yi + ky >= 0 && yi + ky < p.Hi && xi + kx >= 0 && xi + kx < p.Wi) mask |= 1 << (ky * 3 + kx);
-            base = In + (((int64_t)bb * p.Hi + yi) * p.Wi + xi) * p.Cin;
+            base = (((int64_t)bb * p.Hi + yi) * p.Wi + xi) * p.Cin;
         }
-        rowbase[i] = base;
+        rowoff[i] = base;
         rowmask[i] = mask;
         rowchunk[i] = ((lane & 7) ^ swz_x(r)) * 8;
     }
 
     const int cpt = p.Cin / BK;  // K steps per tap
     const int nk1 = 9 * cpt;     // K steps of one weight term
-    // PX: element distance from the hi plane of the input to its lo plane (the third K segment reads the lo plane against the hi weights)
-    const int64_t lo_delta = (PX && p.in_lo) ? ((int64_t)((intptr_t)p.in_lo - (intptr_t)p.in) / (int64_t)sizeof(T)) : 0;   // two separate allocations: integer arithmetic
+    // PX: the third K segment reads the LO plane of the input against the hi weights: the plane's base pointer is chosen per segment, the per-row offsets
+    // are plain integers (r05 formed the lo address as `hi pointer + (in_lo - in)`: arithmetic across two allocations)
+    const T* const InLo = (PX && p.in_lo) ? (const T*)p.in_lo : In;
     auto stage = [&](int kt, char* xbuf, char* wbuf) {
         const int seg = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
         const int kta = kt - seg * nk1;              // the activation side wraps at every segment
         const int ktw = seg == 2 ? kta : kt;         // segments 0 / 1 / 2 meet the weight images hi / lo / hi
         const int tap = kta / cpt, ci0 = (kta - tap * cpt) * BK;
         const int ky = tap / 3, kx = tap - ky * 3;
-        const int64_t toff = (ky * p.Wi + kx) * p.Cin + ci0 + ((PX && seg == 2) ? lo_delta : 0);
+        const int64_t toff = (ky * p.Wi + kx) * p.Cin + ci0;
+        const T* const plane = (PX && seg == 2) ? InLo : In;
         if (!(p.ablate & 1))
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const T* src = ((rowmask[i] >> tap) & 1) ? rowbase[i] + toff + rowchunk[i] : Z + rowchunk[i];
+            const T* src = ((rowmask[i] >> tap) & 1) ? plane + (rowoff[i] + toff + rowchunk[i]) : Z + rowchunk[i];
             glds16(src, xbuf + (wave * XP + i) * 1024);
         }
         if (!(p.ablate & 2))

@@ -857,23 +857,10 @@ int launch_ctblk(const CtBlkCall& c, hipStream_t stream) {
     const int variant = tune_get("ct_variant", 3);
     if (c.terms != 1 && c.terms != 2) { set_error("ct_block: weight terms %d (1 or 2)", c.terms); return FVIT_EINVAL; }
     if (variant == 3) {   // the 8-wave form: waves split output channels, no fp32 partial exchange
-        // r06: two images per workgroup (fvit_tune "ct_nimg", default 2; 1 = the r03 form): every weight fragment feeds two MFMAs, half the workgroups
-        const int nimg = c.batch >= 2 ? tune_get("ct_nimg", 2) : 1;
-        const int depth = tune_get("ct8_depth", nimg == 2 ? 2 : 3);   // ring steps of 8 fragments in flight per wave (2 / 3 / 4; two images: 2 / 3)
-        if (nimg == 2) {
-            const int grid2 = (c.batch + 1) / 2;
-            prof_note("ctblk8_kernel<256,G16,2img>", grid2);
-#define FVIT_CT8X2(T_, WT_) do { \
-            if (depth == 2) hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 2, false, 2>), dim3(grid2), dim3(512), 0, stream, p); \
-            else hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 3, false, 2>), dim3(grid2), dim3(512), 0, stream, p); } while (0)
-            if (c.dtype == FVIT_F16) {
-                if (c.terms == 2) FVIT_CT8X2(_Float16, 2); else FVIT_CT8X2(_Float16, 1);
-            } else if (c.dtype == FVIT_BF16) {
-                if (c.terms == 2) FVIT_CT8X2(__bf16, 2); else FVIT_CT8X2(__bf16, 1);
-#undef FVIT_CT8X2
-            } else { set_error("ct_block: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
-            return check_launch("ctblk8_kernel");
-        }
+        // (r06 measured two images per workgroup -- ctblk8_kernel<.., NIMG = 2>: every weight fragment feeds two MFMAs, half the workgroups -- at -4.5 % images/s,
+        // 80.0k vs 83.7k in three interleaved pairs, profiles/r06_ct_two_images_per_workgroup_ab.log: the workgroup's life is its chain of small dependent phases,
+        // not its weight stream, and the chain doubles; not instantiated.  What stayed from that work: the rows parked in LDS and the streaming LayerNorm.)
+        const int depth = tune_get("ct8_depth", 3);   // ring steps of 8 fragments in flight per wave (2 / 3 / 4)
 #define FVIT_CT8(T_, WT_) do { \
             if (depth == 2) hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 2>), dim3(c.batch), dim3(512), 0, stream, p); \
             else if (depth == 4) hipLaunchKernelGGL((ctblk8_kernel<T_, WT_, 4>), dim3(c.batch), dim3(512), 0, stream, p); \

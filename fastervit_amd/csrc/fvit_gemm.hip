@@ -676,10 +676,8 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
                               : c.epilogue == 1 ? (pp ? "gemm_pp_kernel<1> 256x256" : big ? "gemm_kernel<1> 256x256" : small ? "gemm_kernel<1> 64-row" : "gemm_kernel<1> 128-row")
                                                 : (pp ? "gemm_pp_kernel<0> 256x256" : big ? "gemm_kernel<0> 256x256" : small ? "gemm_kernel<0> 64-row" : "gemm_kernel<0> 128-row"), grid);
     if (splits > 1) prof_note(small ? "gemm_kernel<2> 64-row split-K" : "gemm_kernel<2> 128-row split-K", grid);
-    // measured r01: a 3-stage ring with counted vmcnt gave no gain over 2 stages at 64..392 workgroups => opt-in only
-    const bool deep = !small && !nw8 && grid <= tune_get("gemm_3stage_max_grid", 0) && p.K / BK >= 3;
-    // ring depth of the 64-row tiles (small grids): 2 (48 KiB, three workgroups per CU), 3 (72 KiB, two) or 4 (96 KiB, one)
-    const int ring = small && !nw8 && p.K / BK >= 4 ? tune_get("gemm_ring", 2) : 2;
+    // (measured r01 / r03: 3- and 4-deep rings with counted vmcnt gave no gain over 2 stages at 64..392 workgroups, and their instances missed the 2-waves-per-SIMD
+    // register target; the opt-in knobs "gemm_3stage_max_grid" / "gemm_ring" and those instances were removed in r06: git history, profiles/HISTORY.md)
 #define FVIT_GEMM(E, NS, MI_, NW_) hipLaunchKernelGGL((gemm_kernel<T, E, NS, MI_, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p)
 #define FVIT_GEMM256(E) hipLaunchKernelGGL((gemm_kernel<T, E, 2, 4, 8, 8>), dim3(grid), dim3(512), 0, stream, p)
 #define FVIT_GEMM_E(NS, MI_, NW_) \
@@ -711,10 +709,7 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     else if (big) { switch (c.epilogue) { case 0: FVIT_GEMM256(0); break; case 1: FVIT_GEMM256(1); break; default: FVIT_GEMM256(2); break; } }
     else if (nw8 && small) { FVIT_GEMM_E(2, 1, 8) }        // 64 rows = 4 waves along M x 16 rows
     else if (nw8) { FVIT_GEMM_E(2, 2, 8) }            // 128 rows = 4 waves x 32 rows
-    else if (small && ring == 4) { FVIT_GEMM_E(4, 2, 4) }
-    else if (small && ring == 3) { FVIT_GEMM_E(3, 2, 4) }
     else if (small) { FVIT_GEMM_E(2, 2, 4) }          // 64 rows = 2 waves x 32 rows
-    else if (deep) { FVIT_GEMM_E(3, 4, 4) }
     else { FVIT_GEMM_E(2, 4, 4) }
 #undef FVIT_GEMM_E
 #undef FVIT_GEMM256

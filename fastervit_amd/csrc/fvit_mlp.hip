@@ -455,26 +455,11 @@ int launch_t(const MlpFusedCall& c, hipStream_t stream) {
         // auto: 32 rows per wave (half the weight traffic per row) once 128-row workgroups fill the chip with two per CU, else 16 rows per
         // wave with the input rows kept in registers (M = 54272: 96-107 vs 117-134 us; M = 18020: 72-74 vs 58-59 us, r01 sweep r27)
         if (variant < 0) variant = (c.M + 127) / 128 >= 400 ? 3 : 0;
-        // ring depth 4 (137 KiB of LDS, ONE workgroup per CU) is an opt-in knob: measured r02 (scripts/bench_mlp.py, same box): no gain
-        // where it fits in one round (M = 1360: 35.7 vs 34.4 us: after the ILP rewrite the chunk loop is no longer DMA-bound, skipping
-        // the weight DMA altogether saves 10 %) and a second round of workgroups above 256 (M = 18020, 282 workgroups: 77.9 vs 52.7 us;
-        // end to end 66.7k vs 71.1k images/s)
-        const int grid64 = (c.M + 63) / 64;
-        const bool deep = grid64 <= tune_get("mlp_ring4_max_grid", 0) && variant <= 0;
-        if (deep) {
-            hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 1, true, 4>), dim3(grid64), dim3(256), 0, stream, p);   // 137 KiB of LDS: one workgroup per CU
-            return check_launch("mlp_fused_kernel");
-        }
+        // (r06: the opt-in variants that lost their A/Bs -- the 4-deep ring, 137 KiB of LDS ("mlp_ring4_max_grid", r02: 77.9 vs 52.7 us at 282 workgroups); 8 waves x 128
+        // rows; 64-row workgroups with X re-read; 32 rows per wave with the rows in registers (spills); two waves of 32 rows (437 VGPRs: 57.3 vs 49.0 us) -- are no longer
+        // instantiated: git history, profiles/HISTORY.md)
         switch (variant) {
-            case 2: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 8, 2, true>), dim3((c.M + 127) / 128), dim3(512), 0, stream, p); break;
             case 3: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2, false>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;
-            case 4: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, false>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p); break;
-            case 5: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 4, 2, true>), dim3((c.M + 127) / 128), dim3(256), 0, stream, p); break;  // spills
-            // 6: 32 rows per wave, TWO waves per workgroup (64 rows, two workgroups per CU = one wave per SIMD with the 512-register budget,
-            // 437 VGPRs, no spills): every weight fragment read from LDS feeds two MFMAs.  With 16 rows per wave the 8 waves of a CU read
-            // 256 KiB of fragments per chunk round = 0.85 us at 128 B/clk of the measured ~1.28 us; halving that did NOT pay: 57.3 vs 49.0 us
-            // at M = 18232, 70.6k vs 74.5k images/s (r02 call r3i) -- one wave per SIMD leaves its barrier / LDS round trips uncovered
-            case 6: hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 2, 2, 2, true>), dim3((c.M + 63) / 64), dim3(128), 0, stream, p); break;
             default:
                 if (p.dbg || p.dbgx || (p.ablate & (64 | 128)))   // diagnosis build of the same kernel (fvit_debug_mlp_*)
                     hipLaunchKernelGGL((mlp_fused_kernel<T, 256, 1, 4, 2, true, 2, true>), dim3((c.M + 63) / 64), dim3(256), 0, stream, p);

@@ -44,6 +44,8 @@ struct WinMlpParams {
     float* slab;     // NSPLIT > 1: f32 partial outputs [row group][NSPLIT][waves][CBW * NRB][64 lanes][4], 64 x C x 4 bytes per (row group, split)
     int* counters;   // NSPLIT > 1: one arrival counter per row group, zero before the launch, zero again after it
     unsigned long long* ts;   // TS instances only (fvit_debug_win_mlp_timeline): s_memtime stamps [workgroup][wave][16]
+    int ablate;   // DIAGNOSIS build only (fvit_tune "wm_ablate", results are wrong): 1 = no weight loads inside the main loop (the ring keeps the first steps'
+                  // fragments), 2 = no barrier inside the main loop, 4 = GELU -> identity (bias + narrowing stay).  Always 0 in the shipped library.
 };
 
 // phase stamps of the TS (timeline) instances: 0 kernel entry, 1 first ring steps issued, 2 rows loaded, 3 LayerNorm written + barrier,
@@ -77,7 +79,7 @@ constexpr int winmlp_lds_bytes() {
 
 // The kernel body as a device function (blk = blockIdx.x of a stand-alone launch): fvit_stage3.hip runs it as one phase of a persistent workgroup
 // (the timeline stamps index by blockIdx.x: stand-alone launches only).
-template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1, int NSPLIT = 1, bool TS = false>
+template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1, int NSPLIT = 1, bool TS = false, bool PIPE = false>
 __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const smem, const int blk) {
     typedef typename Op16<T>::v8 v8;
     constexpr int C = CC, KK = C / 32, CB = C / 16, NW = NWV;
@@ -120,8 +122,14 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
     v8 ring[DEPTH][8];
     // step (sc, u) into ring slot `slot`; u and slot are compile-time at every call site (the super-chunk loop is not unrolled, a
     // super-chunk is SPS steps and DEPTH divides SPS, so the slot of step SPS sc + u is u % DEPTH)
+#ifdef FVIT_DIAG
+    const bool abl_w = p.ablate & 1, abl_b = p.ablate & 2, abl_g = p.ablate & 4;
+#else
+    constexpr bool abl_w = false, abl_b = false, abl_g = false;   // the shipped library has no knob that can make a kernel skip work
+#endif
+    bool in_loop = false;   // the prologue's first DEPTH steps are always loaded
     auto issue = [&](int sc, int u, int slot) {
-        if (sc < NSC) {
+        if (sc < NSC && !(abl_w && in_loop)) {
             if (u < F1T) {    // fc1, term u / F1S: chunk 8 sc + wave, k steps 4uu .. 4uu + 3 (uu = u % F1S), slot (kk - 4uu) * 2 + hb
                 const int uu = u % F1S;
                 const char* b = W1 + (size_t)(u / F1S) * WBYTES + (size_t)((sc0 + sc) * NW + wave) * 2 * KK * 1024;
@@ -150,6 +158,7 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < DEPTH; ++t) issue(0, t, t);
+    in_loop = true;
     f4 v[2 * KK];
     {
         const int row = min(row0 + ln_rb * 16 + s, p.M - 1);
@@ -209,6 +218,7 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc2[q][rb] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (!PIPE) {
 #pragma unroll 1
     for (int sc = 0; sc < NSC; ++sc) {
         // ---- B: H^T of chunk 8 sc + wave: [32 units][16 NRB rows] ----
@@ -245,13 +255,13 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
                 hv[r] = acc1[0][rb][r] + bA[r];
                 hv[4 + r] = acc1[1][rb][r] + bB[r];
             }
-            gelu_fast_n<8>(hv);   // eight independent Horner chains in lockstep (fvit_common.h), bitwise gelu_fast
+            if (!abl_g) gelu_fast_n<8>(hv);   // eight independent Horner chains in lockstep (fvit_common.h), bitwise gelu_fast
             v8 pf;
 #pragma unroll
             for (int r = 0; r < 8; ++r) pf[r] = sat16<T>(hv[r]);
             *(v8*)(hw + rb * 1024) = pf;
         }
-        __syncthreads();   // H of this super-chunk visible (HBUF = 2: the other buffer's last readers are past their fc2 of super-chunk sc - 1)
+        if (!abl_b) __syncthreads();   // H of this super-chunk visible (HBUF = 2: the other buffer's last readers are past their fc2 of super-chunk sc - 1)
         // ---- C: out^T[this wave's channels][rows] += W2[:, chunk] . H^T over the 8 chunks ----
         const char* hr = smem + OFF_H + hbuf * NW * NRB * 1024 + lane16;
 #pragma unroll
@@ -271,6 +281,108 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
         }
         if (HBUF == 1) __syncthreads();   // single H buffer: every wave is done reading it before the next super-chunk overwrites it
         stamp<TS>(p, wave, lane, NWV, sc + 4 < 13 ? sc + 4 : 13);
+    }
+    } else {
+        // ---- the software-pipelined form (r06, fvit_tune "win_mlp_pipe"): the same steps in the order
+        //          F1(0) GELU(0) | F1(1) B F2(0)+GELU(1) | F1(2) B F2(1)+GELU(2) | ... | B F2(NSC-1)          (B = the workgroup barrier)
+        // fc1 of super-chunk sc + 1 runs BEFORE the barrier that publishes H(sc) (the barrier's skew and the H write's round trip hide behind 32 .. 128
+        // MFMAs), and bias + GELU + narrowing + publishing of H(sc + 1) are issued INSIDE fc2 of super-chunk sc, one row block per fc2 step, so that the VALU
+        // work sits in the shadow of the wave's own MFMAs instead of between two MFMA phases (r05: 496 VALU instructions behind every fc1, the MFMA pipe
+        // idle for all waves of the workgroup at once since the barrier keeps them in phase).  Needs the double-buffered H: H(sc + 1) is written while
+        // other waves still read H(sc); H(sc + 2) is written after barrier sc + 1, which every wave passes after its fc2(sc).
+        // The weight stream is the same list of steps in the new order; a block of the loop is still SPS steps and DEPTH divides F1T and F2T, so ring
+        // slots stay static.  Per value the operations and their order are those of the plain form: bitwise the same result.
+        static_assert(HBUF == 2, "the pipelined form needs the double-buffered H");
+        static_assert(F1T % DEPTH == 0 && F2T % DEPTH == 0, "ring slots must be static inside the pipelined loop");
+        auto load_f1 = [&](int slot, int sc, int u) { issue(sc, u, slot); };                 // fc1 step u of super-chunk sc (nothing beyond the last)
+        auto load_f2 = [&](int slot, int sc, int v) { issue(sc, F1T + v, slot); };           // fc2 step v of super-chunk sc
+        f4 acc1[2][NRB];
+        auto fc1 = [&](int sc, bool first) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc1[hb][rb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < F1T; ++u) {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    v8 xb[NRB];
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) xb[rb] = *(const v8*)(xn + (rb * KK + 4 * (u % F1S) + k4) * 1024);
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb) acc1[hb][rb] = Op16<T>::mfma(ring[u % DEPTH][k4 * 2 + hb], xb[rb], acc1[hb][rb]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the stream after fc1(sc): fc1's own later steps, then fc2(sc - 1) -- or, behind the very first fc1, fc1(1) (fc2(0) when there is one super-chunk)
+                const int nu = u + DEPTH;
+                if (nu < F1T) load_f1(u % DEPTH, sc, nu);
+                else if (first) { if (NSC > 1) load_f1(u % DEPTH, 1, nu - F1T); else load_f2(u % DEPTH, 0, nu - F1T); }
+                else load_f2(u % DEPTH, sc - 1, nu - F1T);
+            }
+        };
+        // bias + GELU + narrowing of row block rb of the accumulators -> H fragment of chunk j, published in buffer hbuf
+        auto gelu_publish = [&](int j, int hbuf, int rb) {
+            const f4 bA = *(const f4*)(b1s + j * 32 + g * 4);
+            const f4 bB = *(const f4*)(b1s + j * 32 + 16 + g * 4);
+            float hv[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                hv[r] = acc1[0][rb][r] + bA[r];
+                hv[4 + r] = acc1[1][rb][r] + bB[r];
+            }
+            if constexpr (NW == 8) {   // 8 waves x 256 registers: two groups of four chains (eight at once spill 7 registers inside the loop)
+                float h0[4] = {hv[0], hv[1], hv[2], hv[3]}, h1[4] = {hv[4], hv[5], hv[6], hv[7]};
+                gelu_fast_n<4>(h0);
+                gelu_fast_n<4>(h1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { hv[r] = h0[r]; hv[4 + r] = h1[r]; }
+            } else {
+                gelu_fast_n<8>(hv);
+            }
+            v8 pf;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pf[r] = sat16<T>(hv[r]);
+            *(v8*)(smem + OFF_H + ((hbuf * NW + wave) * NRB + rb) * 1024 + lane16) = pf;
+        };
+        fc1(0, true);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) gelu_publish(sc0 * NW + wave, 0, rb);
+#pragma unroll 1
+        for (int sc = 0; sc < NSC; ++sc) {
+            const bool has_next = sc + 1 < NSC;
+            if (has_next) fc1(sc + 1, false);
+            if (!abl_b) __syncthreads();   // H(sc) of every wave visible; every wave is past fc2(sc - 1), i.e. done reading the other buffer
+            const int hbuf = sc & 1;
+            const char* hr = smem + OFF_H + hbuf * NW * NRB * 1024 + lane16;
+            // this wave's chunk of the next super-chunk.  Behind the LAST super-chunk there is none: the same instructions then turn the stale fc1 accumulators into an
+            // H fragment nobody reads (a branch around them would end the basic block and put them BEHIND the step's MFMAs instead of between them: r06 ISA check)
+            const int jn = min((sc0 + sc + 1) * NW + wave, HID / 32 - 1);
+#pragma unroll
+            for (int v = 0; v < F2T; ++v) {
+#pragma unroll
+                for (int c = 0; c < CPS; ++c) {
+                    v8 hb4[NRB];
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) hb4[rb] = *(const v8*)(hr + ((CPS * (v % F2S) + c) * NRB + rb) * 1024);
+#pragma unroll
+                    for (int q = 0; q < CBW; ++q)
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb) acc2[q][rb] = Op16<T>::mfma(ring[v % DEPTH][c * CBW + q], hb4[rb], acc2[q][rb]);
+                }
+                // row blocks [v NRB / F2T, (v + 1) NRB / F2T) of H(sc + 1): VALU + one LDS write each, free to move between this step's MFMAs
+#pragma unroll
+                for (int rb = v * NRB / F2T; rb < (v + 1) * NRB / F2T; ++rb) gelu_publish(jn, hbuf ^ 1, rb);
+                __builtin_amdgcn_sched_barrier(0);
+                // the stream after fc2(sc): its own later steps, then fc1(sc + 2) -- or fc2(sc + 1) when sc + 1 is the last super-chunk (it has no fc1 block in front)
+                const int nv = v + DEPTH;
+                if (nv < F2T) load_f2(v % DEPTH, sc, nv);
+                else if (sc + 2 < NSC) load_f1(v % DEPTH, sc + 2, nv - F2T);
+                else load_f2(v % DEPTH, sc + 1, nv - F2T);
+            }
+            stamp<TS>(p, wave, lane, NWV, sc + 4 < 13 ? sc + 4 : 13);
+        }
     }
     stamp<TS>(p, wave, lane, NWV, 14);
 
@@ -363,16 +475,17 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
     }
 }
 
-template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1, int NSPLIT = 1, bool TS = false>
+template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1, int NSPLIT = 1, bool TS = false, bool PIPE = false>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinMlpParams p) {
     __shared__ __attribute__((aligned(16))) char smem[winmlp_lds_bytes<CC, HID, NRB, NWV>()];
-    winmlp_body<T, CC, HID, NRB, DEPTH, NWV, SP, NSPLIT, TS>(p, smem, blockIdx.x);
+    winmlp_body<T, CC, HID, NRB, DEPTH, NWV, SP, NSPLIT, TS, PIPE>(p, smem, blockIdx.x);
 }
 
 inline WinMlpParams make_winmlp_params(const MlpFusedCall& c) {
     WinMlpParams p;
     p.x = c.x; p.ln_w = c.ln_w; p.ln_b = c.ln_b; p.w1f = c.w1f; p.b1 = c.b1; p.w2f = c.w2f; p.b2 = c.b2; p.gamma = c.gamma; p.eps = c.eps; p.M = c.M;
     p.slab = c.slab; p.counters = c.counters; p.ts = (unsigned long long*)c.ts;
+    p.ablate = diag_knob("wm_ablate");
     return p;
 }
 
@@ -396,26 +509,14 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     const double flops = 4.0 * c.M * (double)c.C * c.hidden;
     const double bytes = 8.0 * c.M * (double)c.C + 4.0 * c.C * (double)c.hidden;
     ProfScope prof(FVIT_K_MLP_FUSED, flops, bytes, stream);
-    // C = 256 forms (fvit_tune "win_mlp256"): 1 = 8 waves x 128 rows; 2 (default) = 4 waves x 64 rows, two workgroups per CU; 3 (r03, opt-in) = 2,
-    // except when 64-row workgroups would be just over one per CU (257 .. 384 row groups: the launch then lasts as long as its few doubled-up
-    // CUs, and everywhere else ONE 4-wave workgroup leaves every LDS round trip / vmcnt wait / GELU chain exposed,
-    // profiles/r03_winmlp_phase_timeline.log): then 8 waves x 80 or 96 rows = at most 256 workgroups, one per CU, two waves per SIMD, each weight
-    // fragment feeding 5 / 6 MFMAs.  Measured r03 (call 14, A/B in one box): the launch gets 24 % shorter (50.4 -> 38.2 us, 0.15 -> 0.20 of the
-    // MFMA peak, bitwise the same result) and the STEP gets slower (81.9k -> 80.6k images/s): 124 KiB of LDS and 8 x 200 registers take the
-    // whole CU, the 4-wave form (68 KiB, 4 x 210) leaves half of it to the other stream shards' kernels.  Same lesson as the r02 LDS rule.
-    const int form = c.C == 256 ? tune_get("win_mlp256", 2) : 0;
-    const int n64 = (c.M + 63) / 64;
-    int wide = 0;   // row blocks of the adaptive 8-wave form (0: not used)
-    if (form == 3 && n64 > 256 && !c.ts) {
-        if ((c.M + 79) / 80 <= 256) wide = 5;
-        else if ((c.M + 95) / 96 <= 256) wide = 6;
-    }
-    const int small = c.C == 256 && (form == 2 || form == 3) && !wide;   // 4-wave, 64-row workgroups, two per CU
-    const int rows_per_wg = wide ? 16 * wide : (c.C == 512 || small ? 64 : 128);
+    // C = 256 (stage 2): 4 waves x 64 rows, 68 KiB of LDS, two workgroups per CU.  (r02 / r03 also measured 8 waves x 128 rows -- no gain -- and 8 waves x 80 / 96 rows:
+    // the launch 24 % shorter, 50.4 -> 38.2 us, and the STEP 1.5 % slower, 124 KiB of LDS and 8 x 200 registers take the whole CU from the other stream shard's kernels;
+    // fvit_tune "win_mlp256" = 1 / 3.  Not instantiated since r06: git history, profiles/HISTORY.md.)
+    const int rows_per_wg = 64;
     const int nrg = (c.M + rows_per_wg - 1) / rows_per_wg;
     const int grid = nsplit > 1 ? (nrg + 7) / 8 * 8 * nsplit : nrg;
     prof_note(c.C == 512 ? (nsplit == 2 ? "winmlp_kernel<512,split2>" : "winmlp_kernel<512>")
-                         : (wide == 5 ? "winmlp_kernel<256,80rows>" : wide == 6 ? "winmlp_kernel<256,96rows>" : "winmlp_kernel<256>"), grid);
+                         : "winmlp_kernel<256>", grid);
     if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_mlp: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
     if (c.terms != 1 && c.terms != 2) { set_error("win_mlp: weight terms %d not supported", c.terms); return FVIT_EINVAL; }
 #define FVIT_WINMLP(T, CC_, HID_, NRB_, NWV_, SP_) \
@@ -425,33 +526,40 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
         if (c.dtype == FVIT_F16) { if (c.terms == 2) FVIT_WINMLP(_Float16, CC_, HID_, NRB_, NWV_, 2); else FVIT_WINMLP(_Float16, CC_, HID_, NRB_, NWV_, 1); } \
         else { if (c.terms == 2) FVIT_WINMLP(__bf16, CC_, HID_, NRB_, NWV_, 2); else FVIT_WINMLP(__bf16, CC_, HID_, NRB_, NWV_, 1); } \
     } while (0)
+    // the software-pipelined main loop (r06; fvit_tune "win_mlp_pipe", see winmlp_body): C = 512 only.  Measured in one box, three interleaved pairs
+    // (profiles/r06_winmlp_pipelined_loop_ab.log): winmlp<512> 83.8 -> 80.9 us per launch (-3.4 %, bitwise the same result); the 4-wave C = 256 form gets SLOWER
+    // with it (54.0 -> 56.9 us: 246 instead of 208 registers, and its fc2 has only 64 MFMAs per super-chunk to put 480 VALU instructions behind) and keeps the
+    // plain loop.  What the loop's parts cost (diagnosis build, wm_ablate; profiles/r06_winmlp_ablation.log): weight loads 11-14 %, the barrier 7-10 %, GELU 8-13 % of
+    // a launch; with all three removed 39.8 / 60.1 us remain (C = 256 / 512) = prologue + epilogue + MFMA issue + LDS reads.
+#define FVIT_WINMLP_P(T, CC_, HID_, NRB_, NWV_, SP_) \
+    hipLaunchKernelGGL((winmlp_kernel<T, CC_, HID_, NRB_, 2, NWV_, SP_, 1, false, true>), dim3(grid), dim3(64 * NWV_), 0, stream, p)
+#define FVIT_WINMLP_PT(CC_, HID_, NRB_, NWV_)                                                    \
+    do {                                                                                         \
+        if (c.dtype == FVIT_F16) { if (c.terms == 2) FVIT_WINMLP_P(_Float16, CC_, HID_, NRB_, NWV_, 2); else FVIT_WINMLP_P(_Float16, CC_, HID_, NRB_, NWV_, 1); } \
+        else { if (c.terms == 2) FVIT_WINMLP_P(__bf16, CC_, HID_, NRB_, NWV_, 2); else FVIT_WINMLP_P(__bf16, CC_, HID_, NRB_, NWV_, 1); } \
+    } while (0)
+    const int pipe = tune_get("win_mlp_pipe", 1);
 #define FVIT_WINMLP_S(T, SP_, NS_) hipLaunchKernelGGL((winmlp_kernel<T, 512, 2048, 4, 2, 8, SP_, NS_>), dim3(grid), dim3(512), 0, stream, p)
 #define FVIT_WINMLP_ST(NS_)                                                                      \
     do {                                                                                         \
         if (c.dtype == FVIT_F16) { if (c.terms == 2) FVIT_WINMLP_S(_Float16, 2, NS_); else FVIT_WINMLP_S(_Float16, 1, NS_); } \
         else { if (c.terms == 2) FVIT_WINMLP_S(__bf16, 2, NS_); else FVIT_WINMLP_S(__bf16, 1, NS_); } \
     } while (0)
-    if (c.ts && c.dtype == FVIT_F16 && c.terms == 1 && nsplit == 1 && (c.C == 512 || small)) {   // timeline instances (diagnosis)
+#ifdef FVIT_DIAG
+    if (c.ts && c.dtype == FVIT_F16 && c.terms == 1 && nsplit == 1) {   // timeline instances (fvit_debug_win_mlp_timeline: the diagnosis build only)
         if (c.C == 512) hipLaunchKernelGGL((winmlp_kernel<_Float16, 512, 2048, 4, 2, 8, 1, 1, true>), dim3(grid), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((winmlp_kernel<_Float16, 256, 1024, 4, 2, 4, 1, 1, true>), dim3(grid), dim3(256), 0, stream, p);
-    } else if (c.C == 512 && nsplit == 2) FVIT_WINMLP_ST(2);
+    } else
+#endif
+    if (c.C == 512 && nsplit == 2) FVIT_WINMLP_ST(2);
     // (a 4-deep ring for C = 512 needs 105 spilled registers at 8 waves x 256: not instantiated)
+    else if (c.C == 512 && pipe) FVIT_WINMLP_PT(512, 2048, 4, 8);
     else if (c.C == 512) FVIT_WINMLP_T(512, 2048, 4, 8);
-    else if (wide == 5) FVIT_WINMLP_T(256, 1024, 5, 8);
-    else if (wide == 6) FVIT_WINMLP_T(256, 1024, 6, 8);
-    else if (small && tune_get("win_mlp256_depth", 2) == 4) {
-        // r05 experiment: a 4-deep weight ring (a whole super-chunk of fragments in flight per wave: 32 KiB instead of 16): 256 registers, 12 accumulator
-        // dwords spilled once per super-chunk.  The phase timeline (profiles/r03_winmlp_phase_timeline.log) has 3.85 us per super-chunk against 0.85 us of
-        // MFMA issue: two 8 KiB steps in flight per wave / ~1.9 us = the rate of the 2-deep ring.
-#define FVIT_WINMLP_D4(T, SP_) hipLaunchKernelGGL((winmlp_kernel<T, 256, 1024, 4, 4, 4, SP_>), dim3(grid), dim3(256), 0, stream, p)
-        if (c.dtype == FVIT_F16) { if (c.terms == 2) FVIT_WINMLP_D4(_Float16, 2); else FVIT_WINMLP_D4(_Float16, 1); }
-        else { if (c.terms == 2) FVIT_WINMLP_D4(__bf16, 2); else FVIT_WINMLP_D4(__bf16, 1); }
-#undef FVIT_WINMLP_D4
-    }
-    else if (small) FVIT_WINMLP_T(256, 1024, 4, 4);
-    else FVIT_WINMLP_T(256, 1024, 8, 8);
+    else FVIT_WINMLP_T(256, 1024, 4, 4);
 #undef FVIT_WINMLP_ST
 #undef FVIT_WINMLP_S
+#undef FVIT_WINMLP_PT
+#undef FVIT_WINMLP_P
 #undef FVIT_WINMLP_T
 #undef FVIT_WINMLP
     return check_launch("winmlp_kernel");

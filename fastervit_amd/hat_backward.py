@@ -647,12 +647,18 @@ def drop_path_masks(layer, batch: int, windows_per_image: int, device, generator
             keep = 1.0 - p_
             return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep, generator=generator) / keep
 
+        def unbiased(keep, dt):
+            # the kept value 1 / keep is STORED in dt: in bf16 1 / 0.9 rounds to 1.109375 and E[mask] would be 0.9984 instead of 1.  Draw with the
+            # keep probability whose reciprocal is exactly representable -- 1 / round_dt(1 / keep), within 2^-9 of the requested one -- so that E[mask] = 1
+            inv = torch.tensor(1.0 / keep, dtype=torch.float32).to(dt).float().item()
+            return 1.0 / inv, inv
+
         def elem(rows, cols, mod, dt=torch.float32):
             p_ = float(getattr(mod, "p", 0.0) or 0.0)
             if p_ <= 0.0:
                 return None
-            keep = 1.0 - p_
-            return (torch.empty(rows, cols, dtype=torch.float32, device=device).bernoulli_(keep, generator=generator) / keep).to(dt)
+            keep, inv = unbiased(1.0 - p_, dt)
+            return (torch.empty(rows, cols, dtype=torch.float32, device=device).bernoulli_(keep, generator=generator) * inv).to(dt)
 
         C_, hid = blk.attn.qkv.in_features, blk.mlp.fc1.out_features
         ncw = blk.cr_window ** 2 if blk.do_sr_hat else 0
@@ -665,8 +671,8 @@ def drop_path_masks(layer, batch: int, windows_per_image: int, device, generator
             p_ = float(getattr(mod, "p", 0.0) or 0.0)
             if p_ <= 0.0:
                 return None
-            keep = 1.0 - p_
-            return (torch.empty(items, S, lib.fvit_attention_spad(S), dtype=torch.float32, device=device).bernoulli_(keep, generator=generator) / keep).to(operand_dtype)
+            keep, inv = unbiased(1.0 - p_, operand_dtype)
+            return (torch.empty(items, S, lib.fvit_attention_spad(S), dtype=torch.float32, device=device).bernoulli_(keep, generator=generator) * inv).to(operand_dtype)
 
         m = dict(attn=draw(batch * windows_per_image, blk.drop_path), mlp=draw(batch * windows_per_image, blk.drop_path),
                  attn_out=elem(rows, C_, blk.attn.proj_drop), mlp_out=elem(rows, C_, blk.mlp.drop), mlp_hid=elem(rows, hid, blk.mlp.drop, operand_dtype),

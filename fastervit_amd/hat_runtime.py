@@ -349,6 +349,32 @@ def _geometry(layer, Hp: int, Wp: int):
     return ws, hier, sr0, sr1
 
 
+def x3_unsupported_reason(layer):
+    """Why a transformer level cannot run the 'f16x3' / 'bf16x3' modes AT THE GEOMETRY IT WAS BUILT FOR (None: it can).  The x3 modes run the in-register
+    attention kernel with two-term q / k / v / P -- dense windows only (csrc/fvit_attn.hip::attention_dense) -- and have no Dropout on the softmax
+    probabilities.  A map size that differs from the built-for one is still checked in _prepare."""
+    blk0 = layer.blocks[0]
+    Cdim, heads = blk0.attn.qkv.in_features, blk0.attn.num_heads
+    d = Cdim // heads
+    if d > 96:
+        return f"head_dim {d} > 96 has no attention kernel instance"
+    dpad = 32 if d <= 32 else (64 if d <= 64 else 96)
+    hier = bool(blk0.do_sr_hat)
+    cw2 = blk0.cr_window ** 2 if hier else 0
+    seqs = [("window", layer.window_size ** 2 + cw2)]
+    if hier:
+        seqs.append(("carrier grid", int(blk0.sr_ratio[0]) * int(blk0.sr_ratio[1]) * cw2))
+    for what, n in seqs:
+        if not (1 <= n <= FVIT_MAX_DENSE_SEQ and (dpad <= 64 or n <= 128)):
+            return (f"the {what} has {n} tokens at head_dim {d} (padded {dpad}); the two-term attention kernel covers sequences up to {FVIT_MAX_DENSE_SEQ} tokens "
+                    "(128 at the 96-wide head padding). Use 'f16x2' / 'bf16x2' (two-term weights) for this geometry")
+    for blk in layer.blocks:
+        for att in (blk.attn,) + ((blk.hat_attn,) if hier and hasattr(blk, "hat_attn") else ()):
+            if float(getattr(att.attn_drop, "p", 0.0) or 0.0) > 0.0:
+                return "attn_drop_rate > 0 (Dropout on the softmax probabilities) is not implemented for two-term probabilities; use a 16-bit or x2 mode to train with it"
+    return None
+
+
 def _prepare(layer, x_dev, Hp: int, Wp: int):
     st = _state(layer, x_dev)
     op_name = getattr(layer, "hat_operand_dtype", "f16")

@@ -28,7 +28,7 @@ class CompiledInference:
     """
 
     def __init__(self, model, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True, join_from=None,
-                 conv_down_terms: Optional[int] = None, precise: bool = False):
+                 conv_down_terms: Optional[int] = None, precise: Optional[bool] = None):
         if not example.is_cuda:
             raise RuntimeError("compile_inference: the example input must be on a HIP device (no CPU fallback)")
         if model.training:
@@ -43,7 +43,9 @@ class CompiledInference:
         self.plan.join_from = join_from
         # precise = True: two-term / fp32 streams and two-term weights on the conv side (DeployPlan.precise); with the HAT operand mode "f16x3"
         # (model.set_hat_operand_dtype) the configuration that meets logits max-abs < 1e-3 ABSOLUTE on FasterViT-4 / any-res
-        self.plan.precise = bool(precise)
+        # (None keeps DeployPlan's default, i.e. the FVIT_PRECISE_DEPLOY environment switch, like conv_down_terms below)
+        if precise is not None:
+            self.plan.precise = bool(precise)
         if conv_down_terms is not None:   # 2 = two-term weights in the Downsample.reduction convs: the accuracy option of the 16-bit plan (DeployPlan)
             self.plan.down_weight_terms = int(conv_down_terms)
         self.use_graph = bool(graph)

@@ -475,9 +475,15 @@ class FasterViT(nn.Module):
         route to logits max-abs < 1e-3 with bf16 operands) -- or 'f16x3' / 'bf16x3' -- weights AND activations
         as two terms (three times the MFMA work, unfused kernel chain): ~22 significant bits through the HAT stages, the route to
         logits max-abs < 1e-3 ABSOLUTE on FasterViT-4 / any-res (measured 2.6e-5 on |7.1| with the fp32 conv side)."""
-        from ..hat_runtime import OPERAND_MODES
+        from ..hat_runtime import OPERAND_MODES, x3_unsupported_reason
         if name not in OPERAND_MODES:
             raise ValueError(f"operand mode must be one of {OPERAND_MODES}")
+        if name.endswith("x3"):
+            # geometry the two-term-activation kernels do not cover is refused HERE, by name, not as an error of the first forward (VERDICT r05 item 12)
+            for li, lvl in enumerate(self.levels):
+                why = x3_unsupported_reason(lvl) if lvl.transformer_block and len(lvl.blocks) else None
+                if why is not None:
+                    raise NotImplementedError(f"operand mode {name!r}, level {li}: {why}")
         self.hat_operand_dtype = name
         for lvl in self.levels:
             lvl.hat_operand_dtype = name

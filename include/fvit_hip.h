@@ -535,10 +535,13 @@ int fvit_sgd_momentum(float* param, float* momentum, const float* grad, int64_t 
 /* Performance-experiment knobs for A/B runs inside one process; the same keys can be preset through the environment as
  * FVIT_TUNE_<key>=<int> (read once per key).  Kernel-selection knobs never change results beyond fp32 summation order:
  *   "mlp_fused", "attn_fused" 0/1; "mlp_fused_min_rows", "attn_fused_min_rows", "mlp_fused512_min_rows", "attn_fused512_min_rows";
- *   "mlp_variant" (-1 auto), "ab_variant", "ct_fused" 0/1 (carrier branch in one kernel), "win_fused" 0/1 (stage-3 attention sub-block in one kernel), "win_fused256" 0/1 (its 4-wave C = 256 instance for stage 2, off), "win_mlp" 0/1 (stage-3 MLP sub-block in one kernel), "win_mlp256" 0/1/2 (its C = 256 instances for stage 2: 2 = 4-wave 64-row workgroups (default), 1 = 8-wave 128-row, 0 = fvit_mlp_fused's kernel), "ct_variant", "ct_touch", "ln_gemm" 0/1, "ln_gemm_max_rows", "lngemm_nt", "gemm_ring", "mlp_ring4_max_grid", "gemm_stagger", "ab_stagger", "mlp_stagger" (0 / 1 / 2), "gemm_bm64_max_grid", "gemm_nw8_max_grid", "gemm_3stage_max_grid", "conv_halo" 0/1,
+ *   "mlp_variant" (-1 auto), "ab_variant", "ct_fused" 0/1 (carrier branch in one kernel), "win_fused" 0/1 (stage-3 attention sub-block in one kernel), "win_fused256" 0/1 (its 4-wave C = 256 instance for stage 2, off), "win_mlp" 0/1 (stage-3 MLP sub-block in one kernel), "win_mlp256" 0/1 (its 4-wave 64-row C = 256 instance for stage 2 (default) or fvit_mlp_fused's kernel), "ct_variant", "ct_touch", "ct8_depth" 2/3/4, "ln_gemm" 0/1, "ln_gemm_max_rows", "lngemm_nt", "gemm_stagger", "ab_stagger", "mlp_stagger" (0 / 1 / 2), "gemm_bm64_max_grid", "gemm_nw8_max_grid", "conv_halo" 0/1,
  *   "conv_halo_grid", "conv64_variant", "conv128_narrow", "stem_fused_grid";
  *   r05: "gemm_x3_dual" 1/0 (dual K tiles of the x3 GEMMs vs the K-concatenated walk), "conv_n128_ragged" 1/0 (128 x 128 conv tiles with a ragged last N tile
- *   for Cout % 128 == 64 vs 128 x 64 tiles), "win_mlp256_depth" 2/4 (weight-ring depth of the stage-2 MLP kernel; 4 measured slower), "gemm_splitk" 0/1.
+ *   for Cout % 128 == 64 vs 128 x 64 tiles), "gemm_splitk" 0/1;
+ *   r06: "win_mlp_pipe" 1/0 (software-pipelined super-chunk loop of the C = 512 MLP kernel vs the plain loop; bitwise the same result).
+ *   Removed in r06 with the kernel instances they selected (all measured no better than the defaults): "gemm_ring", "gemm_3stage_max_grid", "mlp_ring4_max_grid",
+ *   "win_mlp256_depth", "win_stage3", "win_mlp256" = 1 / 3, "mlp_variant" = 2 / 4 / 5 / 6.
  * Guarded by a mutex; launches read the values at launch time.
  * DIAGNOSIS BUILD ONLY (libfvit_hip_diag.so, compiled with -DFVIT_DIAG; selected by FVIT_DIAG=1 in the Python binding): the "*_ablate" keys
  * ("mlp_ablate", "ab_ablate", "conv_ablate", "conv_halo_ablate") and "ablate_skip" switch off parts of a kernel / whole kernels for timing and

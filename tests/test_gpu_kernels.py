@@ -323,14 +323,22 @@ def test_mlp_fused(opname, dt, code, M, use_gamma, C):
     assert torch.isfinite(x).all()
     assert (x - ref).abs().max().item() < tol
     assert lib.fvit_win_mlp_supported(C, hid) == 1 and lib.fvit_win_mlp_supported(784, 3136) == 0
-    if True:   # the same contract with the N-split work split (fvit_winmlp.hip: 64-row workgroups for C = 512, 128-row for C = 256)
+    # the same contract with the N-split work split (fvit_winmlp.hip: 64-row workgroups), in its plain and its software-pipelined main loop (r06: the default at
+    # C = 512; C = 256 always runs the plain loop, the knob is a no-op there)
+    outs = {}
+    for pipe in (0, 1):
+        _lib.tune("win_mlp_pipe", pipe)
         xw = torch.cat([x0, torch.full((5, C), float("nan"), device="cuda")])   # rows beyond M stay untouched
-        _lib.check(lib.fvit_win_mlp_fused(code, xw.data_ptr(), M, C, hid, lnw.data_ptr(), lnb.data_ptr(), ctypes.c_float(1e-5), w1p.data_ptr(),
-                                          b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(), gamma.data_ptr() if use_gamma else None, _stream()),
-                   "win_mlp_fused")
+        rc = lib.fvit_win_mlp_fused(code, xw.data_ptr(), M, C, hid, lnw.data_ptr(), lnb.data_ptr(), ctypes.c_float(1e-5), w1p.data_ptr(),
+                                    b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(), gamma.data_ptr() if use_gamma else None, _stream())
+        _lib.tune("win_mlp_pipe", 1)
+        _lib.check(rc, "win_mlp_fused")
         torch.cuda.synchronize()
         assert torch.isfinite(xw[:M]).all() and torch.isnan(xw[M:]).all()
-        assert (xw[:M] - ref).abs().max().item() < tol, f"win_mlp: {(xw[:M] - ref).abs().max().item()} vs {tol}"
+        assert (xw[:M] - ref).abs().max().item() < tol, f"win_mlp (pipe {pipe}): {(xw[:M] - ref).abs().max().item()} vs {tol}"
+        outs[pipe] = xw[:M].clone()
+    # the pipelined loop runs the same operations per value in the same order: bitwise the plain form
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("C,Cv", [(256, 196), (448, 392), (64, 16), (128, 80)])
@@ -702,21 +710,16 @@ def test_ct_block_fused(opname, dt, code, batch, G, use_add, use_gamma):
     out = torch.full((batch * G + 3, C), float("nan"), device="cuda")
     scale = d ** -0.5
     p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-    outs8 = {}
-    for variant, nimg in ((0, 1), (1, 1), (2, 1), (3, 1), (3, 2)):   # 3: the 8-wave form (waves split output channels); r06: one or two images per workgroup
+    for variant in (0, 1, 2, 3):   # 3: the 8-wave form (waves split output channels)
         _lib.tune("ct_variant", variant)
-        _lib.tune("ct_nimg", nimg)
         out.fill_(float("nan"))
         rc = lib.fvit_ct_block_fused(code, X.data_ptr(), rowsA, src_idx.data_ptr(), p(add), out.data_ptr(), batch, G, heads, C, hid,
                                      ln1w.data_ptr(), ln1b.data_ptr(), wqf.data_ptr(), bqh.data_ptr(), wpf.data_ptr(), bproj.data_ptr(), p(g1),
                                      bp.data_ptr(), ctypes.c_float(scale), ln2w.data_ptr(), ln2b.data_ptr(), w1f.data_ptr(), b1.data_ptr(),
                                      w2f.data_ptr(), b2.data_ptr(), p(g2), ctypes.c_float(1e-5), _stream())
-        _lib.tune("ct_variant", 3)   # the defaults
-        _lib.tune("ct_nimg", 2)
+        _lib.tune("ct_variant", 3)   # the default
         _lib.check(rc, "ct_block_fused")
         torch.cuda.synchronize()
-        if variant == 3:
-            outs8[nimg] = out[:batch * G].clone()
         ct = X.view(batch, rowsA, C)[:, src_idx.long()]
         if use_add:
             ct = ct + add[None]
@@ -734,9 +737,7 @@ def test_ct_block_fused(opname, dt, code, batch, G, use_add, use_gamma):
         got = out[:batch * G]
         assert torch.isfinite(got).all() and torch.isnan(out[batch * G:]).all()
         tol = (4e-3 if dt == torch.float16 else 3e-2) * ref.abs().max().item()
-        assert (got - ref).abs().max().item() < tol, f"variant {variant} x {nimg}: {(got - ref).abs().max().item()} vs {tol}"
-    # two images per workgroup share every weight fragment; per image the operations and their order are those of the one-image form
-    assert torch.equal(outs8[1], outs8[2])
+        assert (got - ref).abs().max().item() < tol, f"variant {variant}: {(got - ref).abs().max().item()} vs {tol}"
 
 
 @pytest.mark.parametrize("opname,dt,code", OPS)

@@ -4,7 +4,8 @@ Tolerances (stated per north_star "logits max-abs < 1e-3"; r02: tightened to the
   * fp16 MFMA operands, fp32 accumulate / residual / LayerNorm / softmax (the default): logits max-abs error < 1e-3 for FasterViT-0
     (|logits| <= 1.2) in module mode (conv side fp32), in deploy mode (own fp16 conv kernels), under autocast (automatic plan) and with
     stream shards; relative error < 1.5e-3 for the variants whose logits reach 5-9 (FasterViT-4, any-res, tiny fixtures); stage maps and
-    the 'stress' fixtures relative < 1e-3 (stages) / 5e-3 (per block, logits).
+    the 'stress' fixtures relative < 1e-3 (stages); per block < 1.2e-3 (x) / 1.5e-3 (carrier tokens), tiny-model logits < 1.6e-3, stress logits < 1.1e-3:
+    r06, ~2x the measured errors (profiles/r06_parity_margins_measured.log).
   * bf16 operands: 8 mantissa bits per operand, measured 3.3e-3 on FasterViT-0: asserted < 5e-3, does NOT meet the bar.
 """
 import numpy as np
@@ -43,9 +44,10 @@ def test_tiny_models_vs_reference_goldens(name):
     with torch.no_grad():
         logits = model(x).float().cpu()
     assert _native_loaded()
+    # r06: bounds at ~2x the measurement (profiles/r06_parity_margins_measured.log: level outputs <= 9.7e-4, logits <= 8.0e-4 over the eight fixtures; r05: 5e-3)
     for li in (2, 3):
-        assert rel_err(feats[li], g[f"level{li}_out"]) < 5e-3, f"level {li} output"
-    assert rel_err(logits, g["logits"]) < 5e-3
+        assert rel_err(feats[li], g[f"level{li}_out"]) < 2e-3, f"level {li} output"
+    assert rel_err(logits, g["logits"]) < 1.6e-3
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -66,10 +68,11 @@ def test_hat_blocks_vs_reference_goldens(name):
             with torch.no_grad():
                 xo, cto = blk(xw.cuda(), None if ct is None else ct.cuda())
             ref_x = g[f"l{li}b{bi}_x"]
-            assert rel_err(xo.cpu(), ref_x) < 5e-3, f"{name} level {li} block {bi} x"
+            # r06: ~2x the measured per-block error (x <= 5.7e-4, carrier tokens <= 7.0e-4 over the eight fixtures; r05 asserted 5e-3)
+            assert rel_err(xo.cpu(), ref_x) < 1.2e-3, f"{name} level {li} block {bi} x"
             if ct is not None:
                 ref_ct = g[f"l{li}b{bi}_ct"]
-                assert rel_err(cto.cpu(), ref_ct) < 5e-3, f"{name} level {li} block {bi} ct"
+                assert rel_err(cto.cpu(), ref_ct) < 1.5e-3, f"{name} level {li} block {bi} ct"
                 ct = torch.from_numpy(ref_ct)
             xw = torch.from_numpy(ref_x)  # next block starts from the reference's state: errors do not compound
 
@@ -135,7 +138,7 @@ def test_fvit0_224_stress_logits():
         logits = model(case_input("fvit0_224_stress").cuda()).float().cpu()
     e = rel_err(logits, g["logits"])
     print(f"faster_vit_0_224 stress-weights logits rel err {e:.3e}")
-    assert e < 5e-3
+    assert e < 1.1e-3   # r06: 2x the measured 5.3e-4 (r05: 5e-3)
 
 
 def test_fvit0_224_bf16_operands():

@@ -380,44 +380,6 @@ def test_win_mlp_split_hidden(opname, dt, code, M, nsplit, terms):
     assert (x1 - outs[0][:M]).abs().max().item() < 1e-4 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("opname,dt,code", OPS)
-@pytest.mark.parametrize("M", [16400, 18232, 20481, 24576, 18020])
-def test_win_mlp_wide_row_groups(opname, dt, code, M):
-    """C = 256 MLP kernel, r03 adaptive form (fvit_tune win_mlp256 = 3, opt-in: faster launch, slower step): when 64-row workgroups would be
-    257 .. 384 (just over one per CU) the launcher switches to 8 waves x 80 / 96 rows (<= 256 workgroups).  Same contract; per row the same
-    summation order as the 4-wave 64-row form, hence bitwise the same result."""
-    lib = _lib.lib()
-    C, hid = 256, 1024
-    g = torch.Generator(device="cpu").manual_seed(M)
-    x0 = (torch.randn(M, C, generator=g) * 1.5 + 0.3).cuda()
-    lnw = (torch.rand(C, generator=g) + 0.5).cuda()
-    lnb = (torch.randn(C, generator=g) * 0.2).cuda()
-    w1 = (torch.randn(hid, C, generator=g) / C ** 0.5).to(dt).cuda()
-    b1 = (torch.randn(hid, generator=g) * 0.3).cuda()
-    w2 = (torch.randn(C, hid, generator=g) / hid ** 0.5).to(dt).cuda()
-    b2 = (torch.randn(C, generator=g) * 0.3).cuda()
-    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
-    w1p = hat_runtime.frag_pack_fc1(w1.float()).to(dt).contiguous()
-    w2p = hat_runtime.frag_pack_fc2(w2.float()).to(dt).contiguous()
-    outs = {}
-    try:
-        for form in (3, 2):
-            _lib.tune("win_mlp256", form)
-            xw = torch.cat([x0, torch.full((7, C), float("nan"), device="cuda")])
-            _lib.check(lib.fvit_win_mlp_fused(code, xw.data_ptr(), M, C, hid, lnw.data_ptr(), lnb.data_ptr(), ctypes.c_float(1e-5), w1p.data_ptr(),
-                                              b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), gamma.data_ptr(), _stream()), "win_mlp_fused")
-            torch.cuda.synchronize()
-            outs[form] = xw
-    finally:
-        _lib.tune("win_mlp256", 2)
-    xn = F.layer_norm(x0, (C,), lnw, lnb, 1e-5).to(dt).float()
-    h = F.gelu(xn @ w1.float().t() + b1).to(dt).float()
-    ref = x0 + gamma * (h @ w2.float().t() + b2)
-    tol = (3e-3 if dt == torch.float16 else 2e-2) * ref.abs().max().item()
-    assert torch.isfinite(outs[3][:M]).all() and torch.isnan(outs[3][M:]).all()
-    assert (outs[3][:M] - ref).abs().max().item() < tol
-    assert torch.equal(outs[3][:M], outs[2][:M])
-
 
 def _attention_ref(xin, lnw, lnb, wqkv, bqkv, wproj, bproj, gamma, bias, heads, dt):
     n, S, C = xin.shape

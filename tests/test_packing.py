@@ -118,3 +118,21 @@ def test_three_term_packing_and_the_gemm_column_map():
     exact = a.double() @ w.double().t()
     single = ah.float() @ hi.float().t()
     assert (y.double() - exact).abs().max() < 2e-6 < (single.double() - exact).abs().max()
+
+
+def test_x3_modes_are_refused_at_set_time_for_geometries_they_do_not_cover():
+    """the two-term-activation modes cover dense windows (<= 208 tokens; <= 128 at the 96-wide head padding), head_dim <= 96 and no
+    Dropout on the softmax probabilities; anything else raises in set_hat_operand_dtype, naming the level -- not at the first forward."""
+    import pytest
+    import fastervit_amd
+    m = fastervit_amd.create_model("faster_vit_0_224")
+    m.set_hat_operand_dtype("f16x3")            # 7x7 windows + 4 carriers, head_dim 32: covered
+    assert m.hat_operand_dtype == "f16x3"
+    big = fastervit_amd.create_model("faster_vit_0_any_res", resolution=[512, 512], window_size=[7, 7, 16, 8], ct_size=2)   # 16 x 16 windows: 260 tokens
+    with pytest.raises(NotImplementedError, match="level 2.*window has 260 tokens"):
+        big.set_hat_operand_dtype("bf16x3")
+    big.set_hat_operand_dtype("bf16x2")         # two-term weights only: fine
+    assert big.hat_operand_dtype == "bf16x2"
+    drop = fastervit_amd.create_model("faster_vit_0_224", attn_drop_rate=0.1)
+    with pytest.raises(NotImplementedError, match="attn_drop_rate"):
+        drop.set_hat_operand_dtype("f16x3")
