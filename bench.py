@@ -630,7 +630,7 @@ def compact_line(out, detail_path=None):
     for m in OPERAND_MODES + tuple(mm + "_down2" for mm in ALL_OPERAND_MODES) + ("bf16x3_precise",):
         if "parity_" + m in out:
             c["parity_" + m] = _pick(out["parity_" + m], _PAR_KEYS)
-    for k in ("bf16_under_1e-3_images_per_s", "hat_ms_per_step", "kernel_ms_per_step_serialized", "launches_per_step"):
+    for k in ("bf16_under_1e-3_images_per_s", "bf16_under_1e-3_with_margin_images_per_s", "hat_ms_per_step", "kernel_ms_per_step_serialized", "launches_per_step"):
         if k in out:
             c[k] = out[k]
     if out.get("secondary"):
@@ -837,18 +837,27 @@ def main():
                 out["parity_" + other] = {"error": f"{type(e).__name__}: {e}"[:300]}
         cfg.model.set_hat_operand_dtype(args.operand)
         if cfg.runner is not None and cfg.plan is not None and not args.no_modes:
-            # the accuracy option of the 16-bit plan: two-term weights in the three Downsample.reduction convs (same operand mode otherwise)
-            try:
-                cfg.plan.down_weight_terms, cfg.plan.sig = 2, None
-                cfg.runner.recompile()
-                el = dp.timed_steps(cfg.step, max(5, args.steps // 4), 2, torch.cuda.synchronize, None, dev)
-                y = cfg.logits()
-                err = (y[idx] - ref_all).abs().max().item()
-                out[f"parity_{args.operand}_down2"] = {"logits_max_abs_err": float(f"{err:.3e}"), "images": len(idx), "meets_1e-3": bool(err < 1e-3),
-                                                       "images_per_s": round(args.batch * max(5, args.steps // 4) / el, 1),
-                                                       "vs": "CPU oracle fp32, the images of 'parity'; Downsample.reduction convs with two-term weights"}
-            except Exception as e:
-                out[f"parity_{args.operand}_down2"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # the accuracy option of the 16-bit plan: two-term weights in the three Downsample.reduction convs (same operand mode otherwise); r06: also under
+            # bf16x2 over the FULL --steps region -- bf16 operands with margin under the bar (bf16x2 alone sits AT the bar once all 256 images are checked)
+            for mode_d, full in ((args.operand, False), ("bf16x2", True)):
+                key = f"parity_{mode_d}_down2"
+                try:
+                    cfg.model.set_hat_operand_dtype(mode_d)
+                    cfg.plan.down_weight_terms, cfg.plan.sig = 2, None
+                    cfg.runner.recompile()
+                    nrep, nwarm = (args.steps, args.warmup) if full else (max(5, args.steps // 4), 2)
+                    el = dp.timed_steps(cfg.step, nrep, nwarm, torch.cuda.synchronize, None, dev)
+                    y = cfg.logits()
+                    per_image = (y[idx] - ref_all).abs().amax(dim=1)
+                    err = per_image.max().item()
+                    out[key] = {"logits_max_abs_err": float(f"{err:.3e}"), "images": len(idx), "worst_image": int(per_image.argmax()), "meets_1e-3": bool(err < 1e-3),
+                                "images_per_s": round(args.batch * nrep / el, 1), "steps": nrep,
+                                "vs": f"CPU oracle fp32, all {len(idx)} images; HAT operands {mode_d}, Downsample.reduction convs with two-term weights"}
+                    if full and err < 1e-3:
+                        out["bf16_under_1e-3_with_margin_images_per_s"] = out[key]["images_per_s"]
+                except Exception as e:
+                    out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            cfg.model.set_hat_operand_dtype(args.operand)
             cfg.plan.down_weight_terms, cfg.plan.sig = 1, None
         if cfg.runner is not None:
             cfg.runner.recompile()

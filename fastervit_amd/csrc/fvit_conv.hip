@@ -926,8 +926,15 @@ constexpr int SF_BATCH = 3;                                                  // 
 
 // IN: element type of the caller's image (float / _Float16 / __bf16) -- a compile-time parameter since r03: as a runtime switch it put two
 // scalar branches around every gathered element (~40 instructions per element, the whole of phase A: 12 of the 16.6 us a tile took)
-template <typename T, typename IN = float, bool TS = false>
+// NHWC3 (r06): the caller's image is fp32 channels-last (stride_c = 1, stride_w = 3: validate.py's --channels-last, bench.py).  The nine (kx, c) values of one
+// kernel row are then 36 contiguous bytes, and the gather of a conv1 pixel is THREE bounds-checked buffer loads per lane (dwordx4, dwordx4, dword: row
+// ky = g of the 3 x 3 patch) instead of eight scalar loads with their index arithmetic -- phase A was 78 % of a tile (profiles/r03_stem_phase_accounting.log).
+// The contraction order changes with it: k slot 8g + e = (ky = g, r9 = e) for g < 3, and the ninth value of each row goes to lane group 3 (k slots 24 + ky,
+// three VALU lane swaps); the first-conv weights are re-ordered to match, once per workgroup, into LDS.  Rows above / below the image are out of the
+// buffer's range and read as zero; the left / right border columns are masked (the run then covers the neighbouring row's pixel).
+template <typename T, typename IN = float, bool TS = false, bool NHWC3 = false>
 __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
+    static_assert(!NHWC3 || sizeof(IN) == 4, "the contiguous-run gather needs dword-aligned runs: fp32 input");
     unsigned long long tsA = 0, tsBar = 0, tsB = 0, tsE = 0, tsBar0 = 0, tsN = 0, tsT0 = 0, tsMark = 0;
     unsigned pf_sink = 0;   // keeps the next-tile touch loads alive
     if constexpr (TS) { tsT0 = __builtin_amdgcn_s_memtime(); }
@@ -937,6 +944,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
     float* sb1 = (float*)smem_dyn;             // [64]
     float* sb2 = sb1 + 64;                     // [64]
     char* img = smem_dyn + 1024;               // conv1 tile
+    T* w1s = (T*)(smem_dyn + 1024 + SF_LDS);   // NHWC3: the first-conv weights [64][32] in the run order of the gather (4 KiB)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -944,6 +952,15 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
     const int ch = wave & 1, ph = wave >> 1;
     const int g = lane >> 4, s = lane & 15;
     if (tid < 64) { sb1[tid] = p.b1[tid]; sb2[tid] = p.b2[tid]; }
+    if constexpr (NHWC3) {
+        // w1s[ch][8 gg + e] = w1[ch][k]: gg < 3: k = 9 gg + e (row ky = gg, values r9 = 0 .. 7); gg = 3: k = 9 e + 8 for e < 3 (the ninth value of row e), else 0
+        const T* W1g = (const T*)p.w1;
+        for (int i = tid; i < 64 * 32; i += 256) {
+            const int chn = i >> 5, kk = i & 31, gg = kk >> 3, e = kk & 7;
+            const int k = gg < 3 ? 9 * gg + e : (e < 3 ? 9 * e + 8 : 31);   // k = 31 is a zero column of w1
+            w1s[i] = W1g[chn * 32 + k];
+        }
+    }
 
     const int nblk = gridDim.x;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -984,6 +1001,85 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
         FVIT_SF_MARK(tsBar0)
 
         // ================= phase A: conv1 + bias + ReLU of the tile's 17 x 33 conv1 pixels -> LDS =================
+        if constexpr (NHWC3) {
+            int lane_s = s, lane_g = g;
+            asm volatile("" : "+v"(lane_s), "+v"(lane_g));   // keep the per-group index math inside the loop (registers!)
+            v8 w1f[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) w1f[ni] = *(const v8*)(w1s + ((lane_s >> 2) * 16 + ni * 4 + (lane_s & 3)) * 32 + lane_g * 8);
+            // one buffer per image: every offset outside [0, Hi Wi 12) -- the rows above and below the image, negative offsets included -- reads as zero
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.in.data + (int64_t)b * p.in.stride_b * 4), 0,
+                                                                                   p.Hi * p.Wi * 12, 0x00020000);
+            const int gy = lane_g < 3 ? lane_g : 2;          // lane group 3 repeats group 2's loads; its own values arrive by lane swaps
+            for (int g3 = wave; g3 < SF_GROUPS; g3 += 4 * SF_BATCH) {
+                f4 la[SF_BATCH], lb[SF_BATCH];
+                float lc8[SF_BATCH];
+                int qv[SF_BATCH], lrv[SF_BATCH], lcv[SF_BATCH];
+                bool v1v[SF_BATCH], lft[SF_BATCH], rgt[SF_BATCH];
+#pragma unroll
+                for (int u = 0; u < SF_BATCH; ++u) {
+                    const int q = (g3 + 4 * u) * 16 + lane_s;
+                    const int lr = q / SF_COLS, lc = q - lr * SF_COLS;
+                    const int R = r0 + lr, Cc = c0 + lc;
+                    const bool v1 = q < SF_ROWS * SF_COLS && R >= 0 && R < p.H1 && Cc >= 0 && Cc < p.W1;
+                    const int yi = 2 * R - 1, xi = 2 * Cc - 1;
+                    qv[u] = q; lrv[u] = lr; lcv[u] = lc; v1v[u] = v1;
+                    lft[u] = xi < 0;                // tap column kx = 0 is left of the image: values 0 .. 2 of the run belong to the previous row
+                    rgt[u] = xi + 2 >= p.Wi;        // tap column kx = 2 is right of it: values 6 .. 8 belong to the next row
+                    // a pixel outside the conv1 map (v1 false) is stored as zero below whatever it read: point it at the image's first run.  At the left / right
+                    // border the run starts one pixel later / earlier (and is shifted back in registers below): no access then straddles the start or the end of
+                    // the buffer -- a dwordx4 that is PARTLY out of range comes back as zeros altogether (r06: the image's corner pixels were wrong)
+                    const int off = v1 ? ((yi + gy) * p.Wi + xi + (xi < 0 ? 1 : 0) - (xi + 2 >= p.Wi ? 1 : 0)) * 12 : 0;
+                    la[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+                    lb[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0));
+                    lc8[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 32, 0, 0));
+                }
+#pragma unroll
+                for (int u = 0; u < SF_BATCH; ++u) {
+                    const int q = qv[u], lr = lrv[u], lc = lcv[u];
+                    const bool v1 = v1v[u];
+                    const float l9[9] = {la[u][0], la[u][1], la[u][2], la[u][3], lb[u][0], lb[u][1], lb[u][2], lb[u][3], lc8[u]};
+                    float e9[9];
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) {
+                        const float sl = e >= 3 ? l9[e - 3] : 0.f;    // left border: the run began at tap column 1
+                        const float sr = e < 6 ? l9[e + 3] : 0.f;     // right border: it began one pixel left of tap column 0
+                        e9[e] = lft[u] ? sl : (rgt[u] ? sr : l9[e]);
+                    }
+                    // the ninth value of rows 0 / 1 / 2 (held by lane groups 0 / 1 / 2) -> k slots 24 / 25 / 26 of lane group 3
+                    const auto sw16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(e9[8]), __float_as_uint(e9[8]), false, false);   // [0]: odd rows <- the even row below
+                    const auto sw32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(e9[8]), __float_as_uint(e9[8]), false, false);   // [0]: lanes 32.. <- lanes 0 .. 31
+                    const auto sw3 = __builtin_amdgcn_permlane32_swap(sw16[0], sw16[0], false, false);
+                    const float t0 = __uint_as_float(sw3[0]), t1 = __uint_as_float(sw32[0]), t2 = __uint_as_float(sw16[0]);   // in lane group 3: rows 0, 1, 2
+                    const bool g3l = lane_g == 3;
+                    v8 xf;
+                    xf[0] = (T)(g3l ? t0 : e9[0]);
+                    xf[1] = (T)(g3l ? t1 : e9[1]);
+                    xf[2] = (T)(g3l ? t2 : e9[2]);
+#pragma unroll
+                    for (int e = 3; e < 8; ++e) xf[e] = (T)(g3l ? 0.f : e9[e]);
+                    f4 acc[4];
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[ni] = Op16<T>::mfma(w1f[ni], xf, (f4){0.f, 0.f, 0.f, 0.f});
+                    if (q < SF_ROWS * SF_COLS) {
+                        v8 o0, o1;
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const f4 bv = *(const f4*)(sb1 + lane_g * 16 + ni * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float y = v1 ? fmaxf(acc[ni][r] + bv[r], 0.f) : 0.f;   // outside the conv1 map: conv2's zero padding
+                                if (ni < 2) o0[ni * 4 + r] = (T)y; else o1[(ni - 2) * 4 + r] = (T)y;
+                            }
+                        }
+                        const int px = lc >> 1;
+                        char* dst = img + lr * SF_ROWPITCH + (lc & 1) * SF_PLANE + px * 128;
+                        *(v8*)(dst + (((2 * lane_g) ^ (px & 6)) << 4)) = o0;          // channels 16g .. 16g+7   = chunk 2g
+                        *(v8*)(dst + (((2 * lane_g + 1) ^ (px & 6)) << 4)) = o1;      // channels 16g+8 .. 16g+15 = chunk 2g + 1
+                    }
+                }
+            }
+        } else
         {
             int lane_s = s, lane_g = g;
             asm volatile("" : "+v"(lane_s), "+v"(lane_g));   // keep the per-group index math inside the loop (registers!)
@@ -1358,7 +1454,10 @@ static int stem_fused_impl(int32_t dtype, const FvitMapView* in, const void* w1,
     int maxgrid = tune_get("stem_fused_grid", 512);
     if (maxgrid < 8) maxgrid = 8;
     const int grid = p.tiles < maxgrid ? p.tiles : maxgrid;
-    const size_t lds = 1024 + SF_LDS;
+    // fp32 channels-last image (stride_c 1, stride_w 3, rows and images dword-addressable from the image base with 32-bit offsets): the contiguous-run gather
+    const bool nhwc3 = in->dtype == FVIT_F32 && in->stride_c == 1 && in->stride_w == 3 && in->stride_h == 3 * (int64_t)Wi && (int64_t)Hi * Wi * 12 < 0x7fffff00 &&
+                       tune_get("stem_nhwc3", 1);
+    const size_t lds = 1024 + SF_LDS + (nhwc3 ? 4096 : 0);
     const double M1 = (double)B * p.H1 * p.W1, M2 = (double)B * p.H2 * p.W2;
     const double bytes = (double)B * 3 * Hi * Wi * (in->dtype == FVIT_F32 ? 4 : 2) + 2.0 * M2 * 64;
     ProfScope prof(FVIT_K_CONV, 2.0 * M1 * 64 * 27 + 2.0 * M2 * 64 * 576, bytes, (hipStream_t)stream);
@@ -1370,9 +1469,17 @@ static int stem_fused_impl(int32_t dtype, const FvitMapView* in, const void* w1,
             hipFuncSetAttribute((const void*)stem_fused_kernel<T_, IN_, TS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         hipLaunchKernelGGL((stem_fused_kernel<T_, IN_, TS_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);                      \
     } while (0)
+#define FVIT_STEM_LAUNCH4(T_, IN_, TS_, N3_)                                                                                             \
+    do {                                                                                                                                 \
+        static DeviceOnce once;                                                                                                          \
+        if (once.first_on_current_device())                                                                                              \
+            hipFuncSetAttribute((const void*)stem_fused_kernel<T_, IN_, TS_, N3_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((stem_fused_kernel<T_, IN_, TS_, N3_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);                  \
+    } while (0)
 #define FVIT_STEM_IN(T_)                                                                   \
     do {                                                                                   \
-        if (in->dtype == FVIT_F32) FVIT_STEM_LAUNCH(T_, float, false);                     \
+        if (nhwc3) FVIT_STEM_LAUNCH4(T_, float, false, true);                               \
+        else if (in->dtype == FVIT_F32) FVIT_STEM_LAUNCH(T_, float, false);                \
         else if (in->dtype == FVIT_F16) FVIT_STEM_LAUNCH(T_, _Float16, false);             \
         else if (in->dtype == FVIT_BF16) FVIT_STEM_LAUNCH(T_, __bf16, false);              \
         else { set_error("stem_fused: input dtype %d not supported", in->dtype); return FVIT_EINVAL; } \
@@ -1389,6 +1496,7 @@ static int stem_fused_impl(int32_t dtype, const FvitMapView* in, const void* w1,
         return FVIT_EINVAL;
     }
 #undef FVIT_STEM_IN
+#undef FVIT_STEM_LAUNCH4
 #undef FVIT_STEM_LAUNCH
     return check_launch("stem_fused_kernel");
 }

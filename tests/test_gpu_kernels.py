@@ -514,7 +514,9 @@ def test_stem_conv(dt, code, in_dt, fmt, B, H, W):
 
 @pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
 @pytest.mark.parametrize("in_dt,fmt,B,H,W", [(torch.float32, "nchw", 2, 224, 224), (torch.float16, "nhwc", 3, 64, 96), (torch.float32, "nchw", 1, 50, 38),
-                                            (torch.float32, "nhwc", 2, 36, 132), (torch.float32, "nchw", 5, 8, 8)])
+                                            (torch.float32, "nhwc", 2, 36, 132), (torch.float32, "nchw", 5, 8, 8),
+                                            # r06: fp32 channels-last takes the contiguous-run gather (buffer loads, re-ordered contraction): odd sizes = every border case
+                                            (torch.float32, "nhwc", 3, 51, 37), (torch.float32, "nhwc", 2, 224, 224), (torch.float32, "nhwc", 1, 7, 5)])
 def test_stem_fused(dt, code, in_dt, fmt, B, H, W):
     """Both PatchEmbed convs in one kernel (conv1 3->64 s2 + ReLU kept in LDS, conv2 64->64 s2 + ReLU) vs the two separate kernels
     (same 16-bit rounding of the intermediate) and vs PyTorch fp32."""
