@@ -82,13 +82,17 @@ def parse():
                     help="deploy mode: the two-term-stream conv plan (DeployPlan.precise); with --operand f16x3 the configuration that meets the ABSOLUTE "
                          "1e-3 bar on FasterViT-4 / any-res (the timed configuration of the secondary entries)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--streams", type=int, default=2, help="deploy mode: stream shards of the batch (fork / join inside the hipGraph)")
+    ap.add_argument("--streams", type=int, default=1, help="deploy mode: stream shards of the batch (fork / join inside the hipGraph); r05 default: 2 with --join-from 3 and --inflight 1")
     ap.add_argument("--shard-sizes", type=str, default="", help="comma list of images per stream shard (default: equal split)")
     ap.add_argument("--shard-launch", choices=["free", "forkjoin"], default="forkjoin",
                     help="'free' = one hipGraph per shard on its own stream, no join between steps (r01: slower); 'forkjoin' = one graph per step")
-    ap.add_argument("--join-from", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="deploy + hipGraph: whole-batch steps in flight (fastervit_amd.inference.PipelinedInference: step k replays runner k %% N on its own stream, "
+                         "so the tail of a step overlaps the front of the next one; 1 = one graph, steps strictly one after the other).  Default since r06: 2 steps in flight, "
+                         "whole-batch launches (--streams 1): +4..7 %% images/s over r05's 2 stream shards + join inside one graph, profiles/r06_steps_in_flight_ab.log")
+    ap.add_argument("--join-from", type=int, default=0,
                     help="deploy mode: shards run levels [0, L) on their streams, join, levels [L, end) run once on the whole batch (0: off). "
-                         "Default 3 + 2 shards (r04, A/B in one box x 3: 82.2-83.2k vs 80.2-81.8k images/s for 3 shards without the join: the last "
+                         "r04 / r05 default: 3 with 2 shards ( A/B in one box x 3: 82.2-83.2k vs 80.2-81.8k images/s for 3 shards without the join: the last "
                          "stage of FasterViT-0 is one 49-token window per image, 86-workgroup launches per shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline sample")
@@ -162,6 +166,11 @@ class Config:
                 self.runner.recompile()
             if self.streams > 1 and not a.no_graph and a.shard_launch == "free":
                 self.free_runner = self.plan.shard_runner(self.x, self.streams)
+            self.pipe = None
+            if getattr(a, "inflight", 1) > 1 and not a.no_graph and not sizes and self.free_runner is None:
+                from fastervit_amd.inference import PipelinedInference
+                self.pipe = PipelinedInference(self.model, self.x, depth=a.inflight, streams=self.streams, first=self.runner, dtype=self.conv_dt, join_from=jf,
+                                               precise=bool(getattr(a, "precise", False)))
             return
         self.model.auto_deploy = a.mode == "auto"
         for _ in range(2):
@@ -180,7 +189,22 @@ class Config:
                 self.static_y = self.eager(static_x)
             torch.cuda.synchronize()
 
+    def set_plan(self, **attrs):
+        """Plan options on every runner's plan (the pipelined form has one plan per runner)."""
+        plans = [r.plan for r in self.pipe.runners] if getattr(self, "pipe", None) is not None else ([self.plan] if self.plan is not None else [])
+        for pl in plans:
+            for k, v in attrs.items():
+                setattr(pl, k, v)
+
+    def recompile(self):
+        if getattr(self, "pipe", None) is not None:
+            self.pipe.recompile()
+        elif self.runner is not None:
+            self.runner.recompile()
+
     def step(self):
+        if getattr(self, "pipe", None) is not None:
+            return self.pipe.launch().static_y    # (valid after the next sync; the timed region syncs at its end)
         if self.free_runner is not None:
             self.free_runner.launch()
             return None
@@ -196,11 +220,25 @@ class Config:
         return self.eager(self.x)
 
     def logits(self):
+        if getattr(self, "pipe", None) is not None:
+            # every runner of the pipeline is checked: one more step each, then the element-wise WORST logits error is what parity sees
+            for _ in range(self.pipe.depth):
+                self.pipe.launch()
+            outs = [o.float().cpu() for o in self.pipe.outputs()]
+            for o in outs[1:]:
+                if not torch.equal(o, outs[0]):
+                    raise RuntimeError("pipelined runners disagree on the same input (they must be bitwise equal)")
+            return outs[0]
         out = self.free_runner.outputs() if self.free_runner is not None else self.step()
         torch.cuda.synchronize()
         return out.float().cpu()
 
     def launch_desc(self):
+        if getattr(self, "pipe", None) is not None:
+            jf = getattr(self.plan, "join_from", None)
+            return (f"hipGraph replay, {self.pipe.depth} whole-batch steps in flight (step k replays runner k % {self.pipe.depth} on its own stream; "
+                    f"fastervit_amd.inference.PipelinedInference), each {self.streams} stream shards (fork/join inside the graph)" +
+                    (f", level {jf}+ joined on the whole batch" if jf else ""))
         if self.free_runner is not None:
             return f"{self.streams} free-running stream shards, one hipGraph replay per shard and step"
         g = "eager" if (self.args.no_graph or (self.runner is None and self.graph is None)) else "hipGraph replay"
@@ -502,13 +540,18 @@ def run_secondary(args, dev):
     import copy
     from fastervit_amd import dp
     res = []
-    specs = [("faster_vit_4_224", 128, None, {}, 3, args.secondary_streams or 2),
-             ("faster_vit_4_any_res", 8, (576, 960), dict(resolution=[576, 960], window_size=[7, 7, 12, 6], ct_size=2), 2, args.secondary_streams or 2)]
-    for name, batch, hw, kw, nstreams_fast, nstreams in specs:
+    # (name, batch, image size, model kwargs, steps in flight of the 16-bit plan, steps in flight of the precise plan): r06, whole-batch launches (one stream shard)
+    # with 2 / 3 steps in flight -- call 12: FasterViT-4 3.34k -> 3.39k precise, 6.80k -> 7.02k 16-bit; any-res 275 -> 291 precise, 614 -> 657 16-bit images/s against
+    # r05's 2 / 3 stream shards inside one graph (--secondary-streams N > 0 restores that form with --inflight 1)
+    specs = [("faster_vit_4_224", 128, None, {}, 2, 2),
+             ("faster_vit_4_any_res", 8, (576, 960), dict(resolution=[576, 960], window_size=[7, 7, 12, 6], ct_size=2), 3, 3)]
+    for name, batch, hw, kw, inflight_fast, inflight_precise in specs:
+        nstreams = nstreams_fast = args.secondary_streams or 1
         t0 = time.perf_counter()
         try:
             a1 = copy.copy(args)
             a1.mode, a1.conv_dtype, a1.operand, a1.no_graph, a1.precise = "deploy", "f16", "f16x3", False, True
+            a1.inflight = inflight_precise if (args.inflight > 1 and not args.secondary_streams) else 1
             cfg = Config(a1, dev, 0, name, batch, hw=hw, model_kwargs=kw, streams=nstreams)
             cfg.prepare()
             elapsed = dp.timed_steps(cfg.step, args.secondary_steps, 3, torch.cuda.synchronize, None, dev)
@@ -537,7 +580,9 @@ def run_secondary(args, dev):
             torch.cuda.empty_cache()
             if arch is not None and not args.no_modes:
                 try:
-                    fc = Config(args, dev, 0, name, batch, hw=hw, model_kwargs=kw, streams=nstreams_fast)   # same seeds: same weights and input
+                    a2 = copy.copy(args)
+                    a2.inflight = inflight_fast if (args.inflight > 1 and not args.secondary_streams) else 1
+                    fc = Config(a2, dev, 0, name, batch, hw=hw, model_kwargs=kw, streams=nstreams_fast)   # same seeds: same weights and input
                     fc.prepare()
                     el2 = dp.timed_steps(fc.step, args.secondary_steps, 3, torch.cuda.synchronize, None, dev)
                     yp = fc.logits()
@@ -817,8 +862,7 @@ def main():
         for other in [m for m in OPERAND_MODES if m != args.operand and not args.no_modes]:
             try:
                 cfg.model.set_hat_operand_dtype(other)
-                if cfg.runner is not None:
-                    cfg.runner.recompile()
+                cfg.recompile()
                 # bf16x2 is BASELINE cfg 2's literal dtype under the bar: the FULL --steps / --warmup region (r06); the others a quarter of it
                 full = other == "bf16x2"
                 nrep, nwarm = (args.steps, args.warmup) if full else (max(5, args.steps // 4), 2)
@@ -843,8 +887,8 @@ def main():
                 key = f"parity_{mode_d}_down2"
                 try:
                     cfg.model.set_hat_operand_dtype(mode_d)
-                    cfg.plan.down_weight_terms, cfg.plan.sig = 2, None
-                    cfg.runner.recompile()
+                    cfg.set_plan(down_weight_terms=2, sig=None)
+                    cfg.recompile()
                     nrep, nwarm = (args.steps, args.warmup) if full else (max(5, args.steps // 4), 2)
                     el = dp.timed_steps(cfg.step, nrep, nwarm, torch.cuda.synchronize, None, dev)
                     y = cfg.logits()
@@ -858,9 +902,8 @@ def main():
                 except Exception as e:
                     out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
             cfg.model.set_hat_operand_dtype(args.operand)
-            cfg.plan.down_weight_terms, cfg.plan.sig = 1, None
-        if cfg.runner is not None:
-            cfg.runner.recompile()
+            cfg.set_plan(down_weight_terms=1, sig=None)
+        cfg.recompile()
         if cfg.runner is not None and cfg.plan is not None and not args.no_modes and headline:
             # north_star's "bf16", literally and with margin (r05): the PRECISE conv plan on bf16 planes + HAT operands bf16x3 -- bf16 MFMA operands everywhere, every
             # stream and weight as two bf16 terms -- in the timed launch structure (its own runner: the plan's plane dtype is fixed at compile time)

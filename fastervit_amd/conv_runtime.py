@@ -332,11 +332,14 @@ class DeployPlan:
     def _forward_sharded(self, x):
         n = self.streams
         if n <= 1 or x.shape[0] < 2 * n:
-            with hat_runtime.workspace_slot(0):
+            with hat_runtime.workspace_slot(getattr(self, "slot_base", 0)):
                 return self._forward_one(x)
         # the batch as n independent shards on n HIP streams (fork / join with events; capturable in a hipGraph): every kernel
         # of this pipeline runs its HBM-bound prologue / epilogue and its MFMA phase in lockstep across workgroups, so two
         # half-size pipelines interleave better than one full-size one
+        # slot_base (r06): first workspace slot of this plan; two plans whose forwards are in flight at the same time (inference.PipelinedInference:
+        # consecutive steps on alternating streams) must not share the per-(geometry, slot) stage workspaces
+        sb = getattr(self, "slot_base", 0)
         sizes = getattr(self, "shard_sizes", None)
         parts = x.split(list(sizes), dim=0) if sizes and sum(sizes) == x.shape[0] and len(sizes) == n else x.chunk(n, dim=0)
         outs = [None] * n
@@ -347,7 +350,7 @@ class DeployPlan:
         # The per-geometry index tables (an H2D copy) and workspaces are created lazily by the first stage call too: the forked form
         # is allowed only for a (device, shard sizes, image size, operand mode) that has completed one serial pass.
         ops = tuple(getattr(lvl, "hat_operand_dtype", "f16") for lvl in self.model.levels if lvl.transformer_block)
-        wkey = (str(x.device), tuple(p.shape[0] for p in parts), tuple(x.shape[1:]), ops, getattr(self, "join_from", None))
+        wkey = (str(x.device), tuple(p.shape[0] for p in parts), tuple(x.shape[1:]), ops, getattr(self, "join_from", None), sb)
         warm = self.__dict__.setdefault("_warm_geometries", set())
         serial = getattr(self, "serialize_shards", False) or not self._hat_prepared(x.device) or wkey not in warm
         # join_from = L (r04, ``plan.join_from``; None = off): the shards run levels [0, L) on their own streams, JOIN, and levels
@@ -366,9 +369,9 @@ class DeployPlan:
             # also the measurement aid of bench.py's HIP-event pass: the same shard-sized launches, one after the other on the
             # caller's stream, so that a kernel's event-pair duration is its own and not shared with the other shards' kernels
             for i in range(n):
-                with hat_runtime.workspace_slot(i):
+                with hat_runtime.workspace_slot(sb + i):
                     outs[i] = front(parts[i])
-            with hat_runtime.workspace_slot(0):
+            with hat_runtime.workspace_slot(sb):
                 y = back(outs)
             if not torch.cuda.is_current_stream_capturing():
                 warm.add(wkey)
@@ -378,13 +381,13 @@ class DeployPlan:
         main = torch.cuda.current_stream(x.device)
         for i, s in enumerate(self.side):
             s.wait_stream(main)
-            with torch.cuda.stream(s), hat_runtime.workspace_slot(i + 1):
+            with torch.cuda.stream(s), hat_runtime.workspace_slot(sb + i + 1):
                 outs[i + 1] = front(parts[i + 1])
-        with hat_runtime.workspace_slot(0):
+        with hat_runtime.workspace_slot(sb):
             outs[0] = front(parts[0])
         for s in self.side:
             main.wait_stream(s)   # join: everything the caller enqueues next (the cat below, its own later work) is ordered after the shards
-        with hat_runtime.workspace_slot(0):
+        with hat_runtime.workspace_slot(sb):
             return back(outs)
 
     def shard_runner(self, x, n=None):

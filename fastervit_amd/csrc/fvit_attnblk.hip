@@ -462,6 +462,8 @@ int launch_attnblk(const AttnBlkCall& c, hipStream_t stream) {
     ProfScope prof(FVIT_K_ATTN_FUSED, flops, bytes, stream);
     prof_note(c.C == 256 ? (c.S <= 16 ? "attnblk_kernel<256,S16>" : "attnblk_kernel<256,S64>") : "attnblk_kernel<512,S64>", c.nwin);
     const bool small = c.S <= 16;
+    // r06: stage-2 windows, one weight term: the wave-per-(window, head) cut (fvit_attnblk2.hip); fvit_tune("ab_variant", 0 / 1 / 2) restores the forms below
+    if (attnblk2_supported(c.C, c.heads, c.S) && c.terms == 1 && tune_get("ab_variant", 0) == 3) return launch_attnblk2(c, stream);
     if (c.terms != 1 && (c.terms != 2 || c.C != 256 || small)) {
         set_error("attn_block: weight terms %d at C=%d S=%d (two terms: C = 256, 48 < S <= 64 only)", c.terms, c.C, c.S);
         return FVIT_EINVAL;

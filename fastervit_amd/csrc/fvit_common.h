@@ -398,6 +398,9 @@ struct AttnBlkCall {
 };
 bool attnblk_supported(int C, int heads, int S);
 int launch_attnblk(const AttnBlkCall& c, hipStream_t stream);
+// r06: the same contract for C = 256 / 8 heads / 49..64-token windows with a wave per (window, head) (fvit_attnblk2.hip); launch_attnblk dispatches to it
+bool attnblk2_supported(int C, int heads, int S);
+int launch_attnblk2(const AttnBlkCall& c, hipStream_t stream);
 // same contract for C = 512 / 16 heads, one 49..64-token window per workgroup, waves split heads / output channels (fvit_winblk.hip)
 bool winblk_supported(int C, int heads, int S);
 int launch_winblk(const AttnBlkCall& c, hipStream_t stream);

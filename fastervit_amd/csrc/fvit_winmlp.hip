@@ -512,11 +512,14 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     // C = 256 (stage 2): 4 waves x 64 rows, 68 KiB of LDS, two workgroups per CU.  (r02 / r03 also measured 8 waves x 128 rows -- no gain -- and 8 waves x 80 / 96 rows:
     // the launch 24 % shorter, 50.4 -> 38.2 us, and the STEP 1.5 % slower, 124 KiB of LDS and 8 x 200 registers take the whole CU from the other stream shard's kernels;
     // fvit_tune "win_mlp256" = 1 / 3.  Not instantiated since r06: git history, profiles/HISTORY.md.)
-    const int rows_per_wg = 64;
+    // r06, whole-batch launches with two steps in flight (inference.PipelinedInference): the 8-wave x 128-row form again behind fvit_tune "win_mlp256" = 1
+    // (every weight fragment feeds 8 MFMAs, half the L2 -> CU weight stream per row; one 133-KiB workgroup per CU)
+    const bool wide256 = c.C == 256 && tune_get("win_mlp256", 2) == 1 && !c.ts;
+    const int rows_per_wg = wide256 ? 128 : 64;
     const int nrg = (c.M + rows_per_wg - 1) / rows_per_wg;
     const int grid = nsplit > 1 ? (nrg + 7) / 8 * 8 * nsplit : nrg;
     prof_note(c.C == 512 ? (nsplit == 2 ? "winmlp_kernel<512,split2>" : "winmlp_kernel<512>")
-                         : "winmlp_kernel<256>", grid);
+                         : (wide256 ? "winmlp_kernel<256,128rows>" : "winmlp_kernel<256>"), grid);
     if (c.dtype != FVIT_F16 && c.dtype != FVIT_BF16) { set_error("win_mlp: operand dtype %d not supported", c.dtype); return FVIT_EINVAL; }
     if (c.terms != 1 && c.terms != 2) { set_error("win_mlp: weight terms %d not supported", c.terms); return FVIT_EINVAL; }
 #define FVIT_WINMLP(T, CC_, HID_, NRB_, NWV_, SP_) \
@@ -555,6 +558,7 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     // (a 4-deep ring for C = 512 needs 105 spilled registers at 8 waves x 256: not instantiated)
     else if (c.C == 512 && pipe) FVIT_WINMLP_PT(512, 2048, 4, 8);
     else if (c.C == 512) FVIT_WINMLP_T(512, 2048, 4, 8);
+    else if (wide256) FVIT_WINMLP_T(256, 1024, 8, 8);
     else FVIT_WINMLP_T(256, 1024, 4, 4);
 #undef FVIT_WINMLP_ST
 #undef FVIT_WINMLP_S

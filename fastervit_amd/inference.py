@@ -28,7 +28,7 @@ class CompiledInference:
     """
 
     def __init__(self, model, example: torch.Tensor, dtype=torch.float16, streams: int = 3, graph: bool = True, join_from=None,
-                 conv_down_terms: Optional[int] = None, precise: Optional[bool] = None):
+                 conv_down_terms: Optional[int] = None, precise: Optional[bool] = None, slot_base: int = 0):
         if not example.is_cuda:
             raise RuntimeError("compile_inference: the example input must be on a HIP device (no CPU fallback)")
         if model.training:
@@ -41,6 +41,7 @@ class CompiledInference:
         # join_from = L: the shards run levels [0, L) on their streams, join, and levels [L, end) + head run once on the whole batch
         # (DeployPlan._forward_sharded).  FasterViT-0 at batch 256: streams = 2, join_from = 3 is the measured optimum (bench.py)
         self.plan.join_from = join_from
+        self.plan.slot_base = int(slot_base)   # first stage-workspace slot of this runner (PipelinedInference: one range of slots per runner in flight)
         # precise = True: two-term / fp32 streams and two-term weights on the conv side (DeployPlan.precise); with the HAT operand mode "f16x3"
         # (model.set_hat_operand_dtype) the configuration that meets logits max-abs < 1e-3 ABSOLUTE on FasterViT-4 / any-res
         # (None keeps DeployPlan's default, i.e. the FVIT_PRECISE_DEPLOY environment switch, like conv_down_terms below)
@@ -94,6 +95,55 @@ class CompiledInference:
             else:
                 self.static_y = self.plan.forward(self.static_x)
         return self.static_y[:n]
+
+
+class PipelinedInference:
+    """Throughput form of ``CompiledInference`` (r06): ``depth`` runners of the SAME compiled configuration (stream shards + join inside one hipGraph
+    each), every one with its own static buffers and stage-workspace slots; step k replays runner k % depth on ITS stream, so up to ``depth`` whole-batch
+    steps are in flight and the tail of step k (stage 3 on one stream, the join, the head) overlaps the stem / conv levels of step k + 1.  Every step
+    still runs the whole forward on its whole batch and leaves its logits in its runner's static output; ``wait()`` joins all streams.
+    Images are independent in eval mode: there is no data hazard between steps, only shared read-only packed weights."""
+
+    def __init__(self, model, example: torch.Tensor, depth: int = 2, streams: int = 1, first: Optional[CompiledInference] = None, **kw):
+        self.depth = max(1, int(depth))
+        # ``first``: an existing runner of the same configuration (slot base 0) to use as runner 0
+        self.runners = ([first] if first is not None else []) + \
+            [CompiledInference(model, example, streams=streams, slot_base=i * max(1, int(streams)), **kw) for i in range(1 if first is not None else 0, self.depth)]
+        self.device = example.device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        self._k = 0
+
+    def set_input(self, x: torch.Tensor):
+        for r in self.runners:
+            r.static_x.copy_(x, non_blocking=True)
+        torch.cuda.synchronize(self.device)
+
+    def launch(self):
+        """Enqueue one whole-batch step (no host sync); returns the runner whose static output will hold its logits."""
+        i = self._k % self.depth
+        self._k += 1
+        r = self.runners[i]
+        with torch.no_grad(), torch.cuda.stream(self.streams[i]):
+            if r.graph is not None:
+                r.graph.replay()
+            else:
+                r.static_y = r.plan.forward(r.static_x)
+        return r
+
+    def recompile(self):
+        """Re-capture every runner (after a weight update or a change of the operand mode / plan options)."""
+        self.wait()
+        for r in self.runners:
+            r.recompile()
+
+    def wait(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def outputs(self):
+        """Logits of the last step of every runner, in runner order (after ``wait``)."""
+        self.wait()
+        return [r.static_y for r in self.runners]
 
 
 def accuracy_counts(logits: torch.Tensor, target: torch.Tensor, topk=(1, 5)) -> Tuple[int, ...]:

@@ -569,6 +569,16 @@ class FasterViT(nn.Module):
         return CompiledInference(self, example, dtype=dtype, streams=streams, graph=graph, join_from=join_from, conv_down_terms=conv_down_terms,
                                  precise=precise)
 
+    def pipelined_inference(self, example: torch.Tensor, depth: int = 2, dtype=torch.float16, streams: int = 1, graph: bool = True, join_from=None,
+                            conv_down_terms=None, precise: bool = False):
+        """Throughput entry point with ``depth`` whole-batch steps in flight (r06; what ``bench.py`` times): ``depth`` runners of ``compile_inference``'s
+        configuration, step k replayed on stream k % depth, so the tail of a step (last stage, head) overlaps the stem / conv levels of the next one.
+        ``p.launch()`` enqueues one step and returns its runner (logits in ``runner.static_y`` after ``p.wait()``).  See
+        ``fastervit_amd.inference.PipelinedInference``."""
+        from ..inference import PipelinedInference
+        return PipelinedInference(self, example, depth=depth, streams=streams, dtype=dtype, graph=graph, join_from=join_from, conv_down_terms=conv_down_terms,
+                                  precise=precise)
+
     def enable_hat_backward(self, on: bool = True):
         """Make the transformer stages differentiable in EVAL mode: with grad enabled every HAT stage becomes ONE autograd node whose forward is the HIP
         inference path and whose backward is the kernel sequence of ``fastervit_amd.hat_backward`` (head_dim <= 96, windows and carrier grids of at most

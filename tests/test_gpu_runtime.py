@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from fastervit_amd import hat_runtime
-from fastervit_amd.inference import CompiledInference, accuracy_counts, evaluate
+from fastervit_amd.inference import CompiledInference, PipelinedInference, accuracy_counts, evaluate
 from oracle.model_reference import model_forward
 from tests.cases import CASES
 from tests.util import build_product_model, case_input, load_golden, max_abs
@@ -57,6 +57,44 @@ def test_bench_configuration_every_shard_vs_oracle(streams, join_from, sizes):
     # a shorter batch through the same graph: zero-padded, sliced
     y40 = runner(x[:40]).float().cpu()
     assert y40.shape == (40, 1000) and max_abs(y40, y[:40]) < 2e-4
+
+
+@pytest.mark.parametrize("depth,streams,join_from", [(2, 1, None), (3, 1, None), (2, 2, 3)], ids=["timed-2-in-flight", "3-in-flight", "2-in-flight-2shards-join3"])
+def test_pipelined_steps_in_flight_vs_oracle(depth, streams, join_from):
+    """The configuration bench.py TIMES since r06 -- deploy plan, fp16, batch 256 as whole-batch launches, TWO steps in flight on two streams (one hipGraph
+    with its own static buffers and stage-workspace slots per runner) -- checked against the fp32 CPU oracle on 16 images of every runner's output after a
+    burst of back-to-back launches; all runners bitwise equal to each other and to the single-runner graph (a shared workspace between two steps in flight
+    would show here), and different inputs in flight at the same time keep their own results."""
+    model, sd = build_product_model("fvit0_224", "cuda")
+    model = model.to(memory_format=torch.channels_last)
+    g = torch.Generator(device="cpu").manual_seed(1000)
+    x_cpu = torch.randn(256, 3, 224, 224, generator=g)
+    x = x_cpu.cuda().contiguous(memory_format=torch.channels_last)
+    pipe = model.pipelined_inference(x, depth=depth, dtype=torch.float16, streams=streams, join_from=join_from)
+    assert isinstance(pipe, PipelinedInference) and len(pipe.runners) == depth and all(r.graph is not None for r in pipe.runners)
+    assert sorted(r.plan.slot_base for r in pipe.runners) == [i * streams for i in range(depth)]
+    for _ in range(4 * depth + 1):          # a burst: steps overlap on the GPU
+        pipe.launch()
+    outs = [o.float().cpu().clone() for o in pipe.outputs()]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    single = model.compile_inference(x, dtype=torch.float16, streams=streams, join_from=join_from)
+    assert torch.equal(single(x).float().cpu(), outs[0])
+    assert _native_loaded()
+    idx = list(range(3, 11)) + list(range(131, 139))
+    ref = model_forward(sd, x_cpu[idx], CASES["fvit0_224"]["arch"])
+    err = max_abs(outs[0][idx], ref)
+    print(f"pipelined depth={depth} streams={streams} join_from={join_from}: logits max-abs err {err:.3e} (|logits| max {ref.abs().max():.3f})")
+    assert err < 1e-3
+    # two DIFFERENT batches in flight: runner 1 gets the reversed batch while runner 0 keeps x
+    pipe.wait()
+    pipe.runners[1].static_x.copy_(x.flip(0))
+    torch.cuda.synchronize()
+    pipe._k = 0
+    for _ in range(2 * depth):
+        pipe.launch()
+    o2 = [o.float().cpu() for o in pipe.outputs()]
+    assert torch.equal(o2[0], outs[0]) and max_abs(o2[1], outs[0].flip(0)) < 2e-4   # (an image's rows sit in other tiles: same values to rounding order)
 
 
 def test_compiled_inference_rejects_wrong_inputs():
