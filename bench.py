@@ -249,6 +249,25 @@ class Config:
 
 def step_dispersion(cfg, n):
     """min / median / max over n individually timed steps (event pair per step; not the throughput measurement)."""
+    pipe = getattr(cfg, "pipe", None)
+    if pipe is not None:
+        # steps in flight: a step's LATENCY is the time from its first to its last kernel on its runner's stream, with the other steps' kernels beside it
+        # (about `depth` x the throughput step time); the event pair is recorded on that stream
+        evs = []
+        torch.cuda.synchronize()
+        for _ in range(n):
+            i = pipe._k % pipe.depth
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(pipe.streams[i]):
+                a.record()
+            cfg.step()
+            with torch.cuda.stream(pipe.streams[i]):
+                b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)
+        return {"n": n, "min": round(ms[0], 4), "median": round(statistics.median(ms), 4), "max": round(ms[-1], 4),
+                "note": f"LATENCY of a step with {pipe.depth} steps in flight (event pair on the step's own stream); throughput = ms_per_step"}
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     torch.cuda.synchronize()
     for a, b in evs:

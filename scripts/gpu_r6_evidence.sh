@@ -42,10 +42,10 @@ run_cfg() {   # name, bench args: kernel-trace stats only
   python $R/scripts/summarize_rocprof_db.py $DB $R/gpurun_out/${T}_${N}_rocprof >> $R/$S 2>&1
 }
 KW="{'resolution':[576,960],'window_size':[7,7,12,6],'ct_size':2}"
-run_cfg faster_vit_4_224_precise --model faster_vit_4_224 --batch 128 --streams 2 --join-from 0 --operand f16x3 --precise
-run_cfg faster_vit_4_any_res_precise --model faster_vit_4_any_res --batch 8 --input-size 576x960 --model-kwargs "$KW" --streams 2 --join-from 0 --operand f16x3 --precise
-run_cfg faster_vit_4_224_fast --model faster_vit_4_224 --batch 128 --streams 3 --join-from 0
-CMD4="python $R/bench.py --model faster_vit_4_224 --batch 128 --streams 2 --join-from 0 --operand f16x3 --precise --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-modes --no-train-step --no-graph --prof-steps 0"
+run_cfg faster_vit_4_224_precise --model faster_vit_4_224 --batch 128 --streams 1 --join-from 0 --operand f16x3 --precise
+run_cfg faster_vit_4_any_res_precise --model faster_vit_4_any_res --batch 8 --input-size 576x960 --model-kwargs "$KW" --streams 1 --join-from 0 --operand f16x3 --precise
+run_cfg faster_vit_4_224_fast --model faster_vit_4_224 --batch 128 --streams 1 --join-from 0
+CMD4="python $R/bench.py --model faster_vit_4_224 --batch 128 --streams 1 --join-from 0 --operand f16x3 --precise --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-modes --no-train-step --no-graph --prof-steps 0"
 timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/${T}_f4fetch -o p -- $CMD4 > /tmp/${T}_f4fetch.log 2>&1
 echo "pmc fetch (FasterViT-4 precise) rc=$?" >> $R/$S
 timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/${T}_f4write -o p -- $CMD4 > /tmp/${T}_f4write.log 2>&1

@@ -656,6 +656,23 @@ def test_attn_block_fused(opname, dt, code, S, nwin, use_tables, use_gamma, C):
     if out_win is not None:
         assert torch.isfinite(out_win).all()
         assert (out_win - ref).abs().max().item() < tol, f"win_block: {(out_win - ref).abs().max().item()} vs {tol}"
+    if S > 48 and C == 256:   # r06: the wave-per-(window, head) cut (fvit_attnblk2.hip) behind fvit_tune "ab_variant" = 3, one and two windows per workgroup
+        try:
+            for nw in (1, 2):
+                _lib.tune("ab_variant", 3)
+                _lib.tune("ab2_nwin", nw)
+                o3 = torch.full((rows, C), float("nan"), device="cuda")
+                _lib.check(lib.fvit_attn_block_fused(*args, o3.data_ptr(), nwin, S, heads, C, ctypes.c_float(scale), _stream()), "attn_block_fused (attnblk2)")
+                torch.cuda.synchronize()
+                assert torch.isfinite(o3).all()
+                assert (o3 - ref).abs().max().item() < tol, f"attnblk2 nwin={nw}: {(o3 - ref).abs().max().item()} vs {tol}"
+                o4 = torch.full((rows, C), float("nan"), device="cuda")
+                _lib.check(lib.fvit_attn_block_fused(*args, o4.data_ptr(), nwin, S, heads, C, ctypes.c_float(scale), _stream()), "attn_block_fused (attnblk2)")
+                torch.cuda.synchronize()
+                assert torch.equal(o3, o4)   # fixed reduction order: bitwise repeatable
+        finally:
+            _lib.tune("ab_variant", 0)
+            _lib.tune("ab2_nwin", 1)
     if S > 48 and C == 512:   # r03: the 16 heads split over two sibling workgroups that meet in L2 (last-arriver reduction in split order)
         slab = torch.full((nwin * 2 * 64 * C,), float("nan"), device="cuda")
         cnt = torch.zeros(nwin, dtype=torch.int32, device="cuda")
