@@ -90,6 +90,9 @@ def parse():
                     help="deploy + hipGraph: whole-batch steps in flight (fastervit_amd.inference.PipelinedInference: step k replays runner k %% N on its own stream, "
                          "so the tail of a step overlaps the front of the next one; 1 = one graph, steps strictly one after the other).  Default since r06: 2 steps in flight, "
                          "whole-batch launches (--streams 1): +4..7 %% images/s over r05's 2 stream shards + join inside one graph, profiles/r06_steps_in_flight_ab.log")
+    ap.add_argument("--cu-mask", default="", choices=["", "halves", "interleaved", "xcd"],
+                    help="experiment: the steps in flight on CU-masked streams (hipExtStreamCreateWithCUMask): halves = CU bits [0,128) / [128,256); interleaved = even / odd bits; "
+                         "xcd = bits with (i % 8) < 4 / >= 4")
     ap.add_argument("--join-from", type=int, default=0,
                     help="deploy mode: shards run levels [0, L) on their streams, join, levels [L, end) run once on the whole batch (0: off). "
                          "r04 / r05 default: 3 with 2 shards ( A/B in one box x 3: 82.2-83.2k vs 80.2-81.8k images/s for 3 shards without the join: the last "
@@ -169,8 +172,14 @@ class Config:
             self.pipe = None
             if getattr(a, "inflight", 1) > 1 and not a.no_graph and not sizes and self.free_runner is None:
                 from fastervit_amd.inference import PipelinedInference
-                self.pipe = PipelinedInference(self.model, self.x, depth=a.inflight, streams=self.streams, first=self.runner, dtype=self.conv_dt, join_from=jf,
-                                               precise=bool(getattr(a, "precise", False)))
+                masks = None
+                if getattr(a, "cu_mask", "") and a.inflight == 2:
+                    def words(pred):
+                        return [sum((1 << b) for b in range(32) if pred(32 * w + b)) for w in range(8)]
+                    sel = {"halves": lambda i: i < 128, "interleaved": lambda i: i % 2 == 0, "xcd": lambda i: (i % 8) < 4}[a.cu_mask]
+                    masks = [words(sel), words(lambda i: not sel(i))]
+                self.pipe = PipelinedInference(self.model, self.x, depth=a.inflight, streams=self.streams, first=self.runner, cu_masks=masks, dtype=self.conv_dt,
+                                               join_from=jf, precise=bool(getattr(a, "precise", False)))
             return
         self.model.auto_deploy = a.mode == "auto"
         for _ in range(2):

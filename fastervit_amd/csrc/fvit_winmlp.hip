@@ -71,9 +71,11 @@ __device__ __forceinline__ void stamp(const WinMlpParams& p, int wave, int lane,
 // anybody (no spin: placement- and residency-independent).  Sibling workgroups get block ids that differ by a multiple of 8 (same XCD
 // under the observed round-robin dispatch): their partials and the rows they all read stay in one L2 (speed only, never correctness).
 // LDS bytes of a workgroup: XN (NRB x C / 32 KiB), H (single or double buffered, see HBUF below), the fc1 bias
+// one workgroup per CU (all of its LDS, one or two waves per SIMD): the 8-wave forms, and (r06 experiment) 4 waves x 128 rows with up to 512 registers per wave
+constexpr bool winmlp_one_per_cu(int NWV, int NRB) { return NWV == 8 || NRB == 8; }
 template <int CC, int HID, int NRB, int NWV>
 constexpr int winmlp_lds_bytes() {
-    constexpr int hbuf = (NRB * (CC / 32) + 2 * NWV * NRB) * 1024 + HID * 4 <= (NWV == 8 ? 150 : 72) * 1024 ? 2 : 1;
+    constexpr int hbuf = (NRB * (CC / 32) + 2 * NWV * NRB) * 1024 + HID * 4 <= (winmlp_one_per_cu(NWV, NRB) ? 150 : 72) * 1024 ? 2 : 1;
     return NRB * (CC / 32) * 1024 + hbuf * NWV * NRB * 1024 + HID * 4;
 }
 
@@ -95,7 +97,7 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
     static_assert(SPS % DEPTH == 0, "ring slots must be static inside the super-chunk loop");
     constexpr bool LN_EVEN = NW % NRB == 0;        // else (NRB = 5 / 6 with 8 waves): waves 0 .. NRB - 1 take one whole row block each in phase A
     constexpr int WPR = LN_EVEN ? NW / NRB : 1;    // waves sharing a row block in the LayerNorm phase (2 / 1)
-    constexpr int HBUF = (NRB * KK + 2 * NW * NRB) * 1024 + HID * 4 <= (NW == 8 ? 150 : 72) * 1024 ? 2 : 1;   // H double-buffered when it fits
+    constexpr int HBUF = (NRB * KK + 2 * NW * NRB) * 1024 + HID * 4 <= (winmlp_one_per_cu(NW, NRB) ? 150 : 72) * 1024 ? 2 : 1;   // H double-buffered when it fits
     constexpr int OFF_H = NRB * KK * 1024;         // XN: 64 KiB; H: HBUF x NW x NRB KiB; fc1 bias
     constexpr int OFF_B1 = OFF_H + HBUF * NW * NRB * 1024;
     static_assert(OFF_B1 + HID * 4 == winmlp_lds_bytes<CC, HID, NRB, NWV>(), "LDS layout");
@@ -150,8 +152,8 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
     // inside the chunk loops would queue behind the ring's prefetches and drain it); its LDS write used to sit BEFORE the row loads were even
     // requested: one memory round trip (3.8 us at C = 512, profiles/r03_winmlp_phase_timeline.log) in front of the prologue.
     constexpr int NT = 64 * NW;
-    const bool ln_wave = LN_EVEN || wave < NRB;
-    const int ln_rb = LN_EVEN ? wave / WPR : (wave < NRB ? wave : 0), ln_part = LN_EVEN ? wave % WPR : 0;
+    // (r06: NRB > NW -- four waves x 128 rows -- takes ceil(NRB / NW) passes: wave w normalises row blocks w, w + NW, ...)
+    constexpr int NPASS = LN_EVEN ? 1 : (NRB + NW - 1) / NW;
     float c1[HID / NT];
 #pragma unroll
     for (int i = 0; i < HID / NT; ++i) c1[i] = p.b1[tid + NT * i];
@@ -159,6 +161,11 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
 #pragma unroll
     for (int t = 0; t < DEPTH; ++t) issue(0, t, t);
     in_loop = true;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+    const int ln_rb_raw = LN_EVEN ? wave / WPR : ps * NW + wave;
+    const bool ln_wave = LN_EVEN || ln_rb_raw < NRB;
+    const int ln_rb = ln_wave ? ln_rb_raw : 0, ln_part = LN_EVEN ? wave % WPR : 0;
     f4 v[2 * KK];
     {
         const int row = min(row0 + ln_rb * 16 + s, p.M - 1);
@@ -169,9 +176,11 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (ps == 0) {
 #pragma unroll
-    for (int i = 0; i < HID / NT; ++i) b1s[tid + NT * i] = c1[i];
-    stamp<TS>(p, wave, lane, NWV, 1);
+        for (int i = 0; i < HID / NT; ++i) b1s[tid + NT * i] = c1[i];
+        stamp<TS>(p, wave, lane, NWV, 1);
+    }
     if (ln_wave) {
         constexpr int KP = KK / WPR;
         const int rb = ln_rb, part = ln_part;
@@ -179,7 +188,7 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
 #pragma unroll
         for (int i = 0; i < 2 * KK; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         sum = sum_xor32(sum_xor16(sum));
-        stamp<TS>(p, wave, lane, NWV, 2);
+        if (ps == 0) stamp<TS>(p, wave, lane, NWV, 2);
         const float mean = sum / (float)C;
         float sq = 0.f;
 #pragma unroll
@@ -207,6 +216,7 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
             }
             *(v8*)(smem + ((rb * KK + k8 + part * KP) * 1024) + lane16) = o;
         }
+    }
     }
     __syncthreads();
     stamp<TS>(p, wave, lane, NWV, 3);
@@ -476,7 +486,7 @@ __device__ __forceinline__ void winmlp_body(const WinMlpParams& p, char* const s
 }
 
 template <typename T, int CC, int HID, int NRB, int DEPTH, int NWV = 8, int SP = 1, int NSPLIT = 1, bool TS = false, bool PIPE = false>
-__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void winmlp_kernel(WinMlpParams p) {
+__global__ __launch_bounds__(64 * NWV, winmlp_one_per_cu(NWV, NRB) ? 1 : 2) void winmlp_kernel(WinMlpParams p) {
     __shared__ __attribute__((aligned(16))) char smem[winmlp_lds_bytes<CC, HID, NRB, NWV>()];
     winmlp_body<T, CC, HID, NRB, DEPTH, NWV, SP, NSPLIT, TS, PIPE>(p, smem, blockIdx.x);
 }
@@ -514,7 +524,11 @@ int launch_winmlp(const MlpFusedCall& c, hipStream_t stream) {
     // fvit_tune "win_mlp256" = 1 / 3.  Not instantiated since r06: git history, profiles/HISTORY.md.)
     // r06, whole-batch launches with two steps in flight (inference.PipelinedInference): the 8-wave x 128-row form again behind fvit_tune "win_mlp256" = 1
     // (every weight fragment feeds 8 MFMAs, half the L2 -> CU weight stream per row; one 133-KiB workgroup per CU)
-    const bool wide256 = c.C == 256 && tune_get("win_mlp256", 2) == 1 && !c.ts;
+    // (r06 also measured FOUR waves x 128 rows -- one workgroup per CU, ONE wave per SIMD, up to 512 registers; weight ring 2 / 4 deep, plain / pipelined loop: the template
+    // takes NRB = 8, NWV = 4 since then -- at 126-134 us per whole-batch launch against 97-99 us for the default and 106-108 us for the 8-wave form: halving the L2 -> CU
+    // weight stream buys nothing when one wave per SIMD has to hide every latency by itself; profiles/r06_steps_in_flight_ab.log, call 17.  Not instantiated.)
+    const int form256 = c.C == 256 && !c.ts ? tune_get("win_mlp256", 2) : 2;
+    const bool wide256 = form256 == 1;
     const int rows_per_wg = wide256 ? 128 : 64;
     const int nrg = (c.M + rows_per_wg - 1) / rows_per_wg;
     const int grid = nsplit > 1 ? (nrg + 7) / 8 * 8 * nsplit : nrg;

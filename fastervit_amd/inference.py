@@ -97,6 +97,19 @@ class CompiledInference:
         return self.static_y[:n]
 
 
+def _masked_stream(device, mask_words):
+    """A HIP stream restricted to the CUs of ``mask_words`` (hipExtStreamCreateWithCUMask), wrapped for PyTorch."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    arr = (ctypes.c_uint32 * len(mask_words))(*[int(w) & 0xffffffff for w in mask_words])
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(len(mask_words)), arr)
+    if rc != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 class PipelinedInference:
     """Throughput form of ``CompiledInference`` (r06): ``depth`` runners of the SAME compiled configuration (stream shards + join inside one hipGraph
     each), every one with its own static buffers and stage-workspace slots; step k replays runner k % depth on ITS stream, so up to ``depth`` whole-batch
@@ -104,13 +117,20 @@ class PipelinedInference:
     still runs the whole forward on its whole batch and leaves its logits in its runner's static output; ``wait()`` joins all streams.
     Images are independent in eval mode: there is no data hazard between steps, only shared read-only packed weights."""
 
-    def __init__(self, model, example: torch.Tensor, depth: int = 2, streams: int = 1, first: Optional[CompiledInference] = None, **kw):
+    def __init__(self, model, example: torch.Tensor, depth: int = 2, streams: int = 1, first: Optional[CompiledInference] = None, cu_masks=None, **kw):
         self.depth = max(1, int(depth))
         # ``first``: an existing runner of the same configuration (slot base 0) to use as runner 0
         self.runners = ([first] if first is not None else []) + \
             [CompiledInference(model, example, streams=streams, slot_base=i * max(1, int(streams)), **kw) for i in range(1 if first is not None else 0, self.depth)]
         self.device = example.device
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        # cu_masks (experiment, r06): one CU bit mask (list of uint32 words, bit i = CU i of the runtime's numbering) per runner: its replays go to a stream created
+        # with hipExtStreamCreateWithCUMask, i.e. the steps in flight are partitioned in SPACE (each on its own CUs) instead of sharing every CU in time
+        if cu_masks:
+            self.streams = [_masked_stream(self.device, m) for m in cu_masks]
+            if len(self.streams) != self.depth:
+                raise ValueError("PipelinedInference: one CU mask per runner")
+        else:
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
         self._k = 0
 
     def set_input(self, x: torch.Tensor):
