@@ -182,7 +182,7 @@ def test_committed_pmc_traffic_file_covers_the_default_kernels():
     for fam in ("winmlp_kernel", "attnblk_kernel", "ctblk8_kernel", "winblk_kernel", "conv3x3_kernel", "conv3x3_c64_halo_kernel", "conv3x3_c128_band_kernel",
                 "stem_fused_kernel"):
         assert fam in fams, f"{bench.PMC_FILE} has no row of {fam}: re-run scripts/gpu_r2_evidence.sh and copy the new file"
-    dom = [r for r in rows if r["kernel"].startswith("winmlp_kernel<f16,256") and r["workgroups"] == 424]   # 128-image shards (r04: 2 stream shards)
+    dom = [r for r in rows if r["kernel"].startswith("winmlp_kernel<f16,256") and r["workgroups"] == 848]   # whole-batch launches (r06: two steps in flight; r04 / r05: 424 = 128-image shards)
     assert dom and dom[0]["hbm_traffic_mb"] > 0
 
 
