@@ -621,9 +621,12 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     p.slab = nullptr;
     p.arow_max = (c.M + 127) / 128 * 128 - 1;
     p.wrow_max = (c.N + 127) / 128 * 128 - 1;
-    // 256 x 256 tiles once they fill the chip (fvit_tune "gemm256_min_tiles"; 0 = never): the large Linear layers of FasterViT-4
+    // 256 x 256 tiles once there are enough of them (fvit_tune "gemm256_min_tiles"; 0 = never): the large Linear layers of FasterViT-4.  192 (r03-r05: a chip-filling
+    // launch beside two other stream shards) -> 96 in r06: with whole-batch launches and two steps in flight a half-filling 256-tile launch beats the 128-tile one
+    // (scripts/r06_calls/call19.sh, two interleaved rounds: FasterViT-4 7.05k -> 7.15k 16-bit / 3.37k -> 3.43k precise, any-res 293 -> 298 precise; 64 = 96, 32 slightly worse).
+    // Bitwise the 128 x 128 tile's result (tests/test_gpu_kernels.py).
     const int t256 = ((c.M + 255) / 256) * ((c.N + 255) / 256);
-    const int min256 = tune_get("gemm256_min_tiles", 192);
+    const int min256 = tune_get("gemm256_min_tiles", 96);
     const bool big = min256 > 0 && t256 >= min256 && p.K / BK >= 4;
     p.tiles_n = big ? (c.N + 255) / 256 : (c.N + BN - 1) / BN;
     p.stagger = tune_get("gemm_stagger", 0);
