@@ -22,6 +22,9 @@
 //   phase 2   ONE barrier, then wave w computes output channels [64w, 64w + 64) of all 128 rows: proj weights (32 KiB per wave) straight
 //             from L2, O fragments from LDS (each feeds 4 MFMAs), the residual rows re-read from L2 / MALL under the MFMAs.
 //   No barrier and no LDS-DMA inside the head loop; 1152 MFMAs per wave between three workgroup barriers.
+// In place (x_out == srcA, as the stage runner calls it): phase 2 gathers the residual rows a SECOND time, so a row's source must be the row itself or a row of srcB
+// (true for the stage tables: local rows map to themselves, carrier rows come from the carrier buffer) -- the same contract as the C = 512 instances of
+// attnblk_kernel / winblk_kernel, which re-gather in their epilogues too.
 #include "fvit_common.h"
 #include <type_traits>
 

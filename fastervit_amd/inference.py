@@ -120,6 +120,8 @@ class PipelinedInference:
     def __init__(self, model, example: torch.Tensor, depth: int = 2, streams: int = 1, first: Optional[CompiledInference] = None, cu_masks=None, **kw):
         self.depth = max(1, int(depth))
         # ``first``: an existing runner of the same configuration (slot base 0) to use as runner 0
+        if first is not None and getattr(first.plan, "slot_base", 0) != 0:
+            raise ValueError("PipelinedInference: the runner passed as `first` must use workspace slot base 0")
         self.runners = ([first] if first is not None else []) + \
             [CompiledInference(model, example, streams=streams, slot_base=i * max(1, int(streams)), **kw) for i in range(1 if first is not None else 0, self.depth)]
         self.device = example.device
