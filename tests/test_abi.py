@@ -1,6 +1,7 @@
 """C-ABI surface and host logic that do not need a GPU."""
 import ctypes
 import os
+import sys
 import re
 
 import pytest
@@ -184,6 +185,29 @@ def test_committed_pmc_traffic_file_covers_the_default_kernels():
         assert fam in fams, f"{bench.PMC_FILE} has no row of {fam}: re-run scripts/gpu_r2_evidence.sh and copy the new file"
     dom = [r for r in rows if r["kernel"].startswith("winmlp_kernel<f16,256") and r["workgroups"] == 848]   # whole-batch launches (r06: two steps in flight; r04 / r05: 424 = 128-image shards)
     assert dom and dom[0]["hbm_traffic_mb"] > 0
+
+
+def test_inference_runners_have_no_cpu_path_and_bench_times_steps_in_flight():
+    """compile_inference / pipelined_inference refuse a CPU example (no fallback); bench.py's default launch structure is the r06 one: two whole-batch steps in
+    flight (--inflight 2, one stream shard, no join), the r05 structure stays reachable by flags."""
+    import fastervit_amd
+    import bench
+    m = fastervit_amd.create_model("faster_vit_0_224").eval()
+    x = torch.zeros(2, 3, 224, 224)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.compile_inference(x)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.pipelined_inference(x, depth=2)
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        a = bench.parse()
+        assert (a.inflight, a.streams, a.join_from, a.batch, a.model) == (2, 1, 0, 256, "faster_vit_0_224")
+        sys.argv = ["bench.py", "--inflight", "1", "--streams", "2", "--join-from", "3"]
+        a = bench.parse()
+        assert (a.inflight, a.streams, a.join_from) == (1, 2, 3)
+    finally:
+        sys.argv = old
 
 
 def test_hat_backward_has_no_cpu_path():
