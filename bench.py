@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--inflight", type=int, default=2,
                     help="deploy + hipGraph: whole-batch steps in flight (fastervit_amd.inference.PipelinedInference: step k replays runner k %% N on its own stream, "
                          "so the tail of a step overlaps the front of the next one; 1 = one graph, steps strictly one after the other).  Default since r06: 2 steps in flight, "
-                         "whole-batch launches (--streams 1): +4..7 %% images/s over r05's 2 stream shards + join inside one graph, profiles/r06_steps_in_flight_ab.log")
+                         "whole-batch launches (--streams 1): +4..8 %% images/s over r05's 2 stream shards + join inside one graph, profiles/r06_steps_in_flight_ab.log")
     ap.add_argument("--cu-mask", default="", choices=["", "halves", "interleaved", "xcd"],
                     help="experiment: the steps in flight on CU-masked streams (hipExtStreamCreateWithCUMask): halves = CU bits [0,128) / [128,256); interleaved = even / odd bits; "
                          "xcd = bits with (i % 8) < 4 / >= 4")
