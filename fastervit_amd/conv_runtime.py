@@ -108,6 +108,9 @@ class DeployPlan:
         self.conv_weight_terms = int(os.environ.get("FVIT_CONV_WEIGHT_TERMS", "1"))
         # two-term / fp32 streams + two-term weights everywhere (module docstring): the ABSOLUTE-1e-3 plan of FasterViT-4 / any-res
         self.precise = os.environ.get("FVIT_PRECISE_DEPLOY", "0") == "1"
+        # r06: 3x3 convs contract over the REAL input channels only (dense K; include/fvit_hip.h): 29 / 56 K steps instead of 36 / 63 on FasterViT-4's
+        # 196- / 392-channel maps (stored as 256 / 448).  Same products in the same order per tap; "0" = the classic [Cout][3][3][Cin padded] matrix
+        self.dense_k = os.environ.get("FVIT_CONV_DENSE_K", "1") != "0"
         self.fused_stem = os.environ.get("FVIT_NO_FUSED_STEM", "0") != "1"   # both PatchEmbed convs in one kernel when in_dim == dim == 64 (the 112x112x64 map never reaches HBM)
 
     # ---- folding -------------------------------------------------------------------------
@@ -118,7 +121,7 @@ class DeployPlan:
             if ".blocks." in name and name.startswith(("levels.2.", "levels.3.")):
                 continue  # HAT parameters are tracked by hat_runtime
             sig.append((p.data_ptr(), p._version))
-        sig.append(("options", self.precise, self.conv_weight_terms, self.down_weight_terms))   # what _build depends on besides the parameters
+        sig.append(("options", self.precise, self.conv_weight_terms, self.down_weight_terms, self.dense_k))   # what _build depends on besides the parameters
         return tuple(sig)
 
     def _cp(self, c):
@@ -147,19 +150,31 @@ class DeployPlan:
         wcl = w.to(self.dtype).contiguous(memory_format=torch.channels_last)
         co, ci, kh, kw = w.shape
         wk = wband = None
+        cv = ci   # channels the kernel contracts over per tap (== ci: the classic [Cout][3][3][Cin] matrix)
         if self.use_hip_conv and kh == 3 and kw == 3 and ci % 64 == 0 and co % 64 == 0:
             wk = wcl.permute(0, 2, 3, 1).contiguous()
+            lo = (w - wcl.float()).to(self.dtype).permute(0, 2, 3, 1).contiguous() if terms == 2 else None
+            cv8 = (ci0 + 7) // 8 * 8
+            if self.dense_k and cv8 < ci:
+                # r06: the pad channels of the INPUT map leave the contraction (fvit_conv3x3_nhwc_dense): [Cout][terms][kd], column t * cv + c
+                cv, kd = cv8, (9 * cv8 + 63) // 64 * 64
+
+                def dense(m):   # m: (co, 3, 3, ci)
+                    d = torch.zeros((co, kd), dtype=m.dtype, device=m.device)
+                    d[:, :9 * cv] = m[..., :cv].reshape(co, 9 * cv)
+                    return d
+                wk = dense(wk) if lo is None else torch.cat([dense(wk), dense(lo)], dim=1).contiguous()
+                return wcl, wk, None, terms, cv
             if terms == 2:   # [Cout][hi (3,3,Cin) | lo (3,3,Cin)]: fvit_conv3x3_nhwc_terms
-                lo = (w - wcl.float()).to(self.dtype).permute(0, 2, 3, 1).contiguous()
                 wk = torch.cat([wk.reshape(co, -1), lo.reshape(co, -1)], dim=1).contiguous()
-                return wcl, wk, None, 2
+                return wcl, wk, None, 2, cv
             if (co, ci) == (128, 128):   # the fragment-order image fvit_conv3x3_c128_band streams (level 1 of FasterViT-0)
                 wband = frag_pack_conv128(wk.reshape(128, 1152))
-        return wcl, wk, wband, 1
+        return wcl, wk, wband, 1, cv
 
     def _conv(self, x, w, bias, stride, act, residual=None):
         """act(conv3x3(x, w) + bias) (+ residual): one fused HIP kernel when supported, else MIOpen conv + glue passes."""
-        wcl, wk, wband, wterms = w
+        wcl, wk, wband, wterms, cv = w
         B, Ci, Hi, Wi = x.shape
         if wk is not None and x.is_contiguous(memory_format=torch.channels_last):
             Co = wk.shape[0]
@@ -174,10 +189,10 @@ class DeployPlan:
                                                        self.zeros.data_ptr(), _stream(self.dev))
                 _lib.check(rc, "fvit_conv3x3_c128_band")
                 return out
-            rc = _lib.lib().fvit_conv3x3_nhwc_terms(self.code, x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
+            rc = _lib.lib().fvit_conv3x3_nhwc_dense(self.code, x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
                                                     residual.data_ptr() if residual is not None else None, out.data_ptr(), B, Hi, Wi,
-                                                    Ci, Co, stride, act, wterms, self.zeros.data_ptr(), _stream(self.dev))
-            _lib.check(rc, "fvit_conv3x3_nhwc_terms")
+                                                    Ci, cv, Co, stride, act, wterms, self.zeros.data_ptr(), _stream(self.dev))
+            _lib.check(rc, "fvit_conv3x3_nhwc_dense")
             return out
         y = F.conv2d(x, wcl, None, stride, 1)
         if residual is not None:
@@ -398,7 +413,7 @@ class DeployPlan:
     def _conv_px(self, x, x_lo, w, bias, stride, act, res=None, res_lo=None, want="planes"):
         """conv3x3_kernel<.., PX>: x (+ x_lo) -> act(conv + bias) (+ res + res_lo).  ``want``: 'planes' -> (hi, lo) 16-bit planes (in place over the
         residual planes when given), 'single' -> (hi, None), 'f32' -> one fp32 channels_last map."""
-        wcl, wk, wband, wterms = w
+        wcl, wk, wband, wterms, cv = w
         if wk is None or not x.is_contiguous(memory_format=torch.channels_last):
             raise RuntimeError("precise deploy plan: this conv shape has no implicit-GEMM kernel (channel counts must pad to multiples of 64)")
         B, Ci, Hi, Wi = x.shape
@@ -413,12 +428,12 @@ class DeployPlan:
             hi = res if res is not None else torch.empty((B, Co, Ho, Wo), dtype=self.dtype, device=x.device, memory_format=torch.channels_last)
             if want == "planes":
                 lo = res_lo if res_lo is not None else torch.empty_like(hi)
-        rc = _lib.lib().fvit_conv3x3_nhwc_px(self.code, x.data_ptr(), x_lo.data_ptr() if x_lo is not None else None, wk.data_ptr(),
+        rc = _lib.lib().fvit_conv3x3_nhwc_px_dense(self.code, x.data_ptr(), x_lo.data_ptr() if x_lo is not None else None, wk.data_ptr(),
                                              bias.data_ptr() if bias is not None else None, res.data_ptr() if res is not None else None,
                                              res_lo.data_ptr() if res_lo is not None else None, hi.data_ptr() if hi is not None else None,
                                              lo.data_ptr() if lo is not None else None, f32.data_ptr() if f32 is not None else None,
-                                             B, Hi, Wi, Ci, Co, stride, act, wterms, self.zeros.data_ptr(), _stream(self.dev))
-        _lib.check(rc, "fvit_conv3x3_nhwc_px")
+                                             B, Hi, Wi, Ci, cv, Co, stride, act, wterms, self.zeros.data_ptr(), _stream(self.dev))
+        _lib.check(rc, "fvit_conv3x3_nhwc_px_dense")
         return f32 if want == "f32" else (hi, lo)
 
     def _ln2d_px(self, x, x_lo, x_f32, w, b, eps, c_valid):

@@ -43,6 +43,11 @@ struct ConvParams {
     void* out_lo;         // lo plane of the output (lo = round(y - hi)) or null
     float* out_f32;       // the output as ONE fp32 map instead of out / out_lo, or null
     int px;               // 1: the two-term-map instance (fvit_conv3x3_nhwc_px)
+    // dense K (r06, conv3x3_kernel<.., DENSE = true>; the *_dense entry points): a map whose Cin channels hold only cv real ones (196 of 256, 392 of 448:
+    // FasterViT-4) contracts over 9 x cv columns packed back to back -- tap t, channel c at column t * cv + c, the row zero-padded to kd K steps of 64 --
+    // instead of 9 x Cin: a 64-wide K step may straddle taps, every lane derives the (tap, channel) of ITS 16-byte chunk.  cv % 8 == 0.
+    int cv, kd;
+    float inv_cv;
 };
 
 __device__ __forceinline__ int swz_x(int r) { return (r >> 1) & 7; }
@@ -71,7 +76,7 @@ __device__ __forceinline__ void dispatch_epilogue(int act, bool has_res, F&& bod
 }
 
 // per-wave tile: 64 pixels x 16*NI channels; workgroup tile: 64*WM pixels x 16*NI*WN channels (WM*WN = 4 waves)
-template <typename T, int WM, int WN, int NI, bool PX = false>
+template <typename T, int WM, int WN, int NI, bool PX = false, bool DENSE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int BM = 64 * WM, BN = 16 * NI * WN;
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     const T* __restrict__ In = (const T*)p.in;
     const T* __restrict__ W = (const T*)p.w;
     const T* __restrict__ Z = (const T*)p.zeros;
-    const int ldw = p.wterms * 9 * p.Cin;
+    const int ldw = DENSE ? p.wterms * p.kd * BK : p.wterms * 9 * p.Cin;
 
     // ---- per-lane gather state for the rows this lane stages (fixed for the whole K loop) ----
     int64_t rowoff[XP];     // element offset of in[b][yo*s-1][xo*s-1][0] from the plane's base (may lie outside the image; only used when the tap is valid)
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     }
 
     const int cpt = p.Cin / BK;  // K steps per tap
-    const int nk1 = 9 * cpt;     // K steps of one weight term
+    const int nk1 = DENSE ? p.kd : 9 * cpt;     // K steps of one weight term
     // PX: the third K segment reads the LO plane of the input against the hi weights: the plane's base pointer is chosen per segment, the per-row offsets
     // are plain integers (r05 formed the lo address as `hi pointer + (in_lo - in)`: arithmetic across two allocations)
     const T* const InLo = (PX && p.in_lo) ? (const T*)p.in_lo : In;
@@ -133,15 +138,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
         const int seg = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
         const int kta = kt - seg * nk1;              // the activation side wraps at every segment
         const int ktw = seg == 2 ? kta : kt;         // segments 0 / 1 / 2 meet the weight images hi / lo / hi
+        const T* const plane = (PX && seg == 2) ? InLo : In;
+        if constexpr (DENSE) {
+            // per-lane (tap, channel) of the lane's 16-byte chunk: k = 64 kta + chunk; tap = floor(k / cv) through the reciprocal ((k + 0.5) / cv is
+            // never within 0.5 / cv of an integer: exact in fp32); columns >= 9 cv (the zero-padded tail of the last K step) give tap 9 = never valid
+            const int k0 = kta * BK;
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const int k = k0 + rowchunk[i];
+                const int tap = (int)(((float)k + 0.5f) * p.inv_cv);
+                const int ci = k - tap * p.cv;
+                const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+                const int toff = (ky * p.Wi + kx) * p.Cin + ci;
+                const T* src = ((rowmask[i] >> tap) & 1) ? plane + (rowoff[i] + toff) : Z + rowchunk[i];
+                glds16(src, xbuf + (wave * XP + i) * 1024);
+            }
+        } else {
         const int tap = kta / cpt, ci0 = (kta - tap * cpt) * BK;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int64_t toff = (ky * p.Wi + kx) * p.Cin + ci0;
-        const T* const plane = (PX && seg == 2) ? InLo : In;
         if (!(p.ablate & 1))
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const T* src = ((rowmask[i] >> tap) & 1) ? plane + (rowoff[i] + toff + rowchunk[i]) : Z + rowchunk[i];
             glds16(src, xbuf + (wave * XP + i) * 1024);
+        }
         }
         if (!(p.ablate & 2))
 #pragma unroll
@@ -1247,12 +1268,12 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
 
 template <typename T>
 int launch_t(ConvParams& p, hipStream_t stream) {
-    if (p.Cin == 64 && p.Cout == 64 && p.stride == 1 && p.wterms == 1 && !p.px && tune_get("conv_halo", 1)) {
+    if (p.Cin == 64 && p.Cout == 64 && p.stride == 1 && p.wterms == 1 && !p.px && !p.cv && tune_get("conv_halo", 1)) {
         if (ablate_skip(64)) return FVIT_OK;
         return launch_halo_t<T>(p, stream);
     }
     if (ablate_skip(32)) return FVIT_OK;
-    const double flops = 2.0 * p.M * (double)p.Cout * 9.0 * p.Cin;
+    const double flops = 2.0 * p.M * (double)p.Cout * 9.0 * (p.cv ? p.cv : p.Cin);
     const double bytes = 2.0 * ((double)p.B * p.Hi * p.Wi * p.Cin * (p.in_lo ? 2.0 : 1.0) + (double)p.M * p.Cout * ((p.res ? (p.res_lo ? 2.0 : 1.0) : 0.0) + ((p.out_lo || p.out_f32) ? 2.0 : 1.0)) +
                                9.0 * p.wterms * p.Cin * p.Cout);
     ProfScope prof(FVIT_K_CONV, flops, bytes, stream);   // (the second weight term is a precision cost, not algorithmic FLOPs)
@@ -1267,12 +1288,14 @@ int launch_t(ConvParams& p, hipStream_t stream) {
         p.tiles_m = (p.M + 127) / 128;
         if (p.Cout % 128 == 0 || (p.Cout > 128 && tune_get("conv_n128_ragged", 1))) {
             p.tiles_n = (p.Cout + 127) / 128;
-            prof_note("conv3x3_kernel<2,2,4,px>", p.tiles_m * p.tiles_n);
-            hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+            prof_note(p.cv ? "conv3x3_kernel<2,2,4,px,dense>" : "conv3x3_kernel<2,2,4,px>", p.tiles_m * p.tiles_n);
+            if (p.cv) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, true, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
         } else {
             p.tiles_n = p.Cout / 64;
-            prof_note("conv3x3_kernel<2,2,2,px>", p.tiles_m * p.tiles_n);
-            hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+            prof_note(p.cv ? "conv3x3_kernel<2,2,2,px,dense>" : "conv3x3_kernel<2,2,2,px>", p.tiles_m * p.tiles_n);
+            if (p.cv) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2, true, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
         }
         return check_launch("conv3x3_kernel<px>");
     }
@@ -1283,9 +1306,10 @@ int launch_t(ConvParams& p, hipStream_t stream) {
     if ((p.Cout % 128 == 0 || (p.Cout > 128 && tune_get("conv_n128_ragged", 1))) && !narrow) {
         p.tiles_m = (p.M + 127) / 128;
         p.tiles_n = (p.Cout + 127) / 128;
-        prof_note("conv3x3_kernel<2,2,4>", p.tiles_m * p.tiles_n);
-        hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
-    } else if (variant == 1) {  // 256 pixels x 64 channels, 80 KiB LDS
+        prof_note(p.cv ? "conv3x3_kernel<2,2,4,dense>" : "conv3x3_kernel<2,2,4>", p.tiles_m * p.tiles_n);
+        if (p.cv) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+    } else if (variant == 1 && !p.cv) {  // 256 pixels x 64 channels, 80 KiB LDS
         p.tiles_m = (p.M + 255) / 256;
         p.tiles_n = p.Cout / 64;
         prof_note("conv3x3_kernel<4,1,4>", p.tiles_m * p.tiles_n);
@@ -1293,8 +1317,9 @@ int launch_t(ConvParams& p, hipStream_t stream) {
     } else {  // 128 pixels x 64 channels, 48 KiB LDS: three workgroups per CU
         p.tiles_m = (p.M + 127) / 128;
         p.tiles_n = p.Cout / 64;
-        prof_note("conv3x3_kernel<2,2,2>", p.tiles_m * p.tiles_n);
-        hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+        prof_note(p.cv ? "conv3x3_kernel<2,2,2,dense>" : "conv3x3_kernel<2,2,2>", p.tiles_m * p.tiles_n);
+        if (p.cv) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
     }
     return check_launch("conv3x3_kernel");
 }
@@ -1307,6 +1332,9 @@ using namespace fvit;
 extern "C" int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual, void* out,
                                        int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride, int32_t act,
                                        int32_t weight_terms, const void* zeros, fvit_stream_t stream);
+extern "C" int fvit_conv3x3_nhwc_dense(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual, void* out,
+                                       int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t cin_valid, int32_t Cout, int32_t stride, int32_t act,
+                                       int32_t weight_terms, const void* zeros, fvit_stream_t stream);
 
 extern "C" int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual, void* out,
                                  int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride, int32_t act,
@@ -1314,8 +1342,28 @@ extern "C" int fvit_conv3x3_nhwc(int32_t dtype, const void* in, const void* weig
     return fvit_conv3x3_nhwc_terms(dtype, in, weight, bias, residual, out, B, Hi, Wi, Cin, Cout, stride, act, 1, zeros, stream);
 }
 
+// dense-K parameters of a launch: cin_valid == Cin -> the classic [Cout][terms][3][3][Cin] weight matrix; cin_valid < Cin -> the dense matrix
+// [Cout][terms][kd * 64] (fvit_hip.h, fvit_conv3x3_dense_k)
+static bool set_dense(ConvParams& p, int cin_valid) {
+    p.cv = 0; p.kd = 0; p.inv_cv = 0.f;
+    if (cin_valid == p.Cin) return true;
+    if (cin_valid <= 0 || cin_valid > p.Cin || (cin_valid % 8)) return false;
+    p.cv = cin_valid;
+    p.kd = (9 * cin_valid + BK - 1) / BK;
+    p.inv_cv = 1.0f / (float)cin_valid;
+    return true;
+}
+
+extern "C" int fvit_conv3x3_dense_k(int32_t cin_valid) { return cin_valid > 0 && cin_valid % 8 == 0 ? (9 * cin_valid + BK - 1) / BK * BK : -1; }
+
 extern "C" int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual, void* out,
                                        int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride, int32_t act,
+                                       int32_t weight_terms, const void* zeros, fvit_stream_t stream) {
+    return fvit_conv3x3_nhwc_dense(dtype, in, weight, bias, residual, out, B, Hi, Wi, Cin, Cin, Cout, stride, act, weight_terms, zeros, stream);
+}
+
+extern "C" int fvit_conv3x3_nhwc_dense(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual, void* out,
+                                       int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t cin_valid, int32_t Cout, int32_t stride, int32_t act,
                                        int32_t weight_terms, const void* zeros, fvit_stream_t stream) {
     if (!in || !weight || !out || !zeros || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 64) ||
         (stride != 1 && stride != 2) || act < 0 || act > 2 || (weight_terms != 1 && weight_terms != 2)) {
@@ -1329,6 +1377,10 @@ extern "C" int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void
     p.ablate = diag_knob("conv_ablate");
     p.wterms = weight_terms;
     p.in_lo = p.res_lo = nullptr; p.out_lo = nullptr; p.out_f32 = nullptr; p.px = 0;
+    if (!set_dense(p, cin_valid)) {
+        set_error("conv3x3: cin_valid=%d must be a multiple of 8 in (0, Cin=%d]", cin_valid, Cin);
+        return FVIT_EINVAL;
+    }
     p.Ho = (Hi + 2 - 3) / stride + 1;
     p.Wo = (Wi + 2 - 3) / stride + 1;
     const int64_t M = (int64_t)B * p.Ho * p.Wo;
@@ -1343,9 +1395,22 @@ extern "C" int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void
     return FVIT_EINVAL;
 }
 
+extern "C" int fvit_conv3x3_nhwc_px_dense(int32_t dtype, const void* in, const void* in_lo, const void* weight, const float* bias, const void* residual,
+                                          const void* residual_lo, void* out, void* out_lo, float* out_f32, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
+                                          int32_t cin_valid, int32_t Cout, int32_t stride, int32_t act, int32_t weight_terms, const void* zeros,
+                                          fvit_stream_t stream);
+
 extern "C" int fvit_conv3x3_nhwc_px(int32_t dtype, const void* in, const void* in_lo, const void* weight, const float* bias, const void* residual,
                                     const void* residual_lo, void* out, void* out_lo, float* out_f32, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
                                     int32_t Cout, int32_t stride, int32_t act, int32_t weight_terms, const void* zeros, fvit_stream_t stream) {
+    return fvit_conv3x3_nhwc_px_dense(dtype, in, in_lo, weight, bias, residual, residual_lo, out, out_lo, out_f32, B, Hi, Wi, Cin, Cin, Cout, stride, act,
+                                      weight_terms, zeros, stream);
+}
+
+extern "C" int fvit_conv3x3_nhwc_px_dense(int32_t dtype, const void* in, const void* in_lo, const void* weight, const float* bias, const void* residual,
+                                          const void* residual_lo, void* out, void* out_lo, float* out_f32, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
+                                          int32_t cin_valid, int32_t Cout, int32_t stride, int32_t act, int32_t weight_terms, const void* zeros,
+                                          fvit_stream_t stream) {
     if (!in || !weight || (!out && !out_f32) || !zeros || B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || (Cin % 64) || (Cout % 64) ||
         (stride != 1 && stride != 2) || act < 0 || act > 2 || (weight_terms != 1 && weight_terms != 2) || (in_lo && weight_terms != 2) ||
         (residual_lo && !residual) || (out_f32 && out_lo) || (out_lo && !out)) {
@@ -1359,6 +1424,10 @@ extern "C" int fvit_conv3x3_nhwc_px(int32_t dtype, const void* in, const void* i
     p.ablate = 0;
     p.wterms = weight_terms;
     p.in_lo = in_lo; p.res_lo = residual_lo; p.out_lo = out_lo; p.out_f32 = out_f32; p.px = 1;
+    if (!set_dense(p, cin_valid)) {
+        set_error("conv3x3_px: cin_valid=%d must be a multiple of 8 in (0, Cin=%d]", cin_valid, Cin);
+        return FVIT_EINVAL;
+    }
     p.Ho = (Hi + 2 - 3) / stride + 1;
     p.Wo = (Wi + 2 - 3) / stride + 1;
     const int64_t M = (int64_t)B * p.Ho * p.Wo;

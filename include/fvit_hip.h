@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FVIT_ABI_VERSION 7
+#define FVIT_ABI_VERSION 8
 
 /* error codes */
 #define FVIT_OK 0
@@ -445,6 +445,20 @@ int fvit_conv3x3_nhwc_terms(int32_t dtype, const void* in, const void* weight, c
 int fvit_conv3x3_nhwc_px(int32_t dtype, const void* in, const void* in_lo, const void* weight, const float* bias, const void* residual,
                          const void* residual_lo, void* out, void* out_lo, float* out_f32, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
                          int32_t Cout, int32_t stride, int32_t act, int32_t weight_terms, const void* zeros, fvit_stream_t stream);
+/* ---- dense K (r06): maps whose channel count is padded (FasterViT-4: 196 real channels in a 256-channel map, 392 in 448) -------------------
+ * The classic entry points contract over 9 * Cin columns, pad channels included (1.31 x / 1.14 x the K steps at 196 / 392).  The *_dense forms
+ * contract over the cin_valid real channels only: weight is [Cout][weight_terms][kd] with kd = fvit_conv3x3_dense_k(cin_valid) =
+ * 9 * cin_valid rounded up to 64; column t * cin_valid + c holds w[co][tap t][channel c], the tail of the row is zero.  Cin stays the channel
+ * STRIDE of the input map; cin_valid % 8 == 0 (a 16-byte chunk never straddles two taps).  cin_valid == Cin is the classic layout and kernel.
+ * Everything else as fvit_conv3x3_nhwc_terms / fvit_conv3x3_nhwc_px.  fvit_conv3x3_dense_k returns -1 for an unsupported cin_valid. */
+int fvit_conv3x3_dense_k(int32_t cin_valid);
+int fvit_conv3x3_nhwc_dense(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual,
+                            void* out, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t cin_valid, int32_t Cout, int32_t stride,
+                            int32_t act, int32_t weight_terms, const void* zeros, fvit_stream_t stream);
+int fvit_conv3x3_nhwc_px_dense(int32_t dtype, const void* in, const void* in_lo, const void* weight, const float* bias, const void* residual,
+                               const void* residual_lo, void* out, void* out_lo, float* out_f32, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
+                               int32_t cin_valid, int32_t Cout, int32_t stride, int32_t act, int32_t weight_terms, const void* zeros,
+                               fvit_stream_t stream);
 /* fvit_layernorm2d_cl on a two-term map (in + in_lo; in_lo may be NULL) or an fp32 map (in_f32, then in = in_lo = NULL); the result as two
  * planes (out_lo may be NULL).  Statistics and affine in fp32 (timm LayerNorm2d, FV:432,438). */
 int fvit_layernorm2d_px(int32_t dtype, const void* in, const void* in_lo, const float* in_f32, void* out, void* out_lo, const float* weight,

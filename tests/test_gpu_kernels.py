@@ -414,6 +414,78 @@ def test_conv3x3_fused(dt, code, B, Ci, Co, H, W, stride, act, res):
         assert torch.equal(out2, out)
 
 
+def _dense_rows(w_cl, cv):
+    """[Co][3][3][Ci] -> the dense-K rows of fvit_conv3x3_nhwc_dense: column t * cv + c, zero tail up to fvit_conv3x3_dense_k(cv)."""
+    co = w_cl.shape[0]
+    kd = _lib.lib().fvit_conv3x3_dense_k(cv)
+    d = torch.zeros(co, kd, dtype=w_cl.dtype, device=w_cl.device)
+    d[:, :9 * cv] = w_cl[..., :cv].reshape(co, 9 * cv)
+    return d
+
+
+@pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
+@pytest.mark.parametrize("B,Ci,Cv,Co,H,W,stride,act,res,terms", [
+    (2, 256, 200, 256, 14, 14, 1, 2, False, 1),    # FasterViT-4 level 0 (196 -> 200 of 256): K steps straddle taps, 29 instead of 36
+    (1, 448, 392, 448, 9, 11, 1, 0, True, 1),      # level 1 (392 of 448), ragged last N tile, residual in place
+    (2, 448, 392, 832, 8, 6, 2, 0, False, 2),      # Downsample 392 -> 784 with two-term weights
+    (3, 64, 24, 64, 9, 13, 1, 0, True, 1),         # the tiny test models: cv < 64, a K step spans three taps; 128 x 64 tiles
+    (2, 64, 16, 64, 16, 16, 2, 1, False, 2), (2, 128, 72, 192, 12, 10, 2, 2, False, 1), (1, 64, 8, 128, 5, 7, 1, 0, False, 1),
+    (2, 128, 128, 256, 7, 9, 1, 2, False, 1)])     # cin_valid == Cin: the classic kernel behind the same entry point
+def test_conv3x3_dense_k(dt, code, B, Ci, Cv, Co, H, W, stride, act, res, terms):
+    """r06: the implicit-GEMM conv contracting over the cin_valid real channels of a channel-padded map (fvit_conv3x3_nhwc_dense) vs F.conv2d in
+    fp32 on those channels, and vs the classic kernel on the zero-padded weight matrix.  The pad channels of the INPUT hold garbage here: the dense
+    kernel must never read them."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(Ci + Co + H + Cv)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    x[:, Cv:] = 1000.0                                    # poison: a classic contraction would see it (its weights there are zero, but 1000 * 0 must not even be formed from a NaN)
+    xz = x.clone(); xz[:, Cv:] = 0
+    x, xz = [t.to(dt).cuda().contiguous(memory_format=torch.channels_last) for t in (x, xz)]
+    w = torch.zeros(Co, Ci, 3, 3)
+    w[:, :Cv] = torch.randn(Co, Cv, 3, 3, generator=g) / (9 * Cv) ** 0.5
+    bias = torch.randn(Co, generator=g).cuda()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(B, Co, Ho, Wo, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last) if res else None
+    wh = w.to(dt)
+    wl = (w - wh.float()).to(dt)
+    cl = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()   # noqa: E731
+    dense = _dense_rows(cl(wh), Cv) if Cv < Ci else cl(wh).reshape(Co, -1)
+    classic = cl(wh).reshape(Co, -1)
+    if terms == 2:
+        dense = torch.cat([dense, _dense_rows(cl(wl), Cv) if Cv < Ci else cl(wl).reshape(Co, -1)], dim=1).contiguous()
+        classic = torch.cat([classic, cl(wl).reshape(Co, -1)], dim=1).contiguous()
+    assert dense.shape[1] == terms * (lib.fvit_conv3x3_dense_k(Cv) if Cv < Ci else 9 * Ci)
+    zeros = torch.zeros(256, dtype=dt, device="cuda")
+    out = torch.full((B, Co, Ho, Wo), float("nan"), dtype=dt, device="cuda").contiguous(memory_format=torch.channels_last)
+    _lib.check(lib.fvit_conv3x3_nhwc_dense(code, x.data_ptr(), dense.data_ptr(), bias.data_ptr(), r.data_ptr() if res else None, out.data_ptr(),
+                                           B, H, W, Ci, Cv, Co, stride, act, terms, zeros.data_ptr(), _stream()), "conv3x3 dense")
+    old = torch.full_like(out, float("nan"))
+    _lib.check(lib.fvit_conv3x3_nhwc_terms(code, xz.data_ptr(), classic.data_ptr(), bias.data_ptr(), r.data_ptr() if res else None, old.data_ptr(),
+                                           B, H, W, Ci, Co, stride, act, terms, zeros.data_ptr(), _stream()), "conv3x3 classic")
+    torch.cuda.synchronize()
+    wref = (wh.float() + wl.float()) if terms == 2 else wh.float()
+    ref = F.conv2d(xz.float(), wref.cuda(), bias, stride, 1)
+    ref = [lambda t: t, torch.relu, F.gelu][act](ref)
+    if res:
+        ref = ref + r.float()
+    scale = max(ref.abs().max().item(), 1.0)
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - ref).abs().max().item() < (5e-3 if dt == torch.float16 else 3e-2) * scale
+    # same products, another grouping into MFMA steps: the two kernels differ by fp32 summation order + one output rounding at most
+    assert (out.float() - old.float()).abs().max().item() <= (2.0 ** -10 if dt == torch.float16 else 2.0 ** -7) * scale
+    if res:
+        r2 = r.clone()
+        _lib.check(lib.fvit_conv3x3_nhwc_dense(code, x.data_ptr(), dense.data_ptr(), bias.data_ptr(), r2.data_ptr(), r2.data_ptr(), B, H, W, Ci, Cv, Co,
+                                               stride, act, terms, zeros.data_ptr(), _stream()), "conv3x3 dense in place")
+        torch.cuda.synchronize()
+        assert torch.equal(r2, out)
+    # argument checks: cin_valid must be a multiple of 8 in (0, Cin]
+    for bad in (0, Cv + 4, Ci + 8):
+        assert lib.fvit_conv3x3_nhwc_dense(code, x.data_ptr(), dense.data_ptr(), bias.data_ptr(), None, out.data_ptr(), B, H, W, Ci, bad, Co, stride, act,
+                                           terms, zeros.data_ptr(), _stream()) != 0
+    assert lib.fvit_conv3x3_dense_k(Cv + 4) == -1
+
+
 @pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
 @pytest.mark.parametrize("B,H,W,act,res", [(86, 28, 28, 2, False), (86, 28, 28, 0, True), (3, 28, 28, 1, True), (2, 30, 30, 0, False), (5, 1, 1, 2, True),
                                            (2, 9, 14, 0, True), (3, 33, 7, 2, False), (1, 14, 14, 0, True), (4, 5, 30, 1, False)])

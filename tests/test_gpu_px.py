@@ -101,6 +101,71 @@ def test_conv3x3_px(B, Ci, Co, H, W, stride, act, in2, res, out):
                                     stride, act, 1, zeros.data_ptr(), _stream()) != 0
 
 
+@pytest.mark.parametrize("B,Ci,Cv,Co,H,W,stride,act,in2,res,out", [
+    (2, 256, 200, 256, 14, 14, 1, 2, False, 0, "single"),   # FasterViT-4 level 0 conv1 (196 -> 200 of 256 channels)
+    (1, 256, 200, 256, 9, 13, 1, 0, False, 2, "planes"),    # conv2: two-term residual in place
+    (1, 448, 392, 832, 11, 9, 2, 0, True, 0, "f32"),        # Downsample 392 -> 784 in front of a transformer level: three K segments, fp32 out
+    (2, 64, 24, 64, 12, 10, 2, 0, True, 0, "planes"),       # tiny models: a K step spans three taps, 128 x 64 tiles
+    (3, 64, 16, 128, 7, 9, 1, 1, False, 1, "planes")])
+def test_conv3x3_px_dense_k(B, Ci, Cv, Co, H, W, stride, act, in2, res, out):
+    """r06: fvit_conv3x3_nhwc_px_dense (the two-term-map conv contracting over the real input channels only) vs F.conv2d in fp64; the pad channels
+    of both input planes hold garbage that must never be read."""
+    lib = _lib.lib()
+    dt = torch.float16
+    g = torch.Generator(device="cpu").manual_seed(Ci + Co + H + stride + Cv)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.zeros(Co, Ci, 3, 3)
+    w[:, :Cv] = torch.randn(Co, Cv, 3, 3, generator=g) / (9 * Cv) ** 0.5
+    bias = torch.randn(Co, generator=g).cuda()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    xh, xl = _split(x)
+    xh_ref, xl_ref = xh.clone(), xl.clone()
+    xh_ref[:, Cv:] = 0; xl_ref[:, Cv:] = 0
+    xh[:, Cv:] = 777.0; xl[:, Cv:] = -3.0
+    wh, wl = _split(w)
+    xh, xl = _cl(xh.cuda()), _cl(xl.cuda())
+    kd = lib.fvit_conv3x3_dense_k(Cv)
+
+    def dense(m):
+        d = torch.zeros(Co, kd, dtype=m.dtype)
+        d[:, :9 * Cv] = m.permute(0, 2, 3, 1)[..., :Cv].reshape(Co, 9 * Cv)
+        return d
+    wk = torch.cat([dense(wh), dense(wl)], dim=1).contiguous().cuda()
+    rh = rl = None
+    if res:
+        r = torch.randn(B, Co, Ho, Wo, generator=g) * 3
+        rh, rl = _split(r)
+        rh, rl = _cl(rh.cuda()), _cl(rl.cuda())
+        if res == 1:
+            rl = None
+    zeros = torch.zeros(256, dtype=dt, device="cuda")
+    nan = float("nan")
+    oh = _cl(torch.full((B, Co, Ho, Wo), nan, dtype=dt, device="cuda")) if out != "f32" else None
+    ol = _cl(torch.full((B, Co, Ho, Wo), nan, dtype=dt, device="cuda")) if out == "planes" else None
+    of = _cl(torch.full((B, Co, Ho, Wo), nan, dtype=torch.float32, device="cuda")) if out == "f32" else None
+    p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    _lib.check(lib.fvit_conv3x3_nhwc_px_dense(1, xh.data_ptr(), p(xl) if in2 else None, wk.data_ptr(), bias.data_ptr(), p(rh), p(rl), p(oh), p(ol), p(of),
+                                              B, H, W, Ci, Cv, Co, stride, act, 2, zeros.data_ptr(), _stream()), "conv3x3_px_dense")
+    torch.cuda.synchronize()
+    xin = xh_ref.double() + (xl_ref.double() if in2 else 0.0)
+    ref = F.conv2d(xin, (wh.double() + wl.double()), bias.double().cpu(), stride, 1)
+    ref = [lambda t: t, torch.relu, lambda t: F.gelu(t)][act](ref)
+    if res:
+        ref = ref + rh.double().cpu() + (rl.double().cpu() if rl is not None else 0.0)
+    scale = max(ref.abs().max().item(), 1.0)
+    if out == "f32":
+        got, tol = of.double().cpu(), 2e-6 * scale
+    elif out == "planes":
+        got, tol = oh.double().cpu() + ol.double().cpu(), 2e-6 * scale
+    else:
+        got, tol = oh.double().cpu(), 6e-4 * scale
+    err = (got - ref).abs().max().item()
+    print(f"conv3x3_px_dense Ci {Ci} Cv {Cv} Co {Co} stride {stride} act {act} in2 {in2} res {res} out {out}: max-abs {err:.2e} (tol {tol:.1e})")
+    assert torch.isfinite(got).all() and err < tol
+    assert lib.fvit_conv3x3_nhwc_px_dense(1, xh.data_ptr(), None, wk.data_ptr(), bias.data_ptr(), None, None, p(oh) or xh.data_ptr(), None, None,
+                                          B, H, W, Ci, Cv + 4, Co, stride, act, 2, zeros.data_ptr(), _stream()) != 0
+
+
 @pytest.mark.parametrize("C,Cv,src", [(64, 64, "planes"), (256, 196, "planes"), (448, 392, "f32"), (832, 784, "f32"), (128, 128, "single"), (1600, 1568, "f32")])
 def test_layernorm2d_px(C, Cv, src):
     lib = _lib.lib()

@@ -19,18 +19,54 @@ def _model(name):
     return m, c
 
 
+def test_dense_k_packing_drops_the_pad_channels_of_the_input():
+    """r06 (fvit_conv3x3_nhwc_dense): a conv whose input map is channel-padded contracts over the real channels only: rows [Cout][terms][kd],
+    column t * cv + c = w[co][tap t][c], zero tail; a conv without padding keeps the classic matrix (cv == Cin)."""
+    m, _ = _model("tiny_hier")
+    for terms in (1, 2):
+        plan = DeployPlan(m, torch.float16)
+        assert plan.dense_k
+        found = 0
+        for blk in m.levels[0].blocks:
+            wa, _ = _fold(blk.conv1, blk.norm1)
+            co, ci = wa.shape[:2]
+            cop, cip = plan._cp(co), plan._cp(ci)
+            wcl, wk, wband, wt, cv = plan._cw(wa, terms=terms)
+            cv8 = (ci + 7) // 8 * 8
+            if cv8 == cip:
+                assert cv == cip and wk.numel() == cop * terms * 9 * cip
+                continue
+            found += 1
+            kd = (9 * cv8 + 63) // 64 * 64
+            assert cv == cv8 and wt == terms and wband is None and tuple(wk.shape) == (cop, terms * kd)
+            hi = wk[:, :9 * cv].float().view(cop, 3, 3, cv)
+            assert wk[:, 9 * cv:kd].abs().sum().item() == 0 and hi[co:].abs().sum().item() == 0 and hi[..., ci:].abs().sum().item() == 0
+            ref = wa.to(torch.float16).float().permute(0, 2, 3, 1)
+            assert torch.equal(hi[:co, :, :, :ci], ref)
+            if terms == 2:
+                lo = wk[:, kd:kd + 9 * cv].float().view(cop, 3, 3, cv)
+                assert ((hi + lo)[:co, :, :, :ci] - wa.permute(0, 2, 3, 1)).abs().max().item() <= 2.0 ** -20 * wa.abs().max().item()
+                assert wk[:, kd + 9 * cv:].abs().sum().item() == 0
+        if plan._cp(m.levels[0].blocks[0].conv1.weight.shape[1]) != (m.levels[0].blocks[0].conv1.weight.shape[1] + 7) // 8 * 8:
+            assert found > 0
+    sig = plan._signature()
+    plan.dense_k = False
+    assert plan._signature() != sig
+
+
 def test_precise_plan_packs_every_conv_weight_as_two_terms():
     m, _ = _model("tiny_hier")
     plan = DeployPlan(m, torch.float16)
     plan.precise = True
+    plan.dense_k = False   # the classic [Cout][3][3][Cin padded] rows (the dense-K packing: test_dense_k_packing_drops_the_pad_channels_of_the_input)
     plan._build()
     t = plan.t
     lvl0 = m.levels[0].blocks[0]
     wa, ba = _fold(lvl0.conv1, lvl0.norm1)                       # fp32 folded conv1 + BN of the first ConvBlock
-    (wcl, wk, wband, terms), bias, _, _ = t["levels"][0]["blocks"][0]
+    (wcl, wk, wband, terms, cv), bias, _, _ = t["levels"][0]["blocks"][0]
     co, ci = wa.shape[:2]
     cop, cip = plan._cp(co), plan._cp(ci)
-    assert terms == 2 and wband is None and tuple(wk.shape) == (cop, 2 * 9 * cip) and wk.dtype == torch.float16
+    assert terms == 2 and wband is None and cv == cip and tuple(wk.shape) == (cop, 2 * 9 * cip) and wk.dtype == torch.float16
     hi = wk[:, :9 * cip].float().view(cop, 3, 3, cip)
     lo = wk[:, 9 * cip:].float().view(cop, 3, 3, cip)
     rec = (hi + lo)[:co, :, :, :ci].permute(0, 3, 1, 2)
