@@ -76,6 +76,8 @@ __device__ __forceinline__ void dispatch_epilogue(int act, bool has_res, F&& bod
 }
 
 // per-wave tile: 64 pixels x 16*NI channels; workgroup tile: 64*WM pixels x 16*NI*WN channels (WM*WN = 4 waves)
+// (r06, scripts/r06_calls/call23.sh: a 3-deep ACTIVATION ring -- X(kt + 2) requested while step kt runs, counted vmcnt, 3 x 16 + 2 x 16 KiB = still two
+// workgroups per CU -- measured equal to this double buffer on the headline and on FasterViT-4 in both plans: the K step is not waiting for the gather.)
 template <typename T, int WM, int WN, int NI, bool PX = false, bool DENSE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     typedef typename Op16<T>::v8 v8;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     constexpr int XP = BM / 8 / 4;  // 1-KiB pieces (8 rows) of the X tile each wave stages per K step
     constexpr int WPIECES = BN / 8;             // 1-KiB pieces of the W tile (8 rows each)
     constexpr int WP = (WPIECES + 3) / 4;       // per wave (waves beyond WPIECES stage nothing)
-    __shared__ __attribute__((aligned(16))) char smem[2 * (X_BYTES + W_BYTES)];
+    __shared__ __attribute__((aligned(16))) char smem[2 * (X_BYTES + W_BYTES)];   // the two X tiles, then the two W tiles
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -134,10 +136,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     // PX: the third K segment reads the LO plane of the input against the hi weights: the plane's base pointer is chosen per segment, the per-row offsets
     // are plain integers (r05 formed the lo address as `hi pointer + (in_lo - in)`: arithmetic across two allocations)
     const T* const InLo = (PX && p.in_lo) ? (const T*)p.in_lo : In;
-    auto stage = [&](int kt, char* xbuf, char* wbuf) {
+    auto stage_x = [&](int kt, char* xbuf) {
         const int seg = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
         const int kta = kt - seg * nk1;              // the activation side wraps at every segment
-        const int ktw = seg == 2 ? kta : kt;         // segments 0 / 1 / 2 meet the weight images hi / lo / hi
         const T* const plane = (PX && seg == 2) ? InLo : In;
         if constexpr (DENSE) {
             // per-lane (tap, channel) of the lane's 16-byte chunk: k = 64 kta + chunk; tap = floor(k / cv) through the reciprocal ((k + 0.5) / cv is
@@ -164,6 +165,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
             glds16(src, xbuf + (wave * XP + i) * 1024);
         }
         }
+    };
+    auto stage_w = [&](int kt, char* wbuf) {
+        const int seg = kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0);
+        const int ktw = seg == 2 ? kt - 2 * nk1 : kt;   // segments 0 / 1 / 2 meet the weight images hi / lo / hi
         if (!(p.ablate & 2))
 #pragma unroll
         for (int i = 0; i < WP; ++i) {
@@ -183,7 +188,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.wterms + ((PX && p.in_lo) ? 1 : 0)) * nk1;
-    stage(0, smem, smem + 2 * X_BYTES);
+    char* const wring = smem + 2 * X_BYTES;
+    stage_x(0, smem);
+    stage_w(0, wring);
 
     const int g = lane >> 4, s = lane & 15;
     // weight row for A-row slot s of fragment i: wn*16*NI + (s>>2)*4*NI + i*4 + (s&3)  => lane (g, .) owns the 4*NI
@@ -198,9 +205,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, smem + (cur ^ 1) * X_BYTES, smem + 2 * X_BYTES + (cur ^ 1) * W_BYTES);
+        if (kt + 1 < nk) { stage_x(kt + 1, smem + (cur ^ 1) * X_BYTES); stage_w(kt + 1, wring + (cur ^ 1) * W_BYTES); }
         const char* xt = smem + cur * X_BYTES;
-        const char* wt = smem + 2 * X_BYTES + cur * W_BYTES;
+        const char* wt = wring + cur * W_BYTES;
         // both 32-deep halves of the K step are read up front: one exposed LDS round trip per step instead of three (see fvit_gemm.hip)
         v8 xf[2][4], wf[2][NI];
 #pragma unroll
@@ -1284,18 +1291,22 @@ int launch_t(ConvParams& p, hipStream_t stream) {
     // (40.6 vs 44 us at 85-86 images, but 41 vs 30 us at 83), yet end to end they lose (68.1k vs 70.0k images/s: the other stream
     // shards' kernels fill the idle slots of a partial round anyway) => opt-in knob only.
     const int narrow = tune_get("conv128_narrow", 0);
+#define FVIT_CONV_LAUNCH(WM_, WN_, NI_, PX_)                                                                                            \
+    do {                                                                                                                                \
+        const dim3 grid_(p.tiles_m * p.tiles_n);                                                                                        \
+        if (p.cv) hipLaunchKernelGGL((conv3x3_kernel<T, WM_, WN_, NI_, PX_, true>), grid_, dim3(256), 0, stream, p);                    \
+        else hipLaunchKernelGGL((conv3x3_kernel<T, WM_, WN_, NI_, PX_, false>), grid_, dim3(256), 0, stream, p);                        \
+    } while (0)
     if (p.px) {   // two-term maps: the implicit GEMM only (128 x 128 tiles when Cout allows, else 128 x 64)
         p.tiles_m = (p.M + 127) / 128;
         if (p.Cout % 128 == 0 || (p.Cout > 128 && tune_get("conv_n128_ragged", 1))) {
             p.tiles_n = (p.Cout + 127) / 128;
             prof_note(p.cv ? "conv3x3_kernel<2,2,4,px,dense>" : "conv3x3_kernel<2,2,4,px>", p.tiles_m * p.tiles_n);
-            if (p.cv) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, true, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+            FVIT_CONV_LAUNCH(2, 2, 4, true);
         } else {
             p.tiles_n = p.Cout / 64;
             prof_note(p.cv ? "conv3x3_kernel<2,2,2,px,dense>" : "conv3x3_kernel<2,2,2,px>", p.tiles_m * p.tiles_n);
-            if (p.cv) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2, true, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+            FVIT_CONV_LAUNCH(2, 2, 2, true);
         }
         return check_launch("conv3x3_kernel<px>");
     }
@@ -1307,8 +1318,7 @@ int launch_t(ConvParams& p, hipStream_t stream) {
         p.tiles_m = (p.M + 127) / 128;
         p.tiles_n = (p.Cout + 127) / 128;
         prof_note(p.cv ? "conv3x3_kernel<2,2,4,dense>" : "conv3x3_kernel<2,2,4>", p.tiles_m * p.tiles_n);
-        if (p.cv) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+        FVIT_CONV_LAUNCH(2, 2, 4, false);
     } else if (variant == 1 && !p.cv) {  // 256 pixels x 64 channels, 80 KiB LDS
         p.tiles_m = (p.M + 255) / 256;
         p.tiles_n = p.Cout / 64;
@@ -1318,10 +1328,10 @@ int launch_t(ConvParams& p, hipStream_t stream) {
         p.tiles_m = (p.M + 127) / 128;
         p.tiles_n = p.Cout / 64;
         prof_note(p.cv ? "conv3x3_kernel<2,2,2,dense>" : "conv3x3_kernel<2,2,2>", p.tiles_m * p.tiles_n);
-        if (p.cv) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+        FVIT_CONV_LAUNCH(2, 2, 2, false);
     }
     return check_launch("conv3x3_kernel");
+#undef FVIT_CONV_LAUNCH
 }
 
 }  // namespace

@@ -391,12 +391,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_kernel(GemmPara
 //           still one barrier before group 0 reads K tile t+1.
 // The loads are never drained inside the loop and there is no point where all eight waves wait for memory at once.
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int EPI, bool X3 = false>
+// XR (r06): depth of the ACTIVATION ring.  2 = the layout above.  3 = a third pair of X half-tiles (160 KiB = the whole LDS of the CU): X0(t+2), X1(t+2) are
+// requested in phases 1 / 2 of K tile t into the slot X(t-1) was read from (the same hazard distance as X(t+1) into "the other buffer"), the W requests stay
+// where they are, and the counted wait at the end of phase 4 leaves FOUR requests in flight (X(t+2), W(t+2): vmcnt(8)).  The activation panel was written by
+// the previous kernel and comes from the memory side; the weights come from L2: the longer lookahead goes to the operand with the longer latency.
+template <typename T, int EPI, bool X3 = false, int XR = 2>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int HT = 128 * BK * 2;            // half-tile bytes
-    constexpr int BUF = 4 * HT;                 // X0 X1 W0 W1
-    __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
+    constexpr int XB = 2 * HT;                  // X0 X1 of one K tile / W0 W1 of one K tile
+    constexpr int XRING = XR * XB;
+    static_assert(XR == 2 || XR == 3, "activation ring: 2 or 3 K tiles");
+    __shared__ __attribute__((aligned(1024))) char smem[XRING + 2 * XB];   // X ring, then the two W buffers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -415,8 +421,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     const int nk = X3 ? p.ka / 32 : p.K / BK;   // X3: dual tiles of 32 contraction indices x {hi, lo} (see GemmParams.x3)
     const int lo_col = X3 ? p.ka : 0;
     auto acol = [&](int kt) { if (X3) return kt * 32; const int k = kt * BK; return k >= p.ka ? k - p.ka : k; };   // K = 1, 2 or 3 x ka (see gemm_kernel)
-    auto req_x = [&](int h, int kt, char* buf) { stage_tile<T, false, 128, 8>(A, p.lda, m0 + 128 * h, acol(kt), buf + h * HT, wave, lane, p.arow_max, lo_col); };
-    auto req_w = [&](int h, int kt, char* buf) { stage_tile<T, true, 128, 8>(W, p.ldw, n0 + 128 * h, kt * (X3 ? 32 : BK), buf + (2 + h) * HT, wave, lane, p.wrow_max, lo_col); };
+    char* const wring = smem + XRING;
+    auto xslot = [&](int kt) { return smem + (XR == 3 ? kt % 3 : (kt & 1)) * XB; };
+    auto wslot = [&](int kt) { return wring + (kt & 1) * XB; };
+    auto req_x = [&](int h, int kt) { stage_tile<T, false, 128, 8>(A, p.lda, m0 + 128 * h, acol(kt), xslot(kt) + h * HT, wave, lane, p.arow_max, lo_col); };
+    auto req_w = [&](int h, int kt) { stage_tile<T, true, 128, 8>(W, p.ldw, n0 + 128 * h, kt * (X3 ? 32 : BK), wslot(kt) + h * HT, wave, lane, p.wrow_max, lo_col); };
 
     f4 acc[4][8];  // [ni][mi]
 #pragma unroll
@@ -427,15 +436,16 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     // fragment byte offsets inside this wave's X half-tile / W half-tile (kk = 0; kk = 1 flips chunk bit 2): fragment i adds 2048 (X) / 512 (W)
     const int xo = wm * HT + s * 128, xs = (s >> 1) & 7;
     const int wr0 = (wn & 1) * 64 + (s >> 2) * 16 + (s & 3);
-    const int wo = (2 + (wn >> 1)) * HT + wr0 * 128, ws = swz_w(wr0);
+    const int wo = (wn >> 1) * HT + wr0 * 128, ws = swz_w(wr0);   // (relative to the W buffer of the K tile)
     const int xoff0 = xo + ((g ^ xs) << 4), xoff1 = xo + (((4 + g) ^ xs) << 4);
     const int woff0 = wo + ((g ^ ws) << 4), woff1 = wo + (((4 + g) ^ ws) << 4);
 
-    // prologue: K tile 0 complete, the W halves of K tile 1 in flight
-    req_x(0, 0, smem); req_x(1, 0, smem); req_w(0, 0, smem); req_w(1, 0, smem);
+    // prologue: K tile 0 complete, the W halves (XR = 3: and the X halves) of K tile 1 in flight
+    req_x(0, 0); req_x(1, 0); req_w(0, 0); req_w(1, 0);
     if (nk > 1) {
-        req_w(0, 1, smem + BUF); req_w(1, 1, smem + BUF);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (XR == 3) { req_x(0, 1); req_x(1, 1); }
+        req_w(0, 1); req_w(1, 1);
+        if (XR == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -445,13 +455,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     v8 xf[2][4], wb0[2][2], wb1[2][2];
 #define FVIT_PP_LOADX(a_)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
-        xf[0][i] = *(const v8*)(cb + xoff0 + ((a_) * 4 + i) * 2048);                                               \
-        xf[1][i] = *(const v8*)(cb + xoff1 + ((a_) * 4 + i) * 2048);                                               \
+        xf[0][i] = *(const v8*)(cx + xoff0 + ((a_) * 4 + i) * 2048);                                               \
+        xf[1][i] = *(const v8*)(cx + xoff1 + ((a_) * 4 + i) * 2048);                                               \
     }
 #define FVIT_PP_LOADW(dst_, b_)                                                                                    \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-        dst_[0][i] = *(const v8*)(cb + woff0 + ((b_) * 2 + i) * 512);                                              \
-        dst_[1][i] = *(const v8*)(cb + woff1 + ((b_) * 2 + i) * 512);                                              \
+        dst_[0][i] = *(const v8*)(cw + woff0 + ((b_) * 2 + i) * 512);                                              \
+        dst_[1][i] = *(const v8*)(cw + woff1 + ((b_) * 2 + i) * 512);                                              \
     }
 #define FVIT_PP_MFMA(a_, b_, wsrc_)                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -468,26 +478,28 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
 
     for (int kt = 0; kt < nk; ++kt) {
-        char* const cb = smem + (kt & 1) * BUF;          // this K tile
-        char* const ob = smem + ((kt & 1) ^ 1) * BUF;    // the next one
+        const char* const cx = xslot(kt);                // this K tile
+        const char* const cw = wslot(kt);
         const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
+        const bool morex = XR == 3 ? more2 : more;       // the X tile requested during this K tile: t + 2 (three-deep ring) or t + 1
+        const int ktx = kt + (XR == 3 ? 2 : 1);
         // phase 1
         FVIT_PP_LOADW(wb0, 0)
         FVIT_PP_LOADX(0)
-        if (more) req_x(0, kt + 1, ob);
+        if (morex) req_x(0, ktx);
         FVIT_PP_MFMA(0, 0, wb0)
         // phase 2
         FVIT_PP_LOADW(wb1, 1)
-        if (more) req_x(1, kt + 1, ob);
+        if (morex) req_x(1, ktx);
         FVIT_PP_MFMA(0, 1, wb1)
         // phase 3
         FVIT_PP_LOADX(1)
-        if (more2) req_w(0, kt + 2, cb);
+        if (more2) req_w(0, kt + 2);
         FVIT_PP_MFMA(1, 1, wb1)
         // phase 4
         if (more2) {
-            req_w(1, kt + 2, cb);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            req_w(1, kt + 2);
+            if (XR == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -670,6 +682,10 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
     }
     ProfScope prof(kind, flops, bytes, stream);
     const bool pp = big && tune_get("gemm_pp", 1);
+    // three-deep activation ring of the ping-pong tile (160 KiB of LDS, gemm_pp_kernel<.., XR = 3>; fvit_tune "gemm_pp_xring" = 2 restores the double buffer).
+    // r06, scripts/r06_calls/call24.sh, two interleaved rounds on FasterViT-4 batch 128: 16-bit plan 7 119 / 7 131 -> 7 180 / 7 169 images/s (+0.7 %); the dual
+    // x3 K loop of the precise plan measured equal (3 436 / 3 432 -> 3 437 / 3 442) and keeps the two-deep ring.  Bitwise the same result (same K order).
+    const bool xr3 = tune_get("gemm_pp_xring", 3) == 3;
     // "dual" K loop of the x3 operand modes (r05, fvit_tune "gemm_x3_dual" = 0 restores the K-concatenated walk): [hi | hi | lo] x [hi | lo | hi] stages the
     // hi activation tile twice and the hi weight tile twice -- six operand tiles from L2 for three products; the dual tile holds 32 contraction indices of
     // both terms of both operands -- four tiles for the same three products, and 24 instead of 16 MFMAs behind every barrier
@@ -702,6 +718,12 @@ int launch_t(const GemmCall& c, hipStream_t stream) {
             switch (c.epilogue) { case 0: FVIT_GEMM_X3(0, 4); break; case 1: FVIT_GEMM_X3(1, 4); break; default: FVIT_GEMM_X3(2, 4); break; }
         }
 #undef FVIT_GEMM_X3
+    } else if (pp && xr3) {
+        switch (c.epilogue) {
+            case 0: hipLaunchKernelGGL((gemm_pp_kernel<T, 0, false, 3>), dim3(grid), dim3(512), 0, stream, p); break;
+            case 1: hipLaunchKernelGGL((gemm_pp_kernel<T, 1, false, 3>), dim3(grid), dim3(512), 0, stream, p); break;
+            default: hipLaunchKernelGGL((gemm_pp_kernel<T, 2, false, 3>), dim3(grid), dim3(512), 0, stream, p); break;
+        }
     } else if (pp) {
         switch (c.epilogue) {
             case 0: hipLaunchKernelGGL((gemm_pp_kernel<T, 0>), dim3(grid), dim3(512), 0, stream, p); break;
