@@ -19,6 +19,9 @@ fi
 ( time timeout 900 python bench.py --record gpurun_out/${T}_bench_detail.json ) > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 echo "bench rc=$? line bytes $(tail -1 gpurun_out/${T}_bench.json | wc -c)" >> $S
 tail -4 gpurun_out/${T}_bench.err >> $S
+# the driver's launch form for N > 1 (one process per GPU under torch.distributed.run, RCCL group), here with the one GPU this box has
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-modes --no-train-step --prof-steps 0 > gpurun_out/${T}_torchrun1.log 2>&1
+echo "torchrun world-1 rc=$? $(grep '^{' gpurun_out/${T}_torchrun1.log | tail -1 | cut -c1-160)" >> $S
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-modes --no-train-step > $R/gpurun_out/${T}_prof_stdout.log 2>&1
 echo "rocprof stats rc=$?" >> $R/$S
