@@ -28,7 +28,7 @@ FVIT_PROF_KINDS = 11
 EXPORTED_SYMBOLS = (
     "fvit_abi_version", "fvit_last_error", "fvit_attention_spad", "fvit_attention_dense", "fvit_stage_workspace_bytes", "fvit_workspace_init",
     "fvit_hat_stage_forward", "fvit_hat_block_forward", "fvit_token_init", "fvit_window_partition", "fvit_window_reverse", "fvit_gemm_bias_act",
-    "fvit_gemm_residual", "fvit_gemm_terms", "fvit_gemm_residual_splitk", "fvit_gemm_terms_lo", "fvit_window_attention_terms",
+    "fvit_gemm_residual", "fvit_gemm_terms", "fvit_gemm_residual_splitk", "fvit_gemm_terms_lo", "fvit_window_attention_terms", "fvit_window_attention_long_terms",
     "fvit_gather_layernorm_terms", "fvit_win_mlp_fused_terms", "fvit_win_mlp_split_bytes", "fvit_win_mlp_fused_split", "fvit_win_block_fused_split",
     "fvit_win_block_fused_terms", "fvit_attn_block_fused_terms", "fvit_ct_block_fused_terms", "fvit_window_attention", "fvit_window_attention_long",
     "fvit_gather_layernorm", "fvit_ln_gemm_supported", "fvit_ln_gemm", "fvit_attn_block_supported", "fvit_attn_block_fused",
@@ -143,6 +143,8 @@ def _declare(lib):
     lib.fvit_gemm_terms_lo.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.fvit_window_attention_terms.restype = C.c_int
     lib.fvit_window_attention_terms.argtypes = [i32, vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, f32, vp]
+    lib.fvit_window_attention_long_terms.restype = C.c_int
+    lib.fvit_window_attention_long_terms.argtypes = [i32, vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]
     lib.fvit_gather_layernorm_terms.restype = C.c_int
     lib.fvit_gather_layernorm_terms.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, f32, i32, i32, i32, vp]
     lib.fvit_win_mlp_fused_terms.restype = C.c_int

@@ -657,6 +657,16 @@ int fvit_window_attention_long(int32_t operand_dtype, const void* qkv, int32_t l
     return launch_attention_long(a, (hipStream_t)stream);
 }
 
+int fvit_window_attention_long_terms(int32_t operand_dtype, const void* qkv, int32_t ldq, int32_t q_lo_off, void* out, int32_t ldo, int32_t o_lo_off,
+                                     const float* rel_table, int32_t rel_w, int32_t rel_ng, int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale,
+                                     fvit_stream_t stream) {
+    AttnCall a = {operand_dtype, qkv, ldq, out, ldo, nullptr, nwin, S, heads, dpad, scale, rel_table, rel_w, rel_ng, 0};
+    a.q_lo_off = q_lo_off;
+    a.o_lo_off = o_lo_off;
+    if (q_lo_off <= 0 || o_lo_off <= 0) { set_error("window_attention_long_terms: q_lo_off / o_lo_off must be > 0"); return FVIT_EINVAL; }
+    return launch_attention_long(a, (hipStream_t)stream);
+}
+
 int fvit_gather_layernorm(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB,
                           const int32_t* src_idx, const int32_t* add_idx, const float* add, float* x_out, void* n_out, int32_t ldn,
                           const float* ln_w, const float* ln_b, float eps, int32_t rows, int32_t rows_per_image, int32_t C,

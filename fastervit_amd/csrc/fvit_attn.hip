@@ -313,13 +313,12 @@ bool attention_dense(int S, int dpad) {
 
 int launch_attention(const AttnCall& c, hipStream_t stream) {
     const bool tt = c.q_lo_off > 0 || c.o_lo_off > 0;
-    if (tt && (!attention_dense(c.S, c.dpad) || c.q_lo_off < 3 * c.heads * c.dpad || c.ldq < c.q_lo_off + 3 * c.heads * c.dpad || (c.q_lo_off % 8) ||
+    if (!attention_dense(c.S, c.dpad)) return launch_attention_long(c, stream);   // (r06: the long kernel has its own two-term instances and argument checks)
+    if (tt && (c.q_lo_off < 3 * c.heads * c.dpad || c.ldq < c.q_lo_off + 3 * c.heads * c.dpad || (c.q_lo_off % 8) ||
                c.o_lo_off < c.heads * c.dpad || c.ldo < c.o_lo_off + c.heads * c.dpad || (c.o_lo_off % 8))) {
-        set_error("attention: two-term activations need a dense window (S=%d <= %d tokens) and rows holding [hi | lo] images (ldq=%d q_lo_off=%d ldo=%d o_lo_off=%d)",
-                  c.S, FVIT_MAX_DENSE_SEQ, c.ldq, c.q_lo_off, c.ldo, c.o_lo_off);
+        set_error("attention: two-term activations need rows holding [hi | lo] images (ldq=%d q_lo_off=%d ldo=%d o_lo_off=%d)", c.ldq, c.q_lo_off, c.ldo, c.o_lo_off);
         return FVIT_EINVAL;
     }
-    if (!attention_dense(c.S, c.dpad)) return launch_attention_long(c, stream);
     if (c.S <= 0 || c.nwin <= 0 || (c.dpad != 32 && c.dpad != 64 && c.dpad != 96) || (c.ldq % 8) || (c.ldo % 8) || !c.bias) {
         set_error("attention: unsupported geometry S=%d nwin=%d dpad=%d ldq=%d ldo=%d bias=%p", c.S, c.nwin, c.dpad, c.ldq, c.ldo, (const void*)c.bias);
         return FVIT_EINVAL;

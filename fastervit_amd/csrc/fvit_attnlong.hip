@@ -21,6 +21,11 @@
 //
 // Workgroup = 4 waves = 64 queries of one (window, head); K fragments come straight from global/L2 (prefetched one tile
 // ahead), V tiles are transposed through LDS once per workgroup (double-buffered, one barrier per tile).
+//
+// TT (r06; weight_terms 3 = the x3 operand modes, as fvit_attn.hip's TT instances): q, k, v are read as hi + lo images of the qkv rows (lo at column
+// q_lo_off), scores = kh.qh + kl.qh + kh.ql, the tile's probabilities are split in registers (ph = round(e), pl = round(e - ph); the running sum takes
+// the fp32 e), O += vh.ph + vl.ph + vh.pl with both V^T images in LDS, and the output leaves as hi + lo (lo at column o_lo_off).  This is what the
+// 21k 384 / 512 / 768 fine-tunes (one window of 24^2 .. 48^2 tokens) and large carrier grids needed to run the ABSOLUTE-tolerance plan (missing 6).
 #include "fvit_common.h"
 
 namespace fvit {
@@ -37,21 +42,24 @@ struct AttnLongParams {
     int nqt;                  // 64-query tiles per (window, head)
     int tab_in_lds;           // the head's table fits the dynamic LDS allocation
     float scale;
+    int q_lo_off, o_lo_off;   // TT: column offset (elements) of the lo image inside a qkv row / an output row
 };
 
 constexpr int LONG_VROW = 40;   // V^T row: 32 key slots + 8 pad elements (rows stay 16-byte aligned, bank stride broken)
 
-template <typename T, int DP>
+template <typename T, int DP, bool TT = false>
 __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
     typedef typename Op16<T>::v8 v8;
     constexpr int KD = DP / 32;   // k-steps over head_dim for the score MFMA
     constexpr int DB = DP / 16;   // output-channel blocks
     constexpr int CH = DP / 8;    // 16-byte chunks per V row
+    constexpr int NT = TT ? 2 : 1;             // operand terms
+    constexpr int VT_TILE = DP * LONG_VROW;    // elements of one V^T image of one tile
     extern __shared__ __attribute__((aligned(16))) char smem_long[];
-    // layout: [V^T tiles 2 x DP x LONG_VROW op16][kpos int32 x Spad32][table f32 x (2w-1)^2]
+    // layout: [V^T tiles 2 buffers x NT terms x DP x LONG_VROW op16][kpos int32 x Spad32][table f32 x (2w-1)^2]
     T* vt_base = (T*)smem_long;
     const int Spad32 = (p.S + 31) & ~31;
-    int* kpos = (int*)(smem_long + 2 * DP * LONG_VROW * 2);
+    int* kpos = (int*)(smem_long + 2 * NT * VT_TILE * 2);
     float* tab = (float*)(kpos + Spad32);
 
     const int tid = threadIdx.x;
@@ -82,15 +90,17 @@ __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
 
     // ---- this lane's query ----
     const int qi = qt * 64 + wave * 16 + s;
-    v8 qf[KD];
+    v8 qf[NT][KD];
 #pragma unroll
-    for (int kd = 0; kd < KD; ++kd) {
-        v8 val;
+    for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
-        if (qi < S) val = *(const v8*)(qkv + (size_t)qi * p.ldq + kd * 32 + g * 8);
-        qf[kd] = val;
-    }
+        for (int kd = 0; kd < KD; ++kd) {
+            v8 val;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
+            if (qi < S) val = *(const v8*)(qkv + tm * p.q_lo_off + (size_t)qi * p.ldq + kd * 32 + g * 8);
+            qf[tm][kd] = val;
+        }
     int qbase = -1;                                   // < 0: this query row carries no bias
     if (gtab && qi >= p.ng && qi < S) {
         const int l = qi - p.ng, y = l / p.w;
@@ -104,31 +114,35 @@ __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
 
     // staging role of this thread: 16-byte chunk e = i*256 + tid of the tile's 32 x CH chunks -> key e / CH, chunk e % CH
     constexpr int NST = (32 * CH + 255) / 256;   // 1 (DP 32, 64) or 2 (DP 96)
-    auto load_v = [&](int t, v8 (&vr)[NST]) {
+    auto load_v = [&](int t, v8 (&vr)[NT][NST]) {
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int e = i * 256 + tid, key_l = e / CH, ch = e - key_l * CH;
-            v8 val;
+        for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
-            const int key = t * 32 + key_l;
-            if (key_l < 32 && key < S) val = *(const v8*)(qkv + (size_t)key * p.ldq + 2 * HD + ch * 8);
-            vr[i] = val;
-        }
-    };
-    auto load_k = [&](int t, v8 (&kf)[2][KD]) {
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-            const int key = t * 32 + jb * 16 + s;
-#pragma unroll
-            for (int kd = 0; kd < KD; ++kd) {
+            for (int i = 0; i < NST; ++i) {
+                const int e = i * 256 + tid, key_l = e / CH, ch = e - key_l * CH;
                 v8 val;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
-                if (key < S) val = *(const v8*)(qkv + (size_t)key * p.ldq + HD + kd * 32 + g * 8);
-                kf[jb][kd] = val;
+                const int key = t * 32 + key_l;
+                if (key_l < 32 && key < S) val = *(const v8*)(qkv + tm * p.q_lo_off + (size_t)key * p.ldq + 2 * HD + ch * 8);
+                vr[tm][i] = val;
             }
-        }
+    };
+    auto load_k = [&](int t, v8 (&kf)[NT][2][KD]) {
+#pragma unroll
+        for (int tm = 0; tm < NT; ++tm)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const int key = t * 32 + jb * 16 + s;
+#pragma unroll
+                for (int kd = 0; kd < KD; ++kd) {
+                    v8 val;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
+                    if (key < S) val = *(const v8*)(qkv + tm * p.q_lo_off + (size_t)key * p.ldq + HD + kd * 32 + g * 8);
+                    kf[tm][jb][kd] = val;
+                }
+            }
     };
 
     const int ntiles = (S + 31) >> 5;
@@ -137,24 +151,26 @@ __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
 #pragma unroll
     for (int db = 0; db < DB; ++db) o[db] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    v8 vreg[NST];
+    v8 vreg[NT][NST];
     load_v(0, vreg);
-    v8 kf[2][KD];
+    v8 kf[NT][2][KD];
     load_k(0, kf);
 
     for (int t = 0; t < ntiles; ++t) {
-        T* vt = vt_base + (t & 1) * DP * LONG_VROW;
+        T* vt = vt_base + (t & 1) * NT * VT_TILE;   // hi image, then (TT) the lo image
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int e = i * 256 + tid, key_l = e / CH, ch = e - key_l * CH;
-            if (key_l < 32) {
-                const int pos = ((key_l >> 2) & 3) * 8 + ((key_l >> 4) & 1) * 4 + (key_l & 3);
+        for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vt[(ch * 8 + j) * LONG_VROW + pos] = vreg[i][j];
+            for (int i = 0; i < NST; ++i) {
+                const int e = i * 256 + tid, key_l = e / CH, ch = e - key_l * CH;
+                if (key_l < 32) {
+                    const int pos = ((key_l >> 2) & 3) * 8 + ((key_l >> 4) & 1) * 4 + (key_l & 3);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vt[tm * VT_TILE + (ch * 8 + j) * LONG_VROW + pos] = vreg[tm][i][j];
+                }
             }
-        }
         __syncthreads();   // tile t staged (and, for t = 0, the tables); buffer (t+1)&1 is free: its readers passed this barrier
-        v8 kn[2][KD];
+        v8 kn[NT][2][KD];
         if (t + 1 < ntiles) {
             load_v(t + 1, vreg);
             load_k(t + 1, kn);
@@ -167,7 +183,13 @@ __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
         for (int jb = 0; jb < 2; ++jb) {
             f4 a = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kd = 0; kd < KD; ++kd) a = Op16<T>::mfma(kf[jb][kd], qf[kd], a);
+            for (int kd = 0; kd < KD; ++kd) {
+                a = Op16<T>::mfma(kf[0][jb][kd], qf[0][kd], a);
+                if constexpr (TT) {
+                    a = Op16<T>::mfma(kf[1][jb][kd], qf[0][kd], a);
+                    a = Op16<T>::mfma(kf[0][jb][kd], qf[1][kd], a);
+                }
+            }
             const int k0 = t * 32 + jb * 16 + g * 4;
             const int4 kp = *(const int4*)(kpos + k0);
             const int kpv[4] = {kp.x, kp.y, kp.z, kp.w};
@@ -187,14 +209,16 @@ __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
         const float alpha = __expf(m - mn);
         m = mn;
         float rs = 0.f;
-        v8 pf;
+        v8 pf, pl;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float e = __expf(sc[jb][r] - mn);
                 rs += e;
-                pf[jb * 4 + r] = (T)e;
+                const T eh = (T)e;
+                pf[jb * 4 + r] = eh;
+                if constexpr (TT) pl[jb * 4 + r] = (T)(e - (float)eh);
             }
         lsum = lsum * alpha + rs;   // per-lane partial sum (alpha is identical in the 4 lanes of a query); reduced at the end
 #pragma unroll
@@ -203,13 +227,21 @@ __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] *= alpha;
             const v8 vf = *(const v8*)(vt + vrow[db]);
-            o[db] = Op16<T>::mfma(vf, pf, a);
+            a = Op16<T>::mfma(vf, pf, a);
+            if constexpr (TT) {
+                const v8 vl = *(const v8*)(vt + VT_TILE + vrow[db]);
+                a = Op16<T>::mfma(vl, pf, a);
+                a = Op16<T>::mfma(vf, pl, a);
+            }
+            o[db] = a;
         }
         if (t + 1 < ntiles) {
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
+            for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
-                for (int kd = 0; kd < KD; ++kd) kf[jb][kd] = kn[jb][kd];
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int kd = 0; kd < KD; ++kd) kf[tm][jb][kd] = kn[tm][jb][kd];
         }
     }
     lsum = sum_xor32(sum_xor16(lsum));
@@ -220,20 +252,26 @@ __global__ __launch_bounds__(256) void attn_long_kernel(AttnLongParams p) {
         T* po = (T*)p.out + ((size_t)win * S + qi) * p.ldo + head * DP + g * (DP / 4);
 #pragma unroll
         for (int hseg = 0; hseg < DB / 2; ++hseg) {
-            v8 ov;
+            v8 ov, ol;
 #pragma unroll
             for (int d2 = 0; d2 < 2; ++d2)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ov[d2 * 4 + r] = sat16<T>(o[hseg * 2 + d2][r] * inv);
+                for (int r = 0; r < 4; ++r) {
+                    const float y = o[hseg * 2 + d2][r] * inv;
+                    const T yh = sat16<T>(y);
+                    ov[d2 * 4 + r] = yh;
+                    if constexpr (TT) ol[d2 * 4 + r] = sat16<T>(y - (float)yh);
+                }
             *(v8*)(po + hseg * 8) = ov;
+            if constexpr (TT) *(v8*)(po + p.o_lo_off + hseg * 8) = ol;
         }
     }
 }
 
-template <typename T, int DP>
+template <typename T, int DP, bool TT>
 int launch_long_t(AttnLongParams& p, hipStream_t stream) {
     const int tw = 2 * p.w - 1;
-    const size_t fixed = 2 * DP * LONG_VROW * 2 + (size_t)((p.S + 31) & ~31) * 4;
+    const size_t fixed = (TT ? 2 : 1) * 2 * DP * LONG_VROW * 2 + (size_t)((p.S + 31) & ~31) * 4;
     const size_t tabb = p.rel_table ? (size_t)tw * tw * 4 : 0;
     p.tab_in_lds = tabb > 0 && fixed + tabb <= 150 * 1024;
     const size_t lds = fixed + (p.tab_in_lds ? tabb : 0);
@@ -243,13 +281,14 @@ int launch_long_t(AttnLongParams& p, hipStream_t stream) {
     }
     static DeviceOnce once;   // opt in to > 64 KiB of dynamic LDS, once per device and kernel instance
     if (once.first_on_current_device())
-        hipFuncSetAttribute((const void*)attn_long_kernel<T, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_long_kernel<T, DP, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     const int64_t grid = (int64_t)p.nwin * p.heads * p.nqt;
     if (grid > 0x7fffffff) {
         set_error("attention(long): grid too large");
         return FVIT_EINVAL;
     }
-    hipLaunchKernelGGL((attn_long_kernel<T, DP>), dim3((unsigned)grid), dim3(256), lds, stream, p);
+    prof_note(TT ? "attn_long_kernel<two-term>" : "attn_long_kernel", (int)grid);
+    hipLaunchKernelGGL((attn_long_kernel<T, DP, TT>), dim3((unsigned)grid), dim3(256), lds, stream, p);
     return check_launch("attn_long_kernel");
 }
 
@@ -264,18 +303,26 @@ int launch_attention_long(const AttnCall& c, hipStream_t stream) {
         set_error("attention(long): bias table geometry w=%d n_g=%d does not cover S=%d tokens (need n_g + w^2 == S)", c.rel_w, c.rel_ng, c.S);
         return FVIT_EINVAL;
     }
+    const bool tt = c.q_lo_off > 0 || c.o_lo_off > 0;
+    if (tt && (c.q_lo_off < 3 * c.heads * c.dpad || c.ldq < c.q_lo_off + 3 * c.heads * c.dpad || (c.q_lo_off % 8) || c.o_lo_off < c.heads * c.dpad ||
+               c.ldo < c.o_lo_off + c.heads * c.dpad || (c.o_lo_off % 8))) {
+        set_error("attention(long): two-term activations need rows holding [hi | lo] images (ldq=%d q_lo_off=%d ldo=%d o_lo_off=%d)", c.ldq, c.q_lo_off, c.ldo, c.o_lo_off);
+        return FVIT_EINVAL;
+    }
+    if (c.drop_mask) { set_error("attention(long): an attn_drop mask is not supported for windows beyond the dense kernel"); return FVIT_EINVAL; }
     AttnLongParams p;
+    p.q_lo_off = c.q_lo_off; p.o_lo_off = c.o_lo_off;
     p.qkv = c.qkv; p.out = c.out; p.rel_table = c.rel_table; p.ldq = c.ldq; p.ldo = c.ldo;
     p.nwin = c.nwin; p.S = c.S; p.heads = c.heads; p.scale = c.scale;
     p.w = c.rel_table ? c.rel_w : 1; p.ng = c.rel_table ? c.rel_ng : c.S;
     p.nqt = (c.S + 63) / 64;
     p.tab_in_lds = 0;
     const double flops = 4.0 * c.nwin * (double)c.heads * c.S * (double)c.S * (c.d > 0 && c.d <= c.dpad ? c.d : c.dpad);
-    const double bytes = 2.0 * c.nwin * (double)c.S * c.heads * c.dpad * 4.0;
+    const double bytes = (tt ? 2.0 : 1.0) * 2.0 * c.nwin * (double)c.S * c.heads * c.dpad * 4.0;
     ProfScope prof(FVIT_K_ATTENTION, flops, bytes, stream);
-#define FVIT_LONG_DP(T) (c.dpad == 32 ? launch_long_t<T, 32>(p, stream) : c.dpad == 64 ? launch_long_t<T, 64>(p, stream) : launch_long_t<T, 96>(p, stream))
-    if (c.dtype == FVIT_F16) return FVIT_LONG_DP(_Float16);
-    if (c.dtype == FVIT_BF16) return FVIT_LONG_DP(__bf16);
+#define FVIT_LONG_DP(T, TT_) (c.dpad == 32 ? launch_long_t<T, 32, TT_>(p, stream) : c.dpad == 64 ? launch_long_t<T, 64, TT_>(p, stream) : launch_long_t<T, 96, TT_>(p, stream))
+    if (c.dtype == FVIT_F16) return tt ? FVIT_LONG_DP(_Float16, true) : FVIT_LONG_DP(_Float16, false);
+    if (c.dtype == FVIT_BF16) return tt ? FVIT_LONG_DP(__bf16, true) : FVIT_LONG_DP(__bf16, false);
 #undef FVIT_LONG_DP
     set_error("attention(long): operand dtype %d not supported", c.dtype);
     return FVIT_EINVAL;

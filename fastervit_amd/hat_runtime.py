@@ -350,24 +350,17 @@ def _geometry(layer, Hp: int, Wp: int):
 
 
 def x3_unsupported_reason(layer):
-    """Why a transformer level cannot run the 'f16x3' / 'bf16x3' modes AT THE GEOMETRY IT WAS BUILT FOR (None: it can).  The x3 modes run the in-register
-    attention kernel with two-term q / k / v / P -- dense windows only (csrc/fvit_attn.hip::attention_dense) -- and have no Dropout on the softmax
-    probabilities.  A map size that differs from the built-for one is still checked in _prepare."""
+    """Why a transformer level cannot run the 'f16x3' / 'bf16x3' modes (None: it can).  The x3 modes run the attention kernels with two-term
+    q / k / v / P -- any window length since r06 (csrc/fvit_attn.hip up to FVIT_MAX_DENSE_SEQ tokens, csrc/fvit_attnlong.hip beyond) -- up to head_dim 96,
+    and have no Dropout on the softmax probabilities."""
     blk0 = layer.blocks[0]
     Cdim, heads = blk0.attn.qkv.in_features, blk0.attn.num_heads
     d = Cdim // heads
     if d > 96:
         return f"head_dim {d} > 96 has no attention kernel instance"
-    dpad = 32 if d <= 32 else (64 if d <= 64 else 96)
     hier = bool(blk0.do_sr_hat)
-    cw2 = blk0.cr_window ** 2 if hier else 0
-    seqs = [("window", layer.window_size ** 2 + cw2)]
-    if hier:
-        seqs.append(("carrier grid", int(blk0.sr_ratio[0]) * int(blk0.sr_ratio[1]) * cw2))
-    for what, n in seqs:
-        if not (1 <= n <= FVIT_MAX_DENSE_SEQ and (dpad <= 64 or n <= 128)):
-            return (f"the {what} has {n} tokens at head_dim {d} (padded {dpad}); the two-term attention kernel covers sequences up to {FVIT_MAX_DENSE_SEQ} tokens "
-                    "(128 at the 96-wide head padding). Use 'f16x2' / 'bf16x2' (two-term weights) for this geometry")
+    # (r06: every sequence length has a two-term attention kernel -- fvit_attn.hip up to FVIT_MAX_DENSE_SEQ tokens, fvit_attnlong.hip beyond: the 21k 384 /
+    #  512 / 768 fine-tunes and large carrier grids take the x3 modes too)
     for blk in layer.blocks:
         for att in (blk.attn,) + ((blk.hat_attn,) if hier and hasattr(blk, "hat_attn") else ()):
             if float(getattr(att.attn_drop, "p", 0.0) or 0.0) > 0.0:
@@ -398,16 +391,6 @@ def _prepare(layer, x_dev, Hp: int, Wp: int):
                              dev_t["up_idx"].data_ptr())
         st.tables[tkey] = (tb, dev_t, ct)
     tb, _, ctables = st.tables[tkey]
-    if terms == 3:
-        # the x3 modes run the in-register attention kernel with two-term q / k / v / P: dense windows only (fvit_attention_dense).  Say so HERE, in
-        # Python, naming the level's geometry -- not as a kernel argument error from inside the stage call
-        lib0 = _lib.lib()
-        for what, n in (("window", tb["S"]),) + ((("carrier grid", tb["G"]),) if hier else ()):
-            if not lib0.fvit_attention_dense(int(n), int(dpad)):
-                raise NotImplementedError(
-                    f"operand mode {op_name!r}: this stage's {what} has {n} tokens at head_dim {d} (padded {dpad}); the two-term attention kernel covers "
-                    f"sequences up to {FVIT_MAX_DENSE_SEQ} tokens ({128} at the 96-wide head padding). Use 'f16x2' / 'bf16x2' (two-term weights) for this "
-                    "geometry (the 21k 384 / 512 / 768 fine-tunes, FasterViT-5 / -6 with large windows).")
     sig = _signature(layer.blocks, x_dev, op_name, bool(getattr(layer, "_is_replica", False))) + (tb["S"], tb["G"])
     if st.sig != sig:
         keep = _Keep(op_dtype, terms)

@@ -247,7 +247,9 @@ int fvit_gemm_terms(int32_t operand_dtype, const void* A, int32_t lda, const voi
  *                                 out_lo_off > 0 (epilogues 0 / 1): the output is stored as two terms too; GELU then uses the
  *                                 1.5e-7-accurate erf instead of the 5e-5 polynomial;
  *   fvit_window_attention_terms   fvit_window_attention on two-term q / k / v (scores qh.kh + qh.kl + ql.kh; P and V as two terms in
- *                                 registers / LDS), output rows [hi | lo].  Dense windows only (fvit_attention_dense).
+ *                                 registers / LDS), output rows [hi | lo].  Dense windows (fvit_attention_dense);
+ *   fvit_window_attention_long_terms (r06) the same on windows beyond the dense kernel: fvit_window_attention_long with two-term q / k / v, the tile's
+ *                                 probabilities split in registers, both V^T images in LDS, output rows [hi | lo] (the 21k 384 / 512 / 768 fine-tunes).
  * The reference computes these in fp32 (FV:557-568, 398-407); this is the route to logits max-abs < 1e-3 ABSOLUTE on the deep /
  * wide variants whose logits reach |7|. */
 int fvit_gemm_terms_lo(int32_t operand_dtype, const void* A, int32_t lda, const void* Wt, int32_t ldw, const float* bias, const float* gamma,
@@ -256,6 +258,9 @@ int fvit_gemm_terms_lo(int32_t operand_dtype, const void* A, int32_t lda, const 
 int fvit_window_attention_terms(int32_t operand_dtype, const void* qkv, int32_t ldq, int32_t q_lo_off, void* out, int32_t ldo,
                                 int32_t o_lo_off, const float* bias, int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale,
                                 fvit_stream_t stream);
+int fvit_window_attention_long_terms(int32_t operand_dtype, const void* qkv, int32_t ldq, int32_t q_lo_off, void* out, int32_t ldo, int32_t o_lo_off,
+                                     const float* rel_table, int32_t rel_w, int32_t rel_ng, int32_t nwin, int32_t S, int32_t heads, int32_t dpad, float scale,
+                                     fvit_stream_t stream);
 int fvit_gather_layernorm_terms(int32_t operand_dtype, const float* srcA, int32_t rowsA, const float* srcB, int32_t rowsB,
                                 const int32_t* src_idx, const int32_t* add_idx, const float* add, float* x_out, void* n_out, int32_t ldn,
                                 int32_t lo_off, const float* ln_w, const float* ln_b, float eps, int32_t rows, int32_t rows_per_image,

@@ -301,7 +301,8 @@ def _precise_logits(name, streams=1, graph=False, join_from=None, operand="f16x3
     return y, runner, x
 
 
-@pytest.mark.parametrize("name,bar", [("fvit4_224", 5e-4), ("fvit4_anyres_576x960", 5e-4), ("fvit0_224", 3e-4)])
+@pytest.mark.parametrize("name,bar", [("fvit4_224", 5e-4), ("fvit4_anyres_576x960", 5e-4), ("fvit0_224", 3e-4),
+                                      ("fvit4_21k_384", 5e-4)])   # r06: 24 x 24 / 12 x 12 windows -- the two-term instances of the LONG attention kernel
 def test_precise_deploy_plan_meets_the_absolute_bar(name, bar):
     """BASELINE configs 3 and 5 (and the headline model) through the plan bench.py TIMES for them: two-term conv streams + f16x3 HAT operands,
     logits vs the reference's CPU forward (committed goldens), ABSOLUTE.  north_star's bar is 1e-3; asserted with 2x margin

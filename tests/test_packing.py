@@ -121,18 +121,19 @@ def test_three_term_packing_and_the_gemm_column_map():
 
 
 def test_x3_modes_are_refused_at_set_time_for_geometries_they_do_not_cover():
-    """the two-term-activation modes cover dense windows (<= 208 tokens; <= 128 at the 96-wide head padding), head_dim <= 96 and no
-    Dropout on the softmax probabilities; anything else raises in set_hat_operand_dtype, naming the level -- not at the first forward."""
+    """the two-term-activation modes cover head_dim <= 96 and no Dropout on the softmax probabilities (r06: any window length -- the long
+    attention kernel has two-term instances); anything else raises in set_hat_operand_dtype, naming the level -- not at the first forward."""
     import pytest
     import fastervit_amd
     m = fastervit_amd.create_model("faster_vit_0_224")
     m.set_hat_operand_dtype("f16x3")            # 7x7 windows + 4 carriers, head_dim 32: covered
     assert m.hat_operand_dtype == "f16x3"
     big = fastervit_amd.create_model("faster_vit_0_any_res", resolution=[512, 512], window_size=[7, 7, 16, 8], ct_size=2)   # 16 x 16 windows: 260 tokens
-    with pytest.raises(NotImplementedError, match="level 2.*window has 260 tokens"):
-        big.set_hat_operand_dtype("bf16x3")
-    big.set_hat_operand_dtype("bf16x2")         # two-term weights only: fine
-    assert big.hat_operand_dtype == "bf16x2"
+    big.set_hat_operand_dtype("bf16x3")         # r05 refused this geometry ("window has 260 tokens"); r06: fvit_attnlong.hip's two-term instances
+    assert big.hat_operand_dtype == "bf16x3" and all(lvl.hat_operand_dtype == "bf16x3" for lvl in big.levels)
+    wide = fastervit_amd.create_model("faster_vit_0_224", dim=128, num_heads=[1, 1, 1, 1])   # head_dim 512 / 1024 at the transformer levels
+    with pytest.raises(NotImplementedError, match="head_dim"):
+        wide.set_hat_operand_dtype("f16x3")
     drop = fastervit_amd.create_model("faster_vit_0_224", attn_drop_rate=0.1)
     with pytest.raises(NotImplementedError, match="attn_drop_rate"):
         drop.set_hat_operand_dtype("f16x3")
