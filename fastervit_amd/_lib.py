@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "fvit_gather_layernorm", "fvit_ln_gemm_supported", "fvit_ln_gemm", "fvit_attn_block_supported", "fvit_attn_block_fused",
     "fvit_ct_block_supported", "fvit_ct_block_fused", "fvit_win_block_supported", "fvit_win_block_fused", "fvit_win_mlp_supported",
     "fvit_win_mlp_fused", "fvit_mlp_fused_supported", "fvit_mlp_fused", "fvit_bias_act_cl", "fvit_bias_residual_cl", "fvit_layernorm2d_cl",
-    "fvit_conv3x3_nhwc", "fvit_conv3x3_nhwc_terms", "fvit_conv3x3_dense_k", "fvit_conv3x3_nhwc_dense", "fvit_conv3x3_nhwc_px_dense", "fvit_conv3x3_c128_band_supported", "fvit_conv3x3_c128_band", "fvit_stem_conv3x3s2",
+    "fvit_conv3x3_nhwc", "fvit_conv3x3_nhwc_terms", "fvit_conv3x3_dense_k", "fvit_conv3x3_patch_form", "fvit_conv3x3_nhwc_dense", "fvit_conv3x3_nhwc_px_dense", "fvit_conv3x3_c128_band_supported", "fvit_conv3x3_c128_band", "fvit_stem_conv3x3s2",
     "fvit_stem_fused", "fvit_window_attention_drop", "fvit_bwd_window_attention_drop", "fvit_global_avgpool_cl", "fvit_conv3x3_nhwc_px", "fvit_layernorm2d_px", "fvit_stem_conv3x3s2_px", "fvit_head_logits", "fvit_head_softmax_xent",
     "fvit_head_grad", "fvit_sgd_momentum", "fvit_bwd_blocks", "fvit_bwd_transpose16", "fvit_bwd_scale_cols", "fvit_bwd_gelu", "fvit_bwd_layernorm",
     "fvit_bwd_colsum_finish", "fvit_bwd_colsum16", "fvit_bwd_window_attention", "fvit_tune", "fvit_prof_enable", "fvit_prof_collect",
@@ -190,6 +190,8 @@ def _declare(lib):
     lib.fvit_bwd_window_attention_drop.argtypes = [i32, vp, i32, vp, i32, vp, i32, f32, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.fvit_global_avgpool_cl.restype = C.c_int
     lib.fvit_global_avgpool_cl.argtypes = [i32, vp, vp, i32, i32, i32, vp]
+    lib.fvit_conv3x3_patch_form.restype = C.c_int
+    lib.fvit_conv3x3_patch_form.argtypes = [i32, i32, i32, i32, i32, i32]
     lib.fvit_conv3x3_dense_k.restype = C.c_int
     lib.fvit_conv3x3_dense_k.argtypes = [i32]
     lib.fvit_conv3x3_nhwc_dense.restype = C.c_int

@@ -163,21 +163,25 @@ class DeployPlan:
                     d = torch.zeros((co, kd), dtype=m.dtype, device=m.device)
                     d[:, :9 * cv] = m[..., :cv].reshape(co, 9 * cv)
                     return d
+                # (the classic matrix next to the dense one: the patch form of the kernel -- fvit_conv3x3_patch_form, chosen per call from the map size -- takes it)
+                classic = wk.reshape(co, -1) if lo is None else torch.cat([wk.reshape(co, -1), lo.reshape(co, -1)], dim=1).contiguous()
                 wk = dense(wk) if lo is None else torch.cat([dense(wk), dense(lo)], dim=1).contiguous()
-                return wcl, wk, None, terms, cv
+                return wcl, wk, None, terms, cv, classic
             if terms == 2:   # [Cout][hi (3,3,Cin) | lo (3,3,Cin)]: fvit_conv3x3_nhwc_terms
                 wk = torch.cat([wk.reshape(co, -1), lo.reshape(co, -1)], dim=1).contiguous()
-                return wcl, wk, None, 2, cv
+                return wcl, wk, None, 2, cv, None
             if (co, ci) == (128, 128):   # the fragment-order image fvit_conv3x3_c128_band streams (level 1 of FasterViT-0)
                 wband = frag_pack_conv128(wk.reshape(128, 1152))
-        return wcl, wk, wband, 1, cv
+        return wcl, wk, wband, 1, cv, None
 
     def _conv(self, x, w, bias, stride, act, residual=None):
         """act(conv3x3(x, w) + bias) (+ residual): one fused HIP kernel when supported, else MIOpen conv + glue passes."""
-        wcl, wk, wband, wterms, cv = w
+        wcl, wk, wband, wterms, cv, wk_classic = w
         B, Ci, Hi, Wi = x.shape
         if wk is not None and x.is_contiguous(memory_format=torch.channels_last):
             Co = wk.shape[0]
+            if wk_classic is not None and _lib.lib().fvit_conv3x3_patch_form(B, Hi, Wi, Ci, Co, stride):
+                wk, cv = wk_classic, Ci   # 8 x 16 patches + halo tiles (r06): the classic [Cout][terms][3][3][Cin] rows
             Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
             out = residual if residual is not None else torch.empty((B, Co, Ho, Wo), dtype=self.dtype, device=x.device,
                                                                     memory_format=torch.channels_last)
@@ -413,11 +417,13 @@ class DeployPlan:
     def _conv_px(self, x, x_lo, w, bias, stride, act, res=None, res_lo=None, want="planes"):
         """conv3x3_kernel<.., PX>: x (+ x_lo) -> act(conv + bias) (+ res + res_lo).  ``want``: 'planes' -> (hi, lo) 16-bit planes (in place over the
         residual planes when given), 'single' -> (hi, None), 'f32' -> one fp32 channels_last map."""
-        wcl, wk, wband, wterms, cv = w
+        wcl, wk, wband, wterms, cv, wk_classic = w
         if wk is None or not x.is_contiguous(memory_format=torch.channels_last):
             raise RuntimeError("precise deploy plan: this conv shape has no implicit-GEMM kernel (channel counts must pad to multiples of 64)")
         B, Ci, Hi, Wi = x.shape
         Co = wk.shape[0]
+        if wk_classic is not None and _lib.lib().fvit_conv3x3_patch_form(B, Hi, Wi, Ci, Co, stride):
+            wk, cv = wk_classic, Ci   # the patch form takes the classic rows
         Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
         if self.zeros is None or self.zeros.device != x.device:
             self.zeros = torch.zeros(256, dtype=self.dtype, device=x.device)

@@ -78,15 +78,28 @@ __device__ __forceinline__ void dispatch_epilogue(int act, bool has_res, F&& bod
 // per-wave tile: 64 pixels x 16*NI channels; workgroup tile: 64*WM pixels x 16*NI*WN channels (WM*WN = 4 waves)
 // (r06, scripts/r06_calls/call23.sh: a 3-deep ACTIVATION ring -- X(kt + 2) requested while step kt runs, counted vmcnt, 3 x 16 + 2 x 16 KiB = still two
 // workgroups per CU -- measured equal to this double buffer on the headline and on FasterViT-4 in both plans: the K step is not waiting for the gather.)
-template <typename T, int WM, int WN, int NI, bool PX = false, bool DENSE = false>
+// HALO (r06, stride 1, WM x WN = 2 x 2): the workgroup's 128 pixels are an 8 x 16 PATCH of one image instead of 128 consecutive pixels, and the activation
+// operand is staged as the patch's 10 x 18 HALO of one 64-channel chunk -- once per chunk, double buffered -- from which the nine taps (and both weight
+// terms) read SHIFTED fragments: LDS row (py + ky) * 18 + px + kx.  The classic form gathers every (tap, chunk) tile separately: each input value crosses
+// L2 -> LDS once per tap and per N tile (and per weight term), 3.7 GB per conv at 128 x 56 x 56 x 256 -- 220 of its 650 us
+// (profiles/r06_conv3x3_kstep_ablation.log); the halo form moves 180 / 128 = 1.4 x the map per N tile.  K order: plane (hi; PX third segment: lo) > chunk >
+// weight term > tap, so the result is not bitwise the classic kernel's (same products, another summation order).  Weights in the classic layout.
+constexpr int PATCH_H = 8, PATCH_W = 16, PHALO_W = PATCH_W + 2, PHALO_ROWS = (PATCH_H + 2) * PHALO_W;   // 180 LDS rows of 128 bytes
+constexpr int PHALO_PIECES = (PHALO_ROWS + 7) / 8;      // 23 pieces of 8 rows
+constexpr int PHALO_BYTES = PHALO_PIECES * 1024;
+
+template <typename T, int WM, int WN, int NI, bool PX = false, bool DENSE = false, bool HALO = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     typedef typename Op16<T>::v8 v8;
+    static_assert(!HALO || (WM == 2 && WN == 2 && !DENSE), "halo form: 8 x 16 patches on the 2 x 2 wave grid, classic weight layout");
     constexpr int BM = 64 * WM, BN = 16 * NI * WN;
-    constexpr int X_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
+    constexpr int X_BYTES = HALO ? PHALO_BYTES : BM * BK * 2, W_BYTES = BN * BK * 2;
     constexpr int XP = BM / 8 / 4;  // 1-KiB pieces (8 rows) of the X tile each wave stages per K step
+    constexpr int HP = (PHALO_PIECES + 3) / 4;   // halo pieces per wave
     constexpr int WPIECES = BN / 8;             // 1-KiB pieces of the W tile (8 rows each)
     constexpr int WP = (WPIECES + 3) / 4;       // per wave (waves beyond WPIECES stage nothing)
-    __shared__ __attribute__((aligned(16))) char smem[2 * (X_BYTES + W_BYTES)];   // the two X tiles, then the two W tiles
+    static_assert(2 * (X_BYTES + W_BYTES) <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) char smem[2 * (X_BYTES + W_BYTES)];   // the two X tiles (halo tiles), then the two W tiles
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,6 +117,119 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
     const T* __restrict__ Z = (const T*)p.zeros;
     const int ldw = DENSE ? p.wterms * p.kd * BK : p.wterms * 9 * p.Cin;
 
+    f4 acc[NI][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, s = lane & 15;
+    // patch of this workgroup (HALO): image bimg, output rows y0 .. y0 + 7, columns x0 .. x0 + 15 (ragged patches at the right / bottom edges)
+    int bimg = 0, y0 = 0, x0 = 0;
+    if constexpr (HALO) {
+        const int tpx = (p.Wo + PATCH_W - 1) / PATCH_W, tpy = (p.Ho + PATCH_H - 1) / PATCH_H;
+        bimg = tm / (tpy * tpx);
+        const int rem = tm - bimg * (tpy * tpx);
+        const int ty = rem / tpx;
+        y0 = ty * PATCH_H;
+        x0 = (rem - ty * tpx) * PATCH_W;
+    }
+    if constexpr (HALO) {
+        // ---- per-lane halo state: the HP pieces (8 LDS rows each) this wave stages per (plane, chunk) block; LDS row r = hy * 18 + hx <-> input pixel (y0 - 1 + hy, x0 - 1 + hx) ----
+        int hoff[HP];      // element offset of the pixel's channel 0 + this lane's source chunk (valid pixels only)
+        int hvalid = 0;    // bit i: piece i of this lane reads a pixel inside the image
+        int hchunk[HP];
+#pragma unroll
+        for (int i = 0; i < HP; ++i) {
+            const int piece = wave + 4 * i;
+            const int r = piece * 8 + (lane >> 3);
+            const int hy = r / PHALO_W, hx = r - hy * PHALO_W;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            const int chunk = ((lane & 7) ^ swz_x(r)) * 8;
+            hchunk[i] = chunk;
+            const bool ok = piece < PHALO_PIECES && r < PHALO_ROWS && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            if (ok) hvalid |= 1 << i;
+            hoff[i] = ok ? ((bimg * p.Hi + iy) * p.Wi + ix) * p.Cin + chunk : 0;   // (B * H * W * Cin < 2^31: checked by the launcher)
+        }
+        const int ncc = p.Cin / BK;                            // 64-channel chunks
+        const int kpb_hi = p.wterms * 9;                       // K steps of a hi-plane block: weight terms x taps
+        const int nblk_hi = ncc, nblk_all = ncc * ((PX && p.in_lo) ? 2 : 1);
+        const int nk = nblk_hi * kpb_hi + (nblk_all - nblk_hi) * 9;
+        const T* const InLo = (PX && p.in_lo) ? (const T*)p.in_lo : In;
+        auto stage_halo = [&](int blk, char* xbuf) {
+            const bool lo = blk >= nblk_hi;
+            const T* const plane = lo ? InLo : In;
+            const int c0 = (lo ? blk - nblk_hi : blk) * BK;
+#pragma unroll
+            for (int i = 0; i < HP; ++i) {
+                const int piece = wave + 4 * i;
+                if (piece < PHALO_PIECES) {
+                    const T* src = ((hvalid >> i) & 1) ? plane + (hoff[i] + c0) : Z + hchunk[i];
+                    glds16(src, xbuf + piece * 1024);
+                }
+            }
+        };
+        // weight tile of K step (blk, kin): hi-plane blocks walk [term 0 taps 0..8 | term 1 taps 0..8], lo-plane blocks the hi image's taps
+        auto stage_w = [&](int blk, int kin, char* wbuf) {
+            const bool lo = blk >= nblk_hi;
+            const int c0 = (lo ? blk - nblk_hi : blk) * BK;
+            const int col = kin * p.Cin + c0;                  // kin = term * 9 + tap: column term * 9 * Cin + tap * Cin + c0 of the classic [hi | lo] row
+#pragma unroll
+            for (int i = 0; i < WP; ++i) {
+                const int piece = wave * WP + i;
+                if (piece < WPIECES) {
+                    const int r = piece * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ swz_w(r);
+                    glds16(W + (size_t)min(n0 + r, p.Cout - 1) * ldw + col + c * 8, wbuf + piece * 1024);
+                }
+            }
+        };
+        char* const wring = smem + 2 * X_BYTES;
+        stage_halo(0, smem);
+        stage_w(0, 0, wring);
+        int rbase[4], wrow[NI];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rbase[i] = (wm * 4 + i) * PHALO_W + s;   // LDS row of pixel (patch row wm * 4 + i, column s) for tap (0, 0)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wrow[i] = wn * 16 * NI + (s >> 2) * 4 * NI + i * 4 + (s & 3);
+        int blk = 0, kin = 0, kpb = kpb_hi, hb = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int cur = kt & 1;
+            // next K step: (blk, kin + 1) or the first step of the next block; the next block's halo is requested at the FIRST step of this block
+            int nblk_ = blk, nkin = kin + 1;
+            if (nkin == kpb) { nblk_ = blk + 1; nkin = 0; }
+            if (kt + 1 < nk) stage_w(nblk_, nkin, wring + (cur ^ 1) * W_BYTES);
+            if (kin == 0 && blk + 1 < nblk_all) stage_halo(blk + 1, smem + (hb ^ 1) * X_BYTES);
+            const char* xt = smem + hb * X_BYTES;
+            const char* wt = wring + cur * W_BYTES;
+            const int tap = kin >= 9 ? kin - 9 : kin;
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+            const int rsh = ky * PHALO_W + kx;
+            v8 xf[2][4], wf[2][NI];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = kk * 4 + g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = rbase[i] + rsh;
+                    xf[kk][i] = *(const v8*)(xt + r * 128 + ((c ^ swz_x(r)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) wf[kk][i] = *(const v8*)(wt + wrow[i] * 128 + ((c ^ swz_w(wrow[i])) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[kk][ni], xf[kk][mi], acc[ni][mi]);
+            blk = nblk_; kin = nkin;
+            if (kin == 0) { hb ^= 1; kpb = blk >= nblk_hi ? 9 : kpb_hi; }
+        }
+    } else {
     // ---- per-lane gather state for the rows this lane stages (fixed for the whole K loop) ----
     int64_t rowoff[XP];     // element offset of in[b][yo*s-1][xo*s-1][0] from the plane's base (may lie outside the image; only used when the tap is valid)
     int rowmask[XP];        // bit ky*3+kx set <=> tap inside the image
@@ -181,18 +307,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
         }
     };
 
-    f4 acc[NI][4];  // [ni][mi]
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-
     const int nk = (p.wterms + ((PX && p.in_lo) ? 1 : 0)) * nk1;
     char* const wring = smem + 2 * X_BYTES;
     stage_x(0, smem);
     stage_w(0, wring);
 
-    const int g = lane >> 4, s = lane & 15;
     // weight row for A-row slot s of fragment i: wn*16*NI + (s>>2)*4*NI + i*4 + (s&3)  => lane (g, .) owns the 4*NI
     // consecutive channels wn*16*NI + g*4*NI .. ; with NI = 4 this is the layout of fvit_gemm.hip
     int xrow[4], wrow[NI];
@@ -227,9 +346,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Op16<T>::mfma(wf[kk][ni], xf[kk][mi], acc[ni][mi]);
     }
+    }
     if (p.ablate & 8) return;
 
     // ---- epilogue: lane holds out[m][nb .. nb + 4*NI - 1] for 4 pixels m ----
+    // output pixel of row fragment mi (linear index into [B][Ho][Wo]; p.M = "no such pixel": ragged patch edge)
+    auto rowm = [&](int mi) {
+        if constexpr (HALO) {
+            const int y = y0 + wm * 4 + mi, x = x0 + s;
+            return (y < p.Ho && x < p.Wo) ? (bimg * p.Ho + y) * p.Wo + x : p.M;
+        } else {
+            return m0 + wm * 64 + mi * 16 + s;
+        }
+    };
     constexpr int NC = 4 * NI;  // consecutive channels per lane (16 or 8)
     typedef T vout __attribute__((ext_vector_type(NC)));
     const int nb = n0 + wn * 16 * NI + g * NC;
@@ -254,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const int m = m0 + wm * 64 + mi * 16 + s;
+                const int m = rowm(mi);
                 if (m < p.M) {
                     float y[NC];
 #pragma unroll
@@ -305,12 +434,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvParams p) {
         vout rvs[4];
         if (RES) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) rvs[mi] = *(const vout*)(R + (size_t)min(m0 + wm * 64 + mi * 16 + s, p.M - 1) * p.Cout + nb);
+            for (int mi = 0; mi < 4; ++mi) rvs[mi] = *(const vout*)(R + (size_t)min(rowm(mi), p.M - 1) * p.Cout + nb);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 64 + mi * 16 + s;
+            const int m = rowm(mi);
             if (m < p.M) {
                 vout rv;
                 if (RES) rv = rvs[mi];
@@ -1273,6 +1402,14 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemFusedParams p) {
 #undef FVIT_SF_MARK
 }
 
+// the patch / halo form of the implicit GEMM (conv3x3_kernel<.., HALO>) applies to this launch
+static bool patch_form_ok(const ConvParams& p) {
+    if (!tune_get("conv_patch", 1) || p.stride != 1 || p.cv || p.Cout < 128 || (p.Cin % BK)) return false;
+    if ((int64_t)p.B * p.Hi * p.Wi * p.Cin >= 0x7fffffffLL) return false;   // 32-bit element offsets of the halo rows
+    const int64_t tiles = (int64_t)p.B * ((p.Ho + PATCH_H - 1) / PATCH_H) * ((p.Wo + PATCH_W - 1) / PATCH_W);
+    return tiles * 128 * 100 <= (int64_t)p.M * (100 + tune_get("conv_patch_max_waste_pct", 10));
+}
+
 template <typename T>
 int launch_t(ConvParams& p, hipStream_t stream) {
     if (p.Cin == 64 && p.Cout == 64 && p.stride == 1 && p.wterms == 1 && !p.px && !p.cv && tune_get("conv_halo", 1)) {
@@ -1291,6 +1428,19 @@ int launch_t(ConvParams& p, hipStream_t stream) {
     // (40.6 vs 44 us at 85-86 images, but 41 vs 30 us at 83), yet end to end they lose (68.1k vs 70.0k images/s: the other stream
     // shards' kernels fill the idle slots of a partial round anyway) => opt-in knob only.
     const int narrow = tune_get("conv128_narrow", 0);
+    // r06: 8 x 16 output patches with the 10 x 18 halo of a 64-channel chunk in LDS (conv3x3_kernel<.., HALO>): stride 1, classic weight layout, 128-column
+    // tiles; only where the patch grid wastes little (fvit_tune "conv_patch_max_waste_pct", default 10): call 31, two interleaved rounds -- any-res 576 x 960 (144 x 240 and 72 x 120 maps: 0 / 6.7 % waste)
+    // +1.9 % (16-bit plan) / +2.4 % (precise plan); FasterViT-4 224 (56 x 56: 14 % waste, and the classic 36 K steps where the dense-K form walks 29) equal / -0.6 %: stays on the dense-K form
+    const bool patch = patch_form_ok(p) && (p.Cout % 128 == 0 || (p.Cout > 128 && tune_get("conv_n128_ragged", 1))) && !narrow;
+    if (patch) {
+        p.tiles_m = p.B * ((p.Ho + PATCH_H - 1) / PATCH_H) * ((p.Wo + PATCH_W - 1) / PATCH_W);
+        p.tiles_n = (p.Cout + 127) / 128;
+        const dim3 grid_(p.tiles_m * p.tiles_n);
+        prof_note(p.px ? "conv3x3_kernel<2,2,4,px,patch>" : "conv3x3_kernel<2,2,4,patch>", p.tiles_m * p.tiles_n);
+        if (p.px) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, true, false, true>), grid_, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 4, false, false, true>), grid_, dim3(256), 0, stream, p);
+        return check_launch("conv3x3_kernel<patch>");
+    }
 #define FVIT_CONV_LAUNCH(WM_, WN_, NI_, PX_)                                                                                            \
     do {                                                                                                                                \
         const dim3 grid_(p.tiles_m * p.tiles_n);                                                                                        \
@@ -1362,6 +1512,15 @@ static bool set_dense(ConvParams& p, int cin_valid) {
     p.kd = (9 * cin_valid + BK - 1) / BK;
     p.inv_cv = 1.0f / (float)cin_valid;
     return true;
+}
+
+extern "C" int fvit_conv3x3_patch_form(int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride) {
+    if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    ConvParams p;
+    p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.cv = 0;
+    p.Ho = (Hi + 2 - 3) / stride + 1; p.Wo = (Wi + 2 - 3) / stride + 1;
+    p.M = B * p.Ho * p.Wo;
+    return patch_form_ok(p) && (Cout % 128 == 0 || (Cout > 128 && tune_get("conv_n128_ragged", 1))) && !tune_get("conv128_narrow", 0) ? 1 : 0;
 }
 
 extern "C" int fvit_conv3x3_dense_k(int32_t cin_valid) { return cin_valid > 0 && cin_valid % 8 == 0 ? (9 * cin_valid + BK - 1) / BK * BK : -1; }

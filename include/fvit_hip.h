@@ -457,6 +457,10 @@ int fvit_conv3x3_nhwc_px(int32_t dtype, const void* in, const void* in_lo, const
  * STRIDE of the input map; cin_valid % 8 == 0 (a 16-byte chunk never straddles two taps).  cin_valid == Cin is the classic layout and kernel.
  * Everything else as fvit_conv3x3_nhwc_terms / fvit_conv3x3_nhwc_px.  fvit_conv3x3_dense_k returns -1 for an unsupported cin_valid. */
 int fvit_conv3x3_dense_k(int32_t cin_valid);
+/* r06: 1 when fvit_conv3x3_nhwc / _terms / _px run this shape in the PATCH form (8 x 16 output patches, the 10 x 18 halo of a 64-channel chunk staged once
+ * for all nine taps and both weight terms): stride 1, Cout >= 128, a patch grid that wastes <= fvit_tune("conv_patch_max_waste_pct") of the pixels, and
+ * fvit_tune("conv_patch") on (the default; max waste 10 %).  The patch form takes the CLASSIC weight layout (cin_valid == Cin): a caller that packs dense-K rows asks here first. */
+int fvit_conv3x3_patch_form(int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t Cout, int32_t stride);
 int fvit_conv3x3_nhwc_dense(int32_t dtype, const void* in, const void* weight, const float* bias, const void* residual,
                             void* out, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t cin_valid, int32_t Cout, int32_t stride,
                             int32_t act, int32_t weight_terms, const void* zeros, fvit_stream_t stream);

@@ -47,7 +47,8 @@ def run(name, res, act, n=24):
     else:
         _lib.tune("conv_halo", 0)
         _lib.tune("conv_ablate", int(name[5:]) if name.startswith("gemma") else 0)   # e.g. gemma3 = conv_ablate bits 1|2
-        _lib.tune("conv128_narrow", 1 if name == "gemmn" else (0 if name == "gemmw" else -1))      # 128x64 / 128x128 tiles / auto
+        _lib.tune("conv128_narrow", 1 if name == "gemmn" else 0)      # "gemmn": 128 x 64 tiles; everything else the library default (128 x 128).  (r01-r06 passed -1 for "auto",
+        #                                                                 which the library reads as non-zero = narrow: calls 29 / 30 of r06 measured the 128 x 64 form under the name "gemm")
     for i in range(3):
         conv(i, res, act)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -487,6 +487,61 @@ def test_conv3x3_dense_k(dt, code, B, Ci, Cv, Co, H, W, stride, act, res, terms)
 
 
 @pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
+@pytest.mark.parametrize("B,Ci,Co,H,W,act,res,terms", [
+    (2, 256, 256, 56, 56, 2, False, 1),     # FasterViT-4 level 0: 7 x 3.5 patches per image (ragged right column)
+    (1, 128, 128, 24, 32, 0, True, 1),      # exact patch grid, residual in place
+    (3, 128, 192, 9, 13, 1, True, 1),       # ragged in both directions + ragged last N tile
+    (2, 448, 448, 14, 20, 0, False, 2),     # two-term weights: both terms read the same halo tile
+    (2, 64, 128, 8, 16, 2, False, 1),       # one chunk, one patch per image
+    (1, 192, 256, 1, 1, 0, True, 2)])       # a single pixel
+def test_conv3x3_patch_form(dt, code, B, Ci, Co, H, W, act, res, terms):
+    """r06: the PATCH form of the implicit-GEMM conv (conv3x3_kernel<.., HALO>: 8 x 16 output patches, the 10 x 18 halo of a 64-channel chunk staged once for nine
+    taps and both weight terms; fvit_tune conv_patch) behind the same entry points: vs F.conv2d in fp32 and vs the classic form (another summation order)."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(Ci + Co + H + W)
+    x = torch.randn(B, Ci, H, W, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    wh = w.to(dt)
+    wl = (w - wh.float()).to(dt)
+    bias = torch.randn(Co, generator=g).cuda()
+    r = torch.randn(B, Co, H, W, generator=g).to(dt).cuda().contiguous(memory_format=torch.channels_last) if res else None
+    cl = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda().reshape(Co, -1)   # noqa: E731
+    wk = cl(wh) if terms == 1 else torch.cat([cl(wh), cl(wl)], dim=1).contiguous()
+    zeros = torch.zeros(256, dtype=dt, device="cuda")
+    outs = {}
+    try:
+        for form in (0, 1):
+            _lib.tune("conv_patch", form)
+            _lib.tune("conv_patch_max_waste_pct", 100000)
+            assert lib.fvit_conv3x3_patch_form(B, H, W, Ci, Co, 1) == form
+            out = torch.full((B, Co, H, W), float("nan"), dtype=dt, device="cuda").contiguous(memory_format=torch.channels_last)
+            _lib.check(lib.fvit_conv3x3_nhwc_terms(code, x.data_ptr(), wk.data_ptr(), bias.data_ptr(), r.data_ptr() if res else None, out.data_ptr(),
+                                                   B, H, W, Ci, Co, 1, act, terms, zeros.data_ptr(), _stream()), "conv3x3")
+            torch.cuda.synchronize()
+            outs[form] = out
+            if res and form == 1:
+                r2 = r.clone()
+                _lib.check(lib.fvit_conv3x3_nhwc_terms(code, x.data_ptr(), wk.data_ptr(), bias.data_ptr(), r2.data_ptr(), r2.data_ptr(), B, H, W, Ci, Co, 1,
+                                                       act, terms, zeros.data_ptr(), _stream()), "conv3x3 patch in place")
+                torch.cuda.synchronize()
+                assert torch.equal(r2, out)
+        assert lib.fvit_conv3x3_patch_form(B, H, W, Ci, Co, 2) == 0        # stride 2: never the patch form
+    finally:
+        _lib.tune("conv_patch", 1)
+        _lib.tune("conv_patch_max_waste_pct", 10)
+    wref = (wh.float() + wl.float()) if terms == 2 else wh.float()
+    ref = F.conv2d(x.float(), wref.cuda(), bias, 1, 1)
+    ref = [lambda t: t, torch.relu, F.gelu][act](ref)
+    if res:
+        ref = ref + r.float()
+    scale = max(ref.abs().max().item(), 1.0)
+    for form in (0, 1):
+        assert torch.isfinite(outs[form].float()).all()
+        assert (outs[form].float() - ref).abs().max().item() < (5e-3 if dt == torch.float16 else 3e-2) * scale
+    assert (outs[1].float() - outs[0].float()).abs().max().item() <= (2.0 ** -10 if dt == torch.float16 else 2.0 ** -7) * scale
+
+
+@pytest.mark.parametrize("dt,code", [(torch.float16, 1), (torch.bfloat16, 2)])
 @pytest.mark.parametrize("B,H,W,act,res", [(86, 28, 28, 2, False), (86, 28, 28, 0, True), (3, 28, 28, 1, True), (2, 30, 30, 0, False), (5, 1, 1, 2, True),
                                            (2, 9, 14, 0, True), (3, 33, 7, 2, False), (1, 14, 14, 0, True), (4, 5, 30, 1, False)])
 def test_conv3x3_c128_band(dt, code, B, H, W, act, res):

@@ -166,6 +166,63 @@ def test_conv3x3_px_dense_k(B, Ci, Cv, Co, H, W, stride, act, in2, res, out):
                                           B, H, W, Ci, Cv + 4, Co, stride, act, 2, zeros.data_ptr(), _stream()) != 0
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W,act,in2,res,out", [
+    (2, 256, 256, 24, 32, 2, False, 0, "single"),     # ConvBlock conv1 on an exact patch grid
+    (1, 256, 256, 20, 27, 0, False, 2, "planes"),     # conv2: two-term residual in place, ragged patches
+    (1, 128, 192, 9, 13, 0, True, 1, "f32"),          # two-term input: the lo-plane blocks follow the hi-plane blocks; ragged N tile
+    (2, 64, 128, 8, 16, 1, True, 0, "planes")])
+def test_conv3x3_px_patch_form(B, Ci, Co, H, W, act, in2, res, out):
+    """r06: the PATCH form (conv3x3_kernel<.., PX, HALO>) of fvit_conv3x3_nhwc_px vs F.conv2d in fp64: stride 1, two-term weights, optional two-term input."""
+    lib = _lib.lib()
+    dt = torch.float16
+    g = torch.Generator(device="cpu").manual_seed(Ci + Co + H + W)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    bias = torch.randn(Co, generator=g).cuda()
+    xh, xl = _split(x)
+    wh, wl = _split(w)
+    xh, xl = _cl(xh.cuda()), _cl(xl.cuda())
+    wk = torch.cat([wh.permute(0, 2, 3, 1).reshape(Co, -1), wl.permute(0, 2, 3, 1).reshape(Co, -1)], dim=1).contiguous().cuda()
+    rh = rl = None
+    if res:
+        r = torch.randn(B, Co, H, W, generator=g) * 3
+        rh, rl = _split(r)
+        rh, rl = _cl(rh.cuda()), _cl(rl.cuda())
+        if res == 1:
+            rl = None
+    zeros = torch.zeros(256, dtype=dt, device="cuda")
+    nan = float("nan")
+    oh = _cl(torch.full((B, Co, H, W), nan, dtype=dt, device="cuda")) if out != "f32" else None
+    ol = _cl(torch.full((B, Co, H, W), nan, dtype=dt, device="cuda")) if out == "planes" else None
+    of = _cl(torch.full((B, Co, H, W), nan, dtype=torch.float32, device="cuda")) if out == "f32" else None
+    p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    try:
+        _lib.tune("conv_patch", 1)
+        _lib.tune("conv_patch_max_waste_pct", 100000)
+        assert lib.fvit_conv3x3_patch_form(B, H, W, Ci, Co, 1) == 1
+        _lib.check(lib.fvit_conv3x3_nhwc_px(1, xh.data_ptr(), p(xl) if in2 else None, wk.data_ptr(), bias.data_ptr(), p(rh), p(rl), p(oh), p(ol), p(of),
+                                            B, H, W, Ci, Co, 1, act, 2, zeros.data_ptr(), _stream()), "conv3x3_px patch form")
+        torch.cuda.synchronize()
+    finally:
+        _lib.tune("conv_patch", 1)
+        _lib.tune("conv_patch_max_waste_pct", 10)
+    xin = xh.double() + (xl.double() if in2 else 0.0)
+    ref = F.conv2d(xin.cpu(), (wh.double() + wl.double()), bias.double().cpu(), 1, 1)
+    ref = [lambda t: t, torch.relu, lambda t: F.gelu(t)][act](ref)
+    if res:
+        ref = ref + rh.double().cpu() + (rl.double().cpu() if rl is not None else 0.0)
+    scale = max(ref.abs().max().item(), 1.0)
+    if out == "f32":
+        got, tol = of.double().cpu(), 2e-6 * scale
+    elif out == "planes":
+        got, tol = oh.double().cpu() + ol.double().cpu(), 2e-6 * scale
+    else:
+        got, tol = oh.double().cpu(), 6e-4 * scale
+    err = (got - ref).abs().max().item()
+    print(f"conv3x3_px patch form Ci {Ci} Co {Co} {H}x{W} act {act} in2 {in2} res {res} out {out}: max-abs {err:.2e} (tol {tol:.1e})")
+    assert torch.isfinite(got).all() and err < tol
+
+
 @pytest.mark.parametrize("C,Cv,src", [(64, 64, "planes"), (256, 196, "planes"), (448, 392, "f32"), (832, 784, "f32"), (128, 128, "single"), (1600, 1568, "f32")])
 def test_layernorm2d_px(C, Cv, src):
     lib = _lib.lib()

@@ -31,14 +31,15 @@ def test_dense_k_packing_drops_the_pad_channels_of_the_input():
             wa, _ = _fold(blk.conv1, blk.norm1)
             co, ci = wa.shape[:2]
             cop, cip = plan._cp(co), plan._cp(ci)
-            wcl, wk, wband, wt, cv = plan._cw(wa, terms=terms)
+            wcl, wk, wband, wt, cv, wk_classic = plan._cw(wa, terms=terms)
             cv8 = (ci + 7) // 8 * 8
             if cv8 == cip:
-                assert cv == cip and wk.numel() == cop * terms * 9 * cip
+                assert cv == cip and wk.numel() == cop * terms * 9 * cip and wk_classic is None
                 continue
             found += 1
             kd = (9 * cv8 + 63) // 64 * 64
             assert cv == cv8 and wt == terms and wband is None and tuple(wk.shape) == (cop, terms * kd)
+            assert tuple(wk_classic.shape) == (cop, terms * 9 * cip)    # the classic rows ride along for the patch form of the kernel
             hi = wk[:, :9 * cv].float().view(cop, 3, 3, cv)
             assert wk[:, 9 * cv:kd].abs().sum().item() == 0 and hi[co:].abs().sum().item() == 0 and hi[..., ci:].abs().sum().item() == 0
             ref = wa.to(torch.float16).float().permute(0, 2, 3, 1)
@@ -63,7 +64,7 @@ def test_precise_plan_packs_every_conv_weight_as_two_terms():
     t = plan.t
     lvl0 = m.levels[0].blocks[0]
     wa, ba = _fold(lvl0.conv1, lvl0.norm1)                       # fp32 folded conv1 + BN of the first ConvBlock
-    (wcl, wk, wband, terms, cv), bias, _, _ = t["levels"][0]["blocks"][0]
+    (wcl, wk, wband, terms, cv, _classic), bias, _, _ = t["levels"][0]["blocks"][0]
     co, ci = wa.shape[:2]
     cop, cip = plan._cp(co), plan._cp(ci)
     assert terms == 2 and wband is None and cv == cip and tuple(wk.shape) == (cop, 2 * 9 * cip) and wk.dtype == torch.float16
