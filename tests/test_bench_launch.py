@@ -122,3 +122,36 @@ def test_r05_record_compacts_with_the_new_entries():
         assert s["fast"]["value"] > s["value"] and not s["fast"]["meets_1e-3"]
     assert c["train_step"]["finite"] and c["train_step"]["value"] > 0
     assert json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_final.json")).read().strip())["value"] == c["value"]
+
+
+def test_r06_final_record_carries_the_contract():
+    """The committed r06 final record (profiles/r06_bench_final*.json, the driver-form `python bench.py` of the final evidence run) through the live compaction: the
+    contract keys, parity on ALL timed images of every configuration, the roofline of the timed region consistent with the committed kernel trace, the CPU baseline,
+    and the printed line == the compaction of the full record."""
+    import csv
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_final_detail.json")))
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    assert len(line) < bench.LINE_BUDGET and "\n" not in line
+    c = json.loads(line)
+    printed = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_final.json")).read().strip().splitlines()[-1])
+    assert printed["value"] == c["value"] and printed["ms_per_step"] == c["ms_per_step"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    assert c["n_gpus"] == 1 and c["scaling"] == "weak" and c["vs_baseline"] is None and c["data"] == "synthetic" and c["higher_is_better"] is True
+    assert abs(c["value"] - 256 * 1e3 / c["ms_per_step"]) < 0.01 * c["value"]                     # images/s = batch / step time
+    assert "faster_vit_0_224" in c["config"]["workload"] and c["config"]["global_batch"] == 256
+    assert c["parity"]["images"] == 256 and c["parity"]["logits_max_abs_err"] < 1e-3 and c["parity"]["runners_max_abs_diff"] == 0.0
+    assert len(c["secondary"]) == 2
+    assert c["secondary"][0]["parity"]["images"] == 128 and c["secondary"][1]["parity"]["images"] == 8
+    for s in c["secondary"]:
+        assert s["parity"]["meets_1e-3"] and s["parity"]["logits_max_abs_err"] < 5e-4 and s["fast"]["value"] > s["value"]
+    r = c["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    # the line's fraction is the kernel-trace (timed-region) figure: recompute it from the committed rocprofv3 summary of the same run
+    rows = [x for x in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_bench_final_fvit_kernels_by_shape.csv")))
+            if x["Name"].startswith("winmlp_kernel<f16,256,") and x["Workgroups"] == str(r["workgroups"])]
+    assert len(rows) == 1
+    tf = r["algorithmic_mflop_per_launch"] / float(rows[0]["AverageUs"])                         # MFLOP / us = TFLOP/s
+    assert abs(tf / r["peak"] - r["frac"]) < 0.05 * r["frac"]
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["cores"] >= 1
